@@ -1,0 +1,185 @@
+/*
+ * seer_hip.h -- C ABI of libseer_hip.so: the MI355X (gfx950) device kernels behind the
+ * Seer DDIM denoising hot path (SeerUNet forward + CFG + DDIM update + VAE decode).
+ *
+ * Boundary rules (all entry points):
+ *   - extern "C", plain pointers and sizes; every pointer is DEVICE memory unless it says "host".
+ *   - explicit stream (a hipStream_t passed as void*); nothing here synchronises, allocates or
+ *     keeps global state, so every call is hipGraph-capturable and thread-safe.
+ *   - returns 0 on success, a negative SEER_E* code otherwise (never throws).
+ *   - activations are token-major / channels-last bf16: [B*F, H*W, C]  (a "token row" = one latent pixel
+ *     of one frame; C contiguous).  Weights are bf16 [N][K] with K contiguous
+ *     (nn.Linear [out,in] as is; conv [Co,Ci,3,3] repacked to [Co][ky][kx][Ci]).
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the reference repo).
+ */
+#ifndef SEER_HIP_H
+#define SEER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEER_OK 0
+#define SEER_EINVAL (-22)   /* bad shape / alignment / flag combination */
+#define SEER_ENOSYS (-38)   /* shape class not built (e.g. head dim) */
+#define SEER_ELAUNCH (-5)   /* hipLaunchKernel reported an error */
+
+/* library / device info ------------------------------------------------------------------- */
+int seer_abi_version(void);                 /* bumps when a struct below changes */
+const char* seer_strerror(int code);        /* host string */
+const char* seer_build_arch(void);          /* "gfx950" */
+
+/* ---- GEMM / implicit-GEMM convolution --------------------------------------------------- */
+/* Replaces: nn.Linear (seer/models/attention.py:484-489,742,783), InflatedConv3d 1x1
+ * (attention.py:111,126; resnet.py:172) and InflatedConv3d 3x3 incl. stride-2 Downsample3D and the
+ * nearest-2x Upsample3D that precedes a conv (resnet.py:8-16,39,52-57,82,144,153).
+ *   C[m, n] = epilogue( sum_k A(m, k) * W[n, k] )
+ * A(m,k):  mode PLAIN  : A[m*lda + k] for k < K1, A2[m*lda2 + (k-K1)] for k >= K1 (channel concat of two
+ *                        tensors: the skip concat of unet_3d_blocks.py:596,712 without materialising it)
+ *          mode CONV3X3: m -> (img, oy, ox); k -> (ky, kx, ci);  X[img, oy*stride+ky-1, ox*stride+kx-1, ci]
+ *                        (zero outside), read through a nearest 2x upsample when `upsample` != 0.
+ * epilogue: + bias[n] ; + rowvec[(m / rows_per_batch), n] (the time-embedding add of resnet.py:191-193);
+ *           + residual[m*ldr + n] ; GEGLU (attention.py:791-793): W rows are interleaved in groups of 16
+ *           (16 value rows, then their 16 gate rows), output is N/2 wide: val * gelu_erf(gate).
+ * K (and K1) must be multiples of 64; N a multiple of 4 (32 for GEGLU); lda/ldc/ldr multiples of 8.
+ */
+#define SEER_GEMM_PLAIN 0
+#define SEER_GEMM_CONV3X3 1
+#define SEER_EPI_GEGLU 1u      /* fused a * gelu(g) */
+#define SEER_EPI_OUT_F32 2u    /* C is fp32 instead of bf16 */
+#define SEER_EPI_SILU 4u       /* C = silu(acc + bias) (time_embedding.linear_1) */
+#define SEER_EPI_TRANS_OUT 8u  /* store C transposed: Ct[n*ldc + m] (used for V^T in the VAE attention) */
+
+typedef struct seer_gemm_desc {
+    const void* A;          /* bf16 */
+    const void* A2;         /* bf16 or NULL */
+    const void* W;          /* bf16 [N][K] */
+    const float* bias;      /* fp32 [N] or NULL */
+    const void* residual;   /* bf16 [M][ldr] or NULL */
+    const float* rowvec;    /* fp32 [M/rows_per_batch][rowvec_ld] or NULL */
+    void* C;                /* bf16 (or fp32) [M][ldc] */
+    int32_t M, N, K, K1;
+    int32_t lda, lda2, ldr, ldc;
+    int32_t rows_per_batch, rowvec_ld;
+    int32_t mode;           /* SEER_GEMM_* */
+    uint32_t epilogue;      /* SEER_EPI_* flags */
+    /* conv geometry (mode CONV3X3): input NHWC [n_img, Hin, Win, Cin] (pre-upsample size) */
+    int32_t Hin, Win, Cin, Hout, Wout, stride, upsample;
+    /* batched GEMM (grid.z): element strides; batch<=1 means a single problem */
+    int32_t batch;
+    int64_t strideA, strideW, strideC;
+    /* tile selection: 0 = auto, else SEER_TILE_* */
+    int32_t tile;
+} seer_gemm_desc;
+
+#define SEER_TILE_AUTO 0
+#define SEER_TILE_128x128 1
+#define SEER_TILE_64x64 2
+#define SEER_TILE_128x64 3
+
+int seer_gemm_bf16(const seer_gemm_desc* desc /* host */, void* stream);
+
+/* ---- attention -------------------------------------------------------------------------- */
+/* Replaces xformers.ops.memory_efficient_attention as called from CrossAttention
+ * (attention.py:622-630: spatial self / text cross, attn_bias None) and from WindowSTempAttention
+ * (attention.py:632-703: LowerTriangularMask over window tokens ordered (f, wy, wx)).
+ *   O[b, sq, h, :] = softmax_j( scale * <Q[b,sq,h,:], K[b,j,h,:]> (+ causal mask j<=i) ) V[b,j,h,:]
+ * Q/K/V/O are addressed as ptr + b*bs + s*ss + h*d (+ element), so they can be column slices of a fused
+ * [tokens, 3C] projection output.  window_ws > 0 selects the temporal window form: the batch index runs
+ * over (window, b) and sequence position p = (f, wy, wx) maps to token f*H*W + (win_y*ws+wy)*W + win_x*ws+wx
+ * (window_partition/window_reverse of attention.py:42-69 folded into the addressing).
+ * head_dim in {40, 80, 160}; bf16 in/out, fp32 softmax statistics and accumulation.
+ */
+typedef struct seer_attn_desc {
+    const void* Q; const void* K; const void* V; void* O;   /* bf16 */
+    int64_t q_bs, k_bs, v_bs, o_bs;     /* batch strides (elements) */
+    int32_t q_ss, k_ss, v_ss, o_ss;     /* sequence(token) strides (elements) */
+    int32_t batch, heads, head_dim;
+    int32_t Sq, Sk;
+    int32_t causal;
+    float scale;
+    /* temporal windows (0 = off) */
+    int32_t window_ws, F, H, W;
+} seer_attn_desc;
+
+int seer_attn_fwd(const seer_attn_desc* desc /* host */, void* stream);
+
+/* Rotary embedding on q and k in place (rotary-embedding-torch 0.1.5 rotate_queries_or_keys as called at
+ * attention.py:649-651): first rot_dim channels of every head, interleaved pairs (x0,x1) -> (x0 c - x1 s, x1 c + x0 s),
+ * angle = fp32(pos) * freqs[j] with freqs the module's `rotary_emb.freqs` buffer (10000^(-2j/rot_dim)),
+ * pos = token index inside its batch element (f*H*W + y*W + x) + pos_offset (pos_offset = first frame * H*W under
+ * frame sharding).  seer_rotary_table fills cos_sin fp32 [T][half][2] once per (level, F); seer_rotary_inplace
+ * rotates x: bf16 [rows, ld] where head h of q occupies columns [col0_q + h*head_dim, ...) and of k [col0_k + ...). */
+int seer_rotary_table(const float* freqs, int32_t T, int32_t half, float* cos_sin, void* stream);
+int seer_rotary_inplace(void* x, int64_t rows, int32_t ld, int32_t col0_q, int32_t col0_k, int32_t heads,
+                        int32_t head_dim, int32_t rot_dim, int32_t tokens_per_batch, int32_t pos_offset,
+                        const float* cos_sin, void* stream);
+
+/* ---- normalisation ---------------------------------------------------------------------- */
+/* GroupNorm over (C/G, F, H, W) per (b, g) on channels-last data -- torch.nn.GroupNorm applied to the 5-D
+ * tensor (resnet.py:179,197; attention.py:133; unet_3d_condition.py:368).  Two sources = channel concat.
+ * stats: accumulates (sum, sumsq) into stats[b][g][2] (fp32, must be zeroed by the caller: one arena memset
+ * per UNet forward).  Under frame sharding the caller all-reduces `stats` between the two calls.
+ * apply: y = (x-mean)*rstd*gamma+beta, optional SiLU, bf16 out [rows, C1+C2]; count = elements per group over
+ * ALL shards (so mean = sum/count). */
+int seer_groupnorm_stats(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t batch,
+                         int64_t rows_per_batch, int32_t groups, float* stats, void* stream);
+int seer_groupnorm_apply(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t batch,
+                         int64_t rows_per_batch, int32_t groups, const float* stats, double count, float eps,
+                         const float* gamma, const float* beta, int32_t silu, void* y, void* stream);
+
+/* nn.LayerNorm(C) per token row (attention.py:198-200,275-277), eps 1e-5; bf16 in/out, fp32 statistics. */
+int seer_layernorm(const void* x, int64_t rows, int32_t C, int32_t ldx, const float* gamma, const float* beta,
+                   float eps, void* y, int32_t ldy, void* stream);
+
+/* softmax over rows of a bf16 [rows, n] matrix with scale (VAE mid attention, ldm/modules/diffusionmodules/model.py:186-197) */
+int seer_softmax_rows(const void* x, int64_t rows, int32_t n, int32_t ld, float scale, void* y, void* stream);
+
+/* ---- small / boundary kernels ----------------------------------------------------------- */
+/* diffusers Timesteps(320, flip_sin_to_cos, freq_shift) (unet_3d_condition.py:97,307): out[b] = [cos | sin](t*f_i)
+ * (or [sin|cos] when flip==0), fp32 [B, dim]. t: int64 [B]. */
+int seer_timestep_embedding(const int64_t* t, int32_t B, int32_t dim, int32_t flip_sin_to_cos, float freq_shift,
+                            float* out, void* stream);
+
+/* small-M linear: y[b, n] = act( sum_k f(x[b,k]) * W[n,k] + bias[n] ), f = SiLU if silu_in.  x fp32 [B,K], W bf16 [N][K],
+ * y fp32.  Used for time_embedding (unet_3d_condition.py:308) and all 22 time_emb_proj at once (resnet.py:192). */
+int seer_linear_smallm(const float* x, int32_t B, int32_t K, const void* W, const float* bias, int32_t N,
+                       int32_t silu_in, int32_t silu_out, float* y, void* stream);
+
+/* conv_in: InflatedConv3d(4->C0, 3x3, pad 1) reading the reference layout [B, Cin, F, H, W] fp32 and writing
+ * channels-last bf16 [B*F, H*W, C0] (unet_3d_condition.py:94,311).  W fp32 repacked to [3][3][Cin][C0]. */
+int seer_conv_in(const float* x, int32_t B, int32_t Cin, int32_t F, int32_t H, int32_t W_, const float* Wt,
+                 const float* bias, int32_t Cout, void* y, void* stream);
+/* conv_out: InflatedConv3d(C0->Cout(4), 3x3, pad 1) reading channels-last bf16 and writing [B, Cout, F, H, W] fp32
+ * (unet_3d_condition.py:205,370).  W fp32 [Cout][3][3][C0]. */
+int seer_conv_out(const void* x, int32_t B, int32_t C0, int32_t F, int32_t H, int32_t W_, const float* Wt,
+                  const float* bias, int32_t Cout, float* y, void* stream);
+
+/* layout / dtype conversion: fp32 [rows, C] -> bf16 (context, weights) */
+int seer_cast_f32_bf16(const float* x, int64_t n, void* y, void* stream);
+/* NHWC bf16 -> NCHW fp32 and back (VAE boundary) */
+int seer_nchw_f32_to_nhwc_bf16(const float* x, int32_t N, int32_t C, int32_t HW, void* y, void* stream);
+int seer_nhwc_bf16_to_nchw_f32(const void* x, int32_t N, int32_t C, int32_t HW, float* y, void* stream);
+
+/* ---- sampler step ------------------------------------------------------------------------ */
+/* CFG combine + DDIM update of DDIMSampler.p_sample_ddim (ldm/models/diffusion/ddim_video.py:209-238), fp32:
+ *   e   = e_uc + scale*(e_c - e_uc)            (only frames >= cond_f of the UNet output are used)
+ *   x0  = (x - sqrt(1-a_t) e)/sqrt(a_t)
+ *   x'  = sqrt(a_prev) x0 + sqrt(1-a_prev-sigma^2) e + sigma*noise
+ * eps: UNet output [2b (uc then c), C, F_total, HW] fp32 (or [b,...] with scale==1 / e_uc NULL semantics:
+ * pass cfg=0); x, x_prev, pred_x0: [b, C, F_pred, HW].  coef: device fp32 [steps][4] = (a_t, a_prev, sigma, sqrt(1-a_t)),
+ * row `index` is used (no host->device scalar copies per step, unlike ddim_video.py:219-222). */
+int seer_cfg_ddim_step(const float* eps, int32_t cfg, int32_t b, int32_t C, int32_t F_total, int32_t cond_f,
+                       int32_t HW, float scale, const float* coef, int32_t index, const float* x,
+                       const float* noise /* may be NULL when sigma==0 */, float* x_prev, float* pred_x0, void* stream);
+
+/* decoded image post-process of ddim_sample (utils/ddim_sampling_utils.py:41): clamp((x+1)/2, 0, 1) in place */
+int seer_clamp01(float* x, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEER_HIP_H */

@@ -1,0 +1,114 @@
+"""ctypes binding of libseer_hip.so (the C ABI declared in include/seer_hip.h).
+
+The library is the product: there is NO fallback.  If it is missing, `load()` raises with the build command;
+if a call returns a negative code, `check()` raises `SeerHipError` with the entry point's name.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+_LIB_PATH = _PKG / "lib" / "libseer_hip.so"
+_lib = None
+
+ABI_VERSION = 1
+
+SEER_GEMM_PLAIN = 0
+SEER_GEMM_CONV3X3 = 1
+SEER_EPI_GEGLU = 1
+SEER_EPI_OUT_F32 = 2
+SEER_EPI_SILU = 4
+SEER_EPI_TRANS_OUT = 8
+SEER_TILE_AUTO, SEER_TILE_128x128, SEER_TILE_64x64, SEER_TILE_128x64 = 0, 1, 2, 3
+
+
+class SeerHipError(RuntimeError):
+    pass
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("A2", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p),
+        ("residual", C.c_void_p), ("rowvec", C.c_void_p), ("C", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("K1", C.c_int32),
+        ("lda", C.c_int32), ("lda2", C.c_int32), ("ldr", C.c_int32), ("ldc", C.c_int32),
+        ("rows_per_batch", C.c_int32), ("rowvec_ld", C.c_int32),
+        ("mode", C.c_int32), ("epilogue", C.c_uint32),
+        ("Hin", C.c_int32), ("Win", C.c_int32), ("Cin", C.c_int32), ("Hout", C.c_int32), ("Wout", C.c_int32),
+        ("stride", C.c_int32), ("upsample", C.c_int32),
+        ("batch", C.c_int32),
+        ("strideA", C.c_int64), ("strideW", C.c_int64), ("strideC", C.c_int64),
+        ("tile", C.c_int32),
+    ]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [
+        ("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p), ("O", C.c_void_p),
+        ("q_bs", C.c_int64), ("k_bs", C.c_int64), ("v_bs", C.c_int64), ("o_bs", C.c_int64),
+        ("q_ss", C.c_int32), ("k_ss", C.c_int32), ("v_ss", C.c_int32), ("o_ss", C.c_int32),
+        ("batch", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32),
+        ("Sq", C.c_int32), ("Sk", C.c_int32), ("causal", C.c_int32), ("scale", C.c_float),
+        ("window_ws", C.c_int32), ("F", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+    ]
+
+
+_vp, _i32, _i64, _f32, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
+
+# name -> argtypes; every symbol include/seer_hip.h declares (tests/test_abi.py checks the list against the header)
+SIGNATURES = {
+    "seer_abi_version": ([], C.c_int),
+    "seer_strerror": ([C.c_int], C.c_char_p),
+    "seer_build_arch": ([], C.c_char_p),
+    "seer_gemm_bf16": ([C.POINTER(GemmDesc), _vp], C.c_int),
+    "seer_attn_fwd": ([C.POINTER(AttnDesc), _vp], C.c_int),
+    "seer_rotary_table": ([_vp, _i32, _i32, _vp, _vp], C.c_int),
+    "seer_rotary_inplace": ([_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp], C.c_int),
+    "seer_groupnorm_stats": ([_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _vp], C.c_int),
+    "seer_groupnorm_apply": ([_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _f64, _f32, _vp, _vp, _i32, _vp, _vp], C.c_int),
+    "seer_layernorm": ([_vp, _i64, _i32, _i32, _vp, _vp, _f32, _vp, _i32, _vp], C.c_int),
+    "seer_softmax_rows": ([_vp, _i64, _i32, _i32, _f32, _vp, _vp], C.c_int),
+    "seer_timestep_embedding": ([_vp, _i32, _i32, _i32, _f32, _vp, _vp], C.c_int),
+    "seer_linear_smallm": ([_vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp], C.c_int),
+    "seer_conv_in": ([_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp], C.c_int),
+    "seer_conv_out": ([_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp], C.c_int),
+    "seer_cast_f32_bf16": ([_vp, _i64, _vp, _vp], C.c_int),
+    "seer_nchw_f32_to_nhwc_bf16": ([_vp, _i32, _i32, _i32, _vp, _vp], C.c_int),
+    "seer_nhwc_bf16_to_nchw_f32": ([_vp, _i32, _i32, _i32, _vp, _vp], C.c_int),
+    "seer_cfg_ddim_step": ([_vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i32, _vp, _vp, _vp, _vp, _vp], C.c_int),
+    "seer_clamp01": ([_vp, _i64, _vp], C.c_int),
+}
+
+
+def lib_path() -> Path:
+    return Path(os.environ.get("SEER_HIP_LIB", _LIB_PATH))
+
+
+def load():
+    """dlopen libseer_hip.so and bind every entry point; raises if the library is absent or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not path.exists():
+        raise SeerHipError(
+            f"{path} not found: the HIP extension is the only compute path of seervideoldm_amd. "
+            "Build it with `python -m seervideoldm_amd.build` (hipcc, --offload-arch=gfx950).")
+    lib = C.CDLL(str(path))
+    for name, (argtypes, restype) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the .so lacks a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = restype
+    ver = lib.seer_abi_version()
+    if ver != ABI_VERSION:
+        raise SeerHipError(f"libseer_hip.so ABI {ver} != binding ABI {ABI_VERSION}: rebuild the library")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = load().seer_strerror(code).decode()
+        raise SeerHipError(f"{what} failed: {msg} ({code})")

@@ -1,0 +1,74 @@
+"""Build libseer_hip.so (gfx950) in-tree with hipcc.
+
+`python -m seervideoldm_amd.build` or `build_library()`; hipcc cross-compiles without a GPU.  The .so lands in
+seervideoldm_amd/lib/ (git-ignored, but it travels with the gpurun snapshot).
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+ROOT = PKG.parent
+CSRC = PKG / "csrc"
+LIBDIR = PKG / "lib"
+LIB = LIBDIR / "libseer_hip.so"
+SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "elementwise.hip"]
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm >= 7.0 to build libseer_hip.so for gfx950)")
+
+
+def _digest() -> str:
+    h = hashlib.sha256()
+    for p in sorted(list(CSRC.glob("*")) + [ROOT / "include" / "seer_hip.h"]):
+        if p.is_file():
+            h.update(p.name.encode())
+            h.update(p.read_bytes())
+    return h.hexdigest()
+
+
+def build_library(force: bool = False, verbose: bool = False) -> Path:
+    LIBDIR.mkdir(exist_ok=True)
+    stamp = LIBDIR / "build.sha256"
+    dig = _digest()
+    if not force and LIB.exists() and stamp.exists() and stamp.read_text().strip() == dig:
+        return LIB
+    hipcc = _hipcc()
+    objdir = LIBDIR / "obj"
+    objdir.mkdir(exist_ok=True)
+    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", f"-I{ROOT / 'include'}", f"-I{CSRC}",
+             "-fno-gpu-rdc", "-Wno-unused-result"]
+
+    def compile_one(src: str) -> Path:
+        obj = objdir / (src + ".o")
+        cmd = [hipcc, *flags, "-c", str(CSRC / src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    stamp.write_text(dig)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,307 @@
+// Flash-style attention forward for gfx950 (MI355X): head_dim 40 / 80 / 160, bf16 in/out.
+//
+// One kernel serves the three attention sites of the Seer UNet (include/seer_hip.h, seer_attn_fwd):
+//   spatial self-attention  [B*F*8, HW, d]  x [.., HW, d]      non-causal
+//   text cross-attention    [B*F*8, HW, d]  x [.., 77, d]      non-causal, Sk tail masked
+//   temporal window attn    [nW*B*8, F*ws^2, d]                causal (LowerTriangularMask), window gather folded
+//                                                              into the token addressing
+//
+// Structure (v1): 256 threads = 4 waves, each wave owns 32 queries; the block shares 64-key K/V tiles in LDS.
+//   S^T = K Q^T  by v_mfma_f32_32x32x16_bf16 with K as the A operand (rows = keys) and Q^T as the B operand, so a lane
+//   holds ONE query column: the online-softmax max/sum are in-lane over 16 registers plus one exchange with lane^32.
+//   P^T (the accumulator) is converted to bf16 in place and used directly as the B operand of
+//   O^T += V^T P^T  (accumulator-as-operand, k order 16s + 8(j>>2) + 4h + (j&3)); the V^T A-fragments come from the
+//   row-major [key][d] LDS image through ds_read_b64_tr_b16 (hardware transpose), so V is never transposed in memory.
+//   No S x S matrix, no P round trip through LDS.
+// LDS images: K rows padded to an odd number of 16-byte chunks (conflict-free ds_read_b128 by key row);
+//             V row stride == 64 or 192 (mod 256) bytes (conflict-free transposed reads of 4 key rows).
+#include "seer_common.h"
+
+namespace {
+
+constexpr int KT = 64;            // keys per LDS tile
+constexpr float kNegInf = -__builtin_inff();
+
+template <int D>
+struct AttnCfg {
+    static constexpr int DP = (D + 15) / 16 * 16;      // contraction length of QK^T (zero padded)
+    static constexpr int KSTEPS = DP / 16;
+    static constexpr int NDT = (D + 31) / 32;          // 32-row d tiles of O^T
+    static constexpr int DV = NDT * 32;
+    static constexpr int KRS = DP + 8;                 // K row stride (elements): odd number of 16-B chunks
+    static constexpr int VRS = DV < 96 ? 96 : DV;      // V row stride (elements): 192 B or 320 B
+    static constexpr int CH = D / 8;                   // 16-byte chunks per row in global memory
+    static constexpr int NCH = (KT * CH + 255) / 256;  // chunks per thread per tile (K or V)
+    static constexpr size_t LDS_BYTES = (size_t)KT * (KRS + VRS) * 2;
+};
+
+struct TokMap {
+    int ws_log2;   // -1: identity
+    int HW, W_, wy0, wx0;
+    __device__ __forceinline__ int operator()(int pos) const {
+        if (ws_log2 < 0) return pos;
+        const int ws2 = 2 * ws_log2;
+        const int f = pos >> ws2;
+        const int rem = pos & ((1 << ws2) - 1);
+        const int wy = rem >> ws_log2, wx = rem & ((1 << ws_log2) - 1);
+        return f * HW + (wy0 + wy) * W_ + wx0 + wx;
+    }
+};
+
+template <int D>
+__global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, const int ws_log2) {
+    using C = AttnCfg<D>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16* Ks = reinterpret_cast<bf16*>(smem);           // [KT][KRS]
+    bf16* Vs = Ks + KT * C::KRS;                        // [KT][VRS]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 31, lh = lane >> 5;
+
+    // ---- batch decode
+    const int y = blockIdx.y;
+    const int head = y % p.heads;
+    int b = y / p.heads;
+    TokMap tok;
+    tok.ws_log2 = ws_log2;
+    tok.HW = p.H * p.W;
+    tok.W_ = p.W;
+    tok.wy0 = tok.wx0 = 0;
+    if (ws_log2 >= 0) {
+        const int win = b / p.batch;
+        b = b - win * p.batch;
+        const int nwx = p.W >> ws_log2;
+        tok.wy0 = (win / nwx) << ws_log2;
+        tok.wx0 = (win % nwx) << ws_log2;
+    }
+    const bf16* __restrict__ Qg = reinterpret_cast<const bf16*>(p.Q) + (int64_t)b * p.q_bs + head * D;
+    const bf16* __restrict__ Kg = reinterpret_cast<const bf16*>(p.K) + (int64_t)b * p.k_bs + head * D;
+    const bf16* __restrict__ Vg = reinterpret_cast<const bf16*>(p.V) + (int64_t)b * p.v_bs + head * D;
+    bf16* __restrict__ Og = reinterpret_cast<bf16*>(p.O) + (int64_t)b * p.o_bs + head * D;
+
+    const int qblk0 = blockIdx.x * 128;
+    const int q0 = qblk0 + wave * 32;             // first query of this wave
+    const bool wave_active = q0 < p.Sq;
+    const int qi = q0 + lq;                       // this lane's query (sequence position)
+    const int qi_c = qi < p.Sq ? qi : p.Sq - 1;
+
+    // ---- zero the K pad columns once (D=40: elements 40..47 take part in the contraction)
+    if constexpr (C::DP != D) {
+        for (int r = tid; r < KT; r += 256) {
+            *reinterpret_cast<u32x4*>(Ks + r * C::KRS + (C::DP - 8)) = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+
+    // ---- Q fragments (B operand: col = query, k = 8h + j inside each 16-wide step)
+    bf16x8 qf[C::KSTEPS];
+    {
+        const bf16* qrow = Qg + (int64_t)tok(qi_c) * p.q_ss;
+#pragma unroll
+        for (int s = 0; s < C::KSTEPS; ++s) {
+            const int e0 = 16 * s + 8 * lh;
+            if (e0 + 8 <= D) {
+                qf[s] = *reinterpret_cast<const bf16x8*>(qrow + e0);
+            } else {
+                u32x4 zz = {0u, 0u, 0u, 0u};
+                qf[s] = __builtin_bit_cast(bf16x8, zz);
+            }
+        }
+    }
+
+    f32x16 oacc[C::NDT];
+#pragma unroll
+    for (int t = 0; t < C::NDT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+    float m_run = kNegInf;      // running max (log2 domain, already scaled)
+    float l_run = 0.f;          // partial row sum over this lane-half's keys
+    const float cscale = p.scale * 1.4426950408889634f;
+
+    // keys this block needs: causal -> up to the last query of the block
+    int k_end = p.Sk;
+    if (p.causal) {
+        const int lastq = min(qblk0 + 127, p.Sq - 1);
+        k_end = min(p.Sk, lastq + 1);
+    }
+    const int ntiles = (k_end + KT - 1) / KT;
+
+    u32x4 kreg[C::NCH], vreg[C::NCH];
+    auto prefetch = [&](int t) {
+        const int kt0 = t * KT;
+#pragma unroll
+        for (int i = 0; i < C::NCH; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < KT * C::CH) {
+                const int key = idx / C::CH, ch = idx - key * C::CH;
+                int kg = kt0 + key;
+                kg = kg < p.Sk ? kg : p.Sk - 1;
+                const int64_t tk = tok(kg);
+                kreg[i] = *reinterpret_cast<const u32x4*>(Kg + tk * p.k_ss + ch * 8);
+                vreg[i] = *reinterpret_cast<const u32x4*>(Vg + tk * p.v_ss + ch * 8);
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < C::NCH; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < KT * C::CH) {
+                const int key = idx / C::CH, ch = idx - key * C::CH;
+                *reinterpret_cast<u32x4*>(Ks + key * C::KRS + ch * 8) = kreg[i];
+                *reinterpret_cast<u32x4*>(Vs + key * C::VRS + ch * 8) = vreg[i];
+            }
+        }
+    };
+
+    if (ntiles > 0) prefetch(0);
+
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();          // every wave finished reading the previous tile
+        commit();
+        __syncthreads();
+        if (t + 1 < ntiles) prefetch(t + 1);
+        if (!wave_active) continue;
+
+        const int kt0 = t * KT;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int kb = kt0 + sub * 32;                 // first key of this 32-key sub tile
+            if (kb >= k_end) continue;
+            if (p.causal && kb > q0 + 31) continue;        // wave-uniform: fully above the diagonal
+
+            // ---- S^T = K Q^T  (rows = keys, cols = queries)
+            f32x16 sacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+            const bf16* krow = Ks + (sub * 32 + lq) * C::KRS + 8 * lh;
+#pragma unroll
+            for (int s = 0; s < C::KSTEPS; ++s) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + 16 * s);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc, 0, 0, 0);
+            }
+
+            // ---- scale (+ mask on boundary tiles)
+            const bool need_mask = (kb + 31 >= p.Sk) || (p.causal && (kb + 31 > q0));
+            float mx = kNegInf;
+            if (need_mask) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const bool ok = (key < p.Sk) && (!p.causal || key <= qi);
+                    const float x = ok ? sacc[r] * cscale : kNegInf;
+                    sacc[r] = x;
+                    mx = fmaxf(mx, x);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float x = sacc[r] * cscale;
+                    sacc[r] = x;
+                    mx = fmaxf(mx, x);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float m_use = (m_new == kNegInf) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);   // m_run == -inf -> 0
+            m_run = m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __builtin_amdgcn_exp2f(sacc[r] - m_use);
+                sacc[r] = e;
+                psum += e;
+            }
+            l_run = l_run * alpha + psum;
+#pragma unroll
+            for (int tt = 0; tt < C::NDT; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[tt][r] *= alpha;
+
+            // ---- P^T -> bf16 B fragments (k-step s2 uses accumulator registers 8*s2 .. 8*s2+7)
+            bf16x8 pf[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[s2][j] = (bf16)sacc[8 * s2 + j];
+
+            // ---- O^T += V^T P^T ; V^T fragments by transposed LDS reads
+            // lane group of 16: i = lane & 15 -> (q = i >> 2: key row of the 4x16 block, pcol = i & 3: 4-column group)
+            const int li = lane & 15;
+            const int g16 = (lane >> 4) & 1;
+            const bf16* vbase = Vs + (sub * 32 + 4 * lh + (li >> 2)) * C::VRS + 16 * g16 + 4 * (li & 3);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+                for (int tt = 0; tt < C::NDT; ++tt) {
+                    const bf16* a0 = vbase + (16 * s2) * C::VRS + 32 * tt;
+                    const bf16* a1 = a0 + 8 * C::VRS;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(a0));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(a1));
+                    bf16x8 vf;
+                    vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                    vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                    oacc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], oacc[tt], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- finalize: O[q][d] = O^T[d][q] / l
+    if (!wave_active) return;
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (qi < p.Sq) {
+        bf16* orow = Og + (int64_t)tok(qi) * p.o_ss;
+#pragma unroll
+        for (int tt = 0; tt < C::NDT; ++tt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = 32 * tt + 8 * g + 4 * lh;
+                if (d0 < D) {
+                    u32x2 o;
+                    o[0] = pack2(oacc[tt][4 * g + 0] * inv, oacc[tt][4 * g + 1] * inv);
+                    o[1] = pack2(oacc[tt][4 * g + 2] * inv, oacc[tt][4 * g + 3] * inv);
+                    *reinterpret_cast<u32x2*>(orow + d0) = o;
+                }
+            }
+        }
+    }
+}
+
+template <int D>
+int launch_attn(const seer_attn_desc& d, int ws_log2, hipStream_t st) {
+    int nbatch = d.batch;
+    if (ws_log2 >= 0) nbatch *= (d.H >> ws_log2) * (d.W >> ws_log2);
+    dim3 grid((d.Sq + 127) / 128, nbatch * d.heads, 1);
+    hipLaunchKernelGGL((seer_attn_kernel<D>), grid, dim3(256), AttnCfg<D>::LDS_BYTES, st, d, ws_log2);
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+}  // namespace
+
+extern "C" int seer_attn_fwd(const seer_attn_desc* desc, void* stream) {
+    if (!desc) return SEER_EINVAL;
+    const seer_attn_desc d = *desc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (!d.Q || !d.K || !d.V || !d.O) return SEER_EINVAL;
+    if (d.batch <= 0 || d.heads <= 0 || d.Sq <= 0 || d.Sk <= 0) return SEER_EINVAL;
+    if ((d.q_ss | d.k_ss | d.v_ss) % 8 || d.o_ss % 4) return SEER_EINVAL;
+    if ((d.q_bs | d.k_bs | d.v_bs) % 8 || d.o_bs % 4) return SEER_EINVAL;
+    int ws_log2 = -1;
+    if (d.window_ws > 0) {
+        if (d.window_ws != 4 && d.window_ws != 8) return SEER_EINVAL;
+        ws_log2 = d.window_ws == 4 ? 2 : 3;
+        if (d.H % d.window_ws || d.W % d.window_ws) return SEER_EINVAL;
+        if (d.Sq != d.F * d.window_ws * d.window_ws || d.Sk != d.Sq) return SEER_EINVAL;
+    }
+    switch (d.head_dim) {
+        case 40: return launch_attn<40>(d, ws_log2, st);
+        case 80: return launch_attn<80>(d, ws_log2, st);
+        case 160: return launch_attn<160>(d, ws_log2, st);
+        default: return SEER_ENOSYS;
+    }
+}

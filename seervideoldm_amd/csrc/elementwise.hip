@@ -1,0 +1,391 @@
+// Small / boundary kernels of the Seer hot path on gfx950: rotary embedding, timestep embedding, small-M linear,
+// conv_in / conv_out (layout change fused), casts, CFG + DDIM update.
+#include "seer_common.h"
+
+namespace {
+
+// ---- rotary ------------------------------------------------------------------------------------------------
+// table[pos][j] = (cos, sin)(pos * freqs[j]) in fp32, angle rounded once like the reference's einsum
+// (rotary-embedding-torch 0.1.5: freqs = einsum('..., f -> ... f', t.float(), freqs)).
+__global__ void rotary_table_kernel(const float* __restrict__ freqs, int T, int half, float* __restrict__ cs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * half) return;
+    const int pos = i / half, j = i - pos * half;
+    const float ang = (float)pos * freqs[j];
+    float s, c;
+    sincosf(ang, &s, &c);
+    cs[2 * i] = c;
+    cs[2 * i + 1] = s;
+}
+
+// one wave per token row: lane -> (which of q/k, head, 8-element chunk of the rotated prefix)
+__global__ void __launch_bounds__(256) rotary_kernel(bf16* __restrict__ x, int64_t rows, int ld, int col0_q, int col0_k,
+                                                     int heads, int head_dim, int rot_dim, int tokens_per_batch,
+                                                     int pos_offset, const float* __restrict__ cs) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int cpr = rot_dim / 8;                 // chunks per head
+    const int per_which = heads * cpr;
+    const int half = rot_dim / 2;
+    const int pos = (int)(row % tokens_per_batch) + pos_offset;
+    for (int item = lane; item < 2 * per_which; item += 64) {
+        const int which = item / per_which;
+        const int rem = item - which * per_which;
+        const int head = rem / cpr, ch = rem - head * cpr;
+        bf16* ptr = x + row * ld + (which ? col0_k : col0_q) + head * head_dim + ch * 8;
+        u32x4 v = *reinterpret_cast<u32x4*>(ptr);
+        float f[8];
+        unpack8(v, f);
+        const float* t = cs + ((int64_t)pos * half + ch * 4) * 2;
+#pragma unroll
+        for (int pi = 0; pi < 4; ++pi) {
+            const float c = t[2 * pi], s = t[2 * pi + 1];
+            const float a = f[2 * pi], b = f[2 * pi + 1];
+            f[2 * pi] = a * c - b * s;        // t*cos + rotate_half(t)*sin, rotate_half: (x0, x1) -> (-x1, x0)
+            f[2 * pi + 1] = b * c + a * s;
+        }
+        *reinterpret_cast<u32x4*>(ptr) = pack8(f);
+    }
+}
+
+// ---- timestep embedding ---------------------------------------------------------------------------------------
+__global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, int B, int dim, int flip, float shift,
+                                          float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = dim / 2;
+    if (i >= B * half) return;
+    const int b = i / half, j = i - b * half;
+    // diffusers 0.10.2 get_timestep_embedding: exponent = -ln(10000) * j / (half - shift); emb = t * exp(exponent)
+    const float expo = -9.210340371976184f * (float)j / ((float)half - shift);
+    const float arg = (float)t[b] * expf(expo);
+    float s, c;
+    sincosf(arg, &s, &c);
+    float* o = out + (int64_t)b * dim;
+    if (flip) { o[j] = c; o[half + j] = s; }
+    else { o[j] = s; o[half + j] = c; }
+}
+
+// ---- small-M linear: one wave per output feature, all B (<= 8) rows at once -----------------------------------
+template <int MAXB>
+__global__ void __launch_bounds__(256) linear_smallm_kernel(const float* __restrict__ x, int B, int K,
+                                                            const bf16* __restrict__ W, const float* __restrict__ bias,
+                                                            int N, int silu_in, int silu_out, float* __restrict__ y) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const int lane = threadIdx.x & 63;
+    float acc[MAXB];
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) acc[b] = 0.f;
+    for (int k0 = lane * 8; k0 < K; k0 += 64 * 8) {
+        const u32x4 wv = *reinterpret_cast<const u32x4*>(W + (int64_t)n * K + k0);
+        float w[8];
+        unpack8(wv, w);
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) {
+            if (b < B) {
+                const float* xr = x + (int64_t)b * K + k0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float xv = xr[e];
+                    if (silu_in) xv = silu_f(xv);
+                    acc[b] += xv * w[e];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) {
+        if (b < B) {
+            float v = wave_sum(acc[b]);
+            if (lane == 0) {
+                if (bias) v += bias[n];
+                if (silu_out) v = silu_f(v);
+                y[(int64_t)b * N + n] = v;
+            }
+        }
+    }
+}
+
+// ---- conv_in: [B, Cin, F, H, W] fp32 -> channels-last bf16 [B*F*H*W, Cout]; weights fp32 [3][3][Cin][Cout] ----
+__global__ void __launch_bounds__(256) conv_in_kernel(const float* __restrict__ x, int B, int Cin, int F, int H, int Wd,
+                                                      const float* __restrict__ Wt, const float* __restrict__ bias,
+                                                      int Cout, bf16* __restrict__ y) {
+    const int cgroups = Cout / 8;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t npix = (int64_t)B * F * H * Wd;
+    if (gid >= npix * cgroups) return;
+    const int cg = (int)(gid % cgroups);
+    const int64_t pix = gid / cgroups;
+    const int ox = (int)(pix % Wd);
+    const int oy = (int)((pix / Wd) % H);
+    const int f = (int)((pix / ((int64_t)Wd * H)) % F);
+    const int b = (int)(pix / ((int64_t)Wd * H * F));
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = bias ? bias[cg * 8 + e] : 0.f;
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy + ky - 1;
+        if (iy < 0 || iy >= H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox + kx - 1;
+            if (ix < 0 || ix >= Wd) continue;
+            for (int ci = 0; ci < Cin; ++ci) {
+                const float xv = x[((((int64_t)b * Cin + ci) * F + f) * H + iy) * Wd + ix];
+                const float* w = Wt + ((int64_t)((ky * 3 + kx) * Cin + ci)) * Cout + cg * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += xv * w[e];
+            }
+        }
+    }
+    *reinterpret_cast<u32x4*>(y + pix * Cout + cg * 8) = pack8(acc);
+}
+
+// ---- conv_out: channels-last bf16 [B*F*H*W, C0] -> [B, Cout, F, H, W] fp32; weights fp32 [Cout][3][3][C0] -------
+template <int COUT>
+__global__ void __launch_bounds__(256) conv_out_kernel(const bf16* __restrict__ x, int B, int C0, int F, int H, int Wd,
+                                                       const float* __restrict__ Wt, const float* __restrict__ bias,
+                                                       float* __restrict__ y) {
+    const int64_t pix = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t npix = (int64_t)B * F * H * Wd;
+    if (pix >= npix) return;
+    const int lane = threadIdx.x & 63;
+    const int ox = (int)(pix % Wd);
+    const int oy = (int)((pix / Wd) % H);
+    const int64_t img = pix / ((int64_t)Wd * H);       // b*F + f
+    const int nch = C0 / 8;
+    float acc[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
+    for (int item = lane; item < 9 * nch; item += 64) {
+        const int tap = item / nch, ch = item - tap * nch;
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        const int iy = oy + ky - 1, ix = ox + kx - 1;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= Wd) continue;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(x + ((img * H + iy) * Wd + ix) * C0 + ch * 8);
+        float f[8];
+        unpack8(v, f);
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) {
+            const float* w = Wt + ((int64_t)o * 9 + tap) * C0 + ch * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[o] += f[e] * w[e];
+        }
+    }
+    const int f_ = (int)(img % F);
+    const int b = (int)(img / F);
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) {
+        const float v = wave_sum(acc[o]);
+        if (lane == 0) y[((((int64_t)b * COUT + o) * F + f_) * H + oy) * Wd + ox] = v + (bias ? bias[o] : 0.f);
+    }
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ x, int64_t n, bf16* __restrict__ y) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+        u32x2 o;
+        o[0] = pack2(v[0], v[1]);
+        o[1] = pack2(v[2], v[3]);
+        *reinterpret_cast<u32x2*>(y + i) = o;
+    } else {
+        for (int64_t j = i; j < n; ++j) y[j] = (bf16)x[j];
+    }
+}
+
+// [N, C, HW] fp32 <-> [N, HW, C] bf16 through a 32x32 LDS tile
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ x, int C, int HW, bf16* __restrict__ y) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const int c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, p = p0 + tx;
+        tile[i][tx] = (c < C && p < HW) ? x[((int64_t)n * C + c) * HW + p] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int p = p0 + i, c = c0 + tx;
+        if (c < C && p < HW) y[((int64_t)n * HW + p) * C + c] = (bf16)tile[tx][i];
+    }
+}
+__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const bf16* __restrict__ x, int C, int HW, float* __restrict__ y) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const int c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int p = p0 + i, c = c0 + tx;
+        tile[i][tx] = (c < C && p < HW) ? (float)x[((int64_t)n * HW + p) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, p = p0 + tx;
+        if (c < C && p < HW) y[((int64_t)n * C + c) * HW + p] = tile[tx][i];
+    }
+}
+
+// ---- CFG + DDIM update (fp32, one thread per latent element) ------------------------------------------------------
+__global__ void cfg_ddim_kernel(const float* __restrict__ eps, int cfg, int b, int C, int Ft, int cond_f, int HW,
+                                float scale, const float* __restrict__ coef, int index, const float* __restrict__ x,
+                                const float* __restrict__ noise, float* __restrict__ x_prev,
+                                float* __restrict__ pred_x0) {
+    const int Fp = Ft - cond_f;
+    const int64_t n = (int64_t)b * C * Fp * HW;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int hw = (int)(i % HW);
+    const int f = (int)((i / HW) % Fp);
+    const int c = (int)((i / ((int64_t)HW * Fp)) % C);
+    const int bi = (int)(i / ((int64_t)HW * Fp * C));
+    const int64_t eoff = (((int64_t)bi * C + c) * Ft + (f + cond_f)) * HW + hw;
+    float e;
+    if (cfg) {
+        const float eu = eps[eoff];
+        const float ec = eps[eoff + (int64_t)b * C * Ft * HW];
+        e = eu + scale * (ec - eu);
+    } else {
+        e = eps[eoff];
+    }
+    const float a_t = coef[4 * index], a_prev = coef[4 * index + 1], sigma = coef[4 * index + 2],
+                s1m = coef[4 * index + 3];
+    const float xv = x[i];
+    const float x0 = (xv - s1m * e) / sqrtf(a_t);
+    const float dir = sqrtf(1.f - a_prev - sigma * sigma) * e;
+    float nz = 0.f;
+    if (noise) nz = sigma * noise[i];
+    x_prev[i] = sqrtf(a_prev) * x0 + dir + nz;
+    if (pred_x0) pred_x0[i] = x0;
+}
+
+__global__ void clamp01_kernel(float* __restrict__ x, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float v = (x[i] + 1.0f) * 0.5f;
+        x[i] = fminf(fmaxf(v, 0.f), 1.f);
+    }
+}
+
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+}  // namespace
+
+extern "C" int seer_rotary_table(const float* freqs, int32_t T, int32_t half, float* cos_sin, void* stream) {
+    if (!freqs || !cos_sin || T <= 0 || half <= 0) return SEER_EINVAL;
+    const int n = T * half;
+    hipLaunchKernelGGL(rotary_table_kernel, dim3((n + 255) / 256), dim3(256), 0, S(stream), freqs, T, half, cos_sin);
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int seer_rotary_inplace(void* x, int64_t rows, int32_t ld, int32_t col0_q, int32_t col0_k, int32_t heads,
+                                   int32_t head_dim, int32_t rot_dim, int32_t tokens_per_batch, int32_t pos_offset,
+                                   const float* cos_sin, void* stream) {
+    if (!x || !cos_sin || rows <= 0 || heads <= 0 || rot_dim <= 0 || rot_dim % 8 || rot_dim > head_dim) return SEER_EINVAL;
+    if (ld % 8 || col0_q % 8 || col0_k % 8 || head_dim % 8 || tokens_per_batch <= 0) return SEER_EINVAL;
+    hipLaunchKernelGGL(rotary_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, S(stream),
+                       reinterpret_cast<bf16*>(x), rows, ld, col0_q, col0_k, heads, head_dim, rot_dim, tokens_per_batch,
+                       pos_offset, cos_sin);
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int seer_timestep_embedding(const int64_t* t, int32_t B, int32_t dim, int32_t flip_sin_to_cos,
+                                       float freq_shift, float* out, void* stream) {
+    if (!t || !out || B <= 0 || dim <= 0 || dim % 2) return SEER_EINVAL;
+    const int n = B * dim / 2;
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n + 255) / 256), dim3(256), 0, S(stream), t, B, dim,
+                       flip_sin_to_cos, freq_shift, out);
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int seer_linear_smallm(const float* x, int32_t B, int32_t K, const void* W, const float* bias, int32_t N,
+                                  int32_t silu_in, int32_t silu_out, float* y, void* stream) {
+    if (!x || !W || !y || B <= 0 || B > 8 || K <= 0 || K % 8 || N <= 0) return SEER_EINVAL;
+    dim3 grid((N + 3) / 4);
+    const bf16* Wb = reinterpret_cast<const bf16*>(W);
+    if (B <= 2) hipLaunchKernelGGL(linear_smallm_kernel<2>, grid, dim3(256), 0, S(stream), x, B, K, Wb, bias, N, silu_in, silu_out, y);
+    else hipLaunchKernelGGL(linear_smallm_kernel<8>, grid, dim3(256), 0, S(stream), x, B, K, Wb, bias, N, silu_in, silu_out, y);
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int seer_conv_in(const float* x, int32_t B, int32_t Cin, int32_t F, int32_t H, int32_t W_, const float* Wt,
+                            const float* bias, int32_t Cout, void* y, void* stream) {
+    if (!x || !Wt || !y || B <= 0 || Cin <= 0 || F <= 0 || H <= 0 || W_ <= 0 || Cout <= 0 || Cout % 8) return SEER_EINVAL;
+    const int64_t n = (int64_t)B * F * H * W_ * (Cout / 8);
+    hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), x, B, Cin, F, H, W_,
+                       Wt, bias, Cout, reinterpret_cast<bf16*>(y));
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int seer_conv_out(const void* x, int32_t B, int32_t C0, int32_t F, int32_t H, int32_t W_, const float* Wt,
+                             const float* bias, int32_t Cout, float* y, void* stream) {
+    if (!x || !Wt || !y || B <= 0 || C0 <= 0 || C0 % 8 || F <= 0 || H <= 0 || W_ <= 0) return SEER_EINVAL;
+    const int64_t npix = (int64_t)B * F * H * W_;
+    dim3 grid((unsigned)((npix + 3) / 4));
+    const bf16* xb = reinterpret_cast<const bf16*>(x);
+    if (Cout == 4) hipLaunchKernelGGL(conv_out_kernel<4>, grid, dim3(256), 0, S(stream), xb, B, C0, F, H, W_, Wt, bias, y);
+    else if (Cout == 3) hipLaunchKernelGGL(conv_out_kernel<3>, grid, dim3(256), 0, S(stream), xb, B, C0, F, H, W_, Wt, bias, y);
+    else return SEER_ENOSYS;
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int seer_cast_f32_bf16(const float* x, int64_t n, void* y, void* stream) {
+    if (!x || !y || n <= 0) return SEER_EINVAL;
+    const int64_t nt = (n + 3) / 4;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, S(stream), x, n,
+                       reinterpret_cast<bf16*>(y));
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int seer_nchw_f32_to_nhwc_bf16(const float* x, int32_t N, int32_t C, int32_t HW, void* y, void* stream) {
+    if (!x || !y || N <= 0 || C <= 0 || HW <= 0) return SEER_EINVAL;
+    dim3 grid((HW + 31) / 32, (C + 31) / 32, N);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, S(stream), x, C, HW, reinterpret_cast<bf16*>(y));
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+extern "C" int seer_nhwc_bf16_to_nchw_f32(const void* x, int32_t N, int32_t C, int32_t HW, float* y, void* stream) {
+    if (!x || !y || N <= 0 || C <= 0 || HW <= 0) return SEER_EINVAL;
+    dim3 grid((HW + 31) / 32, (C + 31) / 32, N);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, S(stream), reinterpret_cast<const bf16*>(x), C, HW, y);
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int seer_cfg_ddim_step(const float* eps, int32_t cfg, int32_t b, int32_t C, int32_t F_total, int32_t cond_f,
+                                  int32_t HW, float scale, const float* coef, int32_t index, const float* x,
+                                  const float* noise, float* x_prev, float* pred_x0, void* stream) {
+    if (!eps || !coef || !x || !x_prev || b <= 0 || C <= 0 || F_total <= cond_f || cond_f < 0 || HW <= 0 || index < 0)
+        return SEER_EINVAL;
+    const int64_t n = (int64_t)b * C * (F_total - cond_f) * HW;
+    hipLaunchKernelGGL(cfg_ddim_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), eps, cfg, b, C,
+                       F_total, cond_f, HW, scale, coef, index, x, noise, x_prev, pred_x0);
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int seer_clamp01(float* x, int64_t n, void* stream) {
+    if (!x || n <= 0) return SEER_EINVAL;
+    hipLaunchKernelGGL(clamp01_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), x, n);
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int seer_abi_version(void) { return 1; }
+extern "C" const char* seer_build_arch(void) { return "gfx950"; }
+extern "C" const char* seer_strerror(int code) {
+    switch (code) {
+        case SEER_OK: return "ok";
+        case SEER_EINVAL: return "invalid argument (shape/alignment/flags)";
+        case SEER_ENOSYS: return "shape class not built";
+        case SEER_ELAUNCH: return "kernel launch failed";
+        default: return "unknown error";
+    }
+}

@@ -1,0 +1,311 @@
+// bf16 MFMA GEMM / implicit-GEMM 3x3 convolution for gfx950 (MI355X).
+//
+//   C[m, n] = epilogue( sum_k A(m, k) * W[n, k] )        (see include/seer_hip.h, seer_gemm_bf16)
+//
+// Structure (v1): 256 threads = 4 waves (2 x 2), block tile BM x BN x 64, v_mfma_f32_16x16x32_bf16,
+// LDS tiles of 128-byte rows with a 16-byte-chunk XOR swizzle (chunk ^= row & 7: conflict-free
+// ds_read_b128 fragment reads), register-staged global->LDS double buffering with ONE barrier per K tile
+// (loads for tile t+1 are issued before the MFMAs of tile t and written to the other buffer after them).
+// The MFMA is issued "swapped" (W fragment as the A operand, activation fragment as the B operand) so that
+// every lane ends up holding 4 CONSECUTIVE output columns of one output row: the epilogue (bias, time-embedding
+// row vector, residual, GEGLU, SiLU) works on 4-wide vectors and stores 8 bytes per lane.
+//
+// Implicit GEMM conv: k = (ky, kx, ci); Cin % 64 == 0 so a 64-wide K tile never straddles a filter tap; the
+// tap -> pixel offset is wave-uniform scalar work, the per-row pixel decode is hoisted out of the K loop.
+#include "seer_common.h"
+
+namespace {
+
+constexpr int BK = 64;
+
+template <int BM, int BN, bool CONV, bool GEGLU>
+__global__ void __launch_bounds__(256) seer_gemm_kernel(const seer_gemm_desc p) {
+    constexpr int WTM = BM / 2, WTN = BN / 2;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int A_CH = BM / 32, B_CH = BN / 32;  // 16-byte chunks per thread per K tile
+    static_assert(!GEGLU || (TN % 2 == 0), "GEGLU needs value/gate n-tile pairs inside one wave");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16* As = reinterpret_cast<bf16*>(smem);   // [2][BM*64]
+    bf16* Bs = As + 2 * BM * BK;                // [2][BN*64]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- block -> tile mapping: XCD-contiguous chunks (blocks b and b+8 share an XCD), grouped along M
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    int wg;
+    {
+        const int L = blockIdx.x;
+        const int xcd = L & 7;
+        const int q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    }
+    constexpr int GM = 8;
+    const int group = wg / (GM * tiles_n);
+    const int first_m = group * GM;
+    const int gsz = min(tiles_m - first_m, GM);
+    const int tm = first_m + (wg % (GM * tiles_n)) % gsz;
+    const int tn = (wg % (GM * tiles_n)) / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int z = blockIdx.z;
+    const bf16* __restrict__ A = reinterpret_cast<const bf16*>(p.A) + (int64_t)z * p.strideA;
+    const bf16* __restrict__ A2 = reinterpret_cast<const bf16*>(p.A2);
+    const bf16* __restrict__ W = reinterpret_cast<const bf16*>(p.W) + (int64_t)z * p.strideW;
+
+    // ---- per-thread staging descriptors
+    const int c8 = (tid & 7) * 8;     // element offset of this thread's chunk inside the K tile
+    const int srow = tid >> 3;        // 0..31
+    int64_t a_off[A_CH];              // plain: row offset into A ; conv: image base offset
+    int64_t a_off2[A_CH];
+    int a_oy[A_CH], a_ox[A_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        int gm = m0 + srow + 32 * i;
+        gm = gm < p.M ? gm : p.M - 1;
+        if constexpr (CONV) {
+            const int hw = p.Hout * p.Wout;
+            const int img = gm / hw;
+            const int rem = gm - img * hw;
+            const int oy = rem / p.Wout;
+            a_oy[i] = oy * p.stride - 1;
+            a_ox[i] = (rem - oy * p.Wout) * p.stride - 1;
+            a_off[i] = (int64_t)img * p.Hin * p.Win * p.Cin;
+            a_off2[i] = 0;
+        } else {
+            a_off[i] = (int64_t)gm * p.lda;
+            a_off2[i] = (int64_t)gm * p.lda2;
+            a_oy[i] = a_ox[i] = 0;
+        }
+    }
+    int64_t b_off[B_CH];
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+        int gn = n0 + srow + 32 * i;
+        gn = gn < p.N ? gn : p.N - 1;
+        b_off[i] = (int64_t)gn * p.K;
+    }
+
+    u32x4 areg[A_CH], breg[B_CH];
+
+    auto load_tile = [&](int kt) {
+        const int kbase = kt * BK;
+        if constexpr (CONV) {
+            const int tap = kbase / p.Cin;
+            const int ci0 = kbase - tap * p.Cin;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int Hs = p.upsample ? p.Hin * 2 : p.Hin;
+            const int Ws = p.upsample ? p.Win * 2 : p.Win;
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) {
+                const int iy = a_oy[i] + ky, ix = a_ox[i] + kx;
+                const bool ok = (iy >= 0) & (iy < Hs) & (ix >= 0) & (ix < Ws);
+                const int sy = p.upsample ? (iy >> 1) : iy;
+                const int sx = p.upsample ? (ix >> 1) : ix;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (ok) {
+                    const bf16* src = A + a_off[i] + ((int64_t)sy * p.Win + sx) * p.Cin + ci0 + c8;
+                    v = *reinterpret_cast<const u32x4*>(src);
+                }
+                areg[i] = v;
+            }
+        } else {
+            const bool second = kbase >= p.K1;
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) {
+                const bf16* src = second ? (A2 + a_off2[i] + (kbase - p.K1) + c8) : (A + a_off[i] + kbase + c8);
+                areg[i] = *reinterpret_cast<const u32x4*>(src);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) {
+            breg[i] = *reinterpret_cast<const u32x4*>(W + b_off[i] + kbase + c8);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        bf16* as = As + buf * BM * BK;
+        bf16* bs = Bs + buf * BN * BK;
+        const int sw = ((tid & 7) ^ (srow & 7)) * 8;   // (row & 7) == (srow & 7) because rows step by 32
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) *reinterpret_cast<u32x4*>(as + (srow + 32 * i) * BK + sw) = areg[i];
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) *reinterpret_cast<u32x4*>(bs + (srow + 32 * i) * BK + sw) = breg[i];
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    const int frow = lane & 15;        // operand row inside a 16-row fragment
+    const int fq = lane >> 4;          // 16-byte chunk inside a 32-wide k-step
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const bf16* as = As + buf * BM * BK + (wm * WTM) * BK;
+        const bf16* bs = Bs + buf * BN * BK + (wn * WTN) * BK;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int sw = (((ks * 4 + fq) ^ (frow & 7)) * 8);
+            bf16x8 af[TM], wf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(as + (i * 16 + frow) * BK + sw);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(bs + (j * 16 + frow) * BK + sw);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds rows n = 4*fq + r (r = 0..3) of the 16x16 D tile, column m = frow
+    const bool out_f32 = (p.epilogue & SEER_EPI_OUT_F32) != 0;
+    const bool do_silu = (p.epilogue & SEER_EPI_SILU) != 0;
+    const bool trans = (p.epilogue & SEER_EPI_TRANS_OUT) != 0;
+    bf16* Cb = reinterpret_cast<bf16*>(p.C) + (int64_t)z * p.strideC;
+    float* Cf = reinterpret_cast<float*>(p.C) + (int64_t)z * p.strideC;
+    const bf16* R = reinterpret_cast<const bf16*>(p.residual);
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * WTM + i * 16 + frow;
+        if (m >= p.M) continue;
+        const int rb = p.rowvec ? (m / p.rows_per_batch) : 0;
+#pragma unroll
+        for (int j = 0; j < TN; j += (GEGLU ? 2 : 1)) {
+            const int n = n0 + wn * WTN + j * 16 + fq * 4;   // first of 4 consecutive GEMM columns
+            if (n >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+            if (p.bias) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += bv[r];
+            }
+            int nc = n;   // output column
+            if constexpr (GEGLU) {
+                float g[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g[r] = acc[i][j + 1][r];
+                if (p.bias) {
+                    const f32x4 bg = *reinterpret_cast<const f32x4*>(p.bias + n + 16);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) g[r] += bg[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_f(g[r]);
+                nc = ((n - fq * 4) >> 1) + fq * 4;
+            }
+            if (p.rowvec) {
+                const f32x4 tv = *reinterpret_cast<const f32x4*>(p.rowvec + (int64_t)rb * p.rowvec_ld + nc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += tv[r];
+            }
+            if (do_silu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+            }
+            if (R) {
+                const u32x2 rv = *reinterpret_cast<const u32x2*>(R + (int64_t)m * p.ldr + nc);
+                v[0] += __builtin_bit_cast(float, rv[0] << 16);
+                v[1] += __builtin_bit_cast(float, rv[0] & 0xffff0000u);
+                v[2] += __builtin_bit_cast(float, rv[1] << 16);
+                v[3] += __builtin_bit_cast(float, rv[1] & 0xffff0000u);
+            }
+            if (trans) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (out_f32) Cf[(int64_t)(nc + r) * p.ldc + m] = v[r];
+                    else Cb[(int64_t)(nc + r) * p.ldc + m] = (bf16)v[r];
+                }
+            } else if (out_f32) {
+                *reinterpret_cast<f32x4*>(Cf + (int64_t)m * p.ldc + nc) = f32x4{v[0], v[1], v[2], v[3]};
+            } else {
+                u32x2 o;
+                o[0] = pack2(v[0], v[1]);
+                o[1] = pack2(v[2], v[3]);
+                *reinterpret_cast<u32x2*>(Cb + (int64_t)m * p.ldc + nc) = o;
+            }
+        }
+    }
+}
+
+template <int BM, int BN>
+int launch_tile(const seer_gemm_desc& d, hipStream_t st) {
+    const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
+    dim3 grid(tiles_m * tiles_n, 1, d.batch > 1 ? d.batch : 1);
+    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16);
+    const bool conv = d.mode == SEER_GEMM_CONV3X3;
+    const bool geglu = (d.epilogue & SEER_EPI_GEGLU) != 0;
+    if (conv && geglu) return SEER_EINVAL;
+    if (conv) {
+        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, true, false>), grid, dim3(256), lds, st, d);
+    } else if (geglu) {
+        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, true>), grid, dim3(256), lds, st, d);
+    } else {
+        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, false>), grid, dim3(256), lds, st, d);
+    }
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+}  // namespace
+
+extern "C" int seer_gemm_bf16(const seer_gemm_desc* desc, void* stream) {
+    if (!desc) return SEER_EINVAL;
+    seer_gemm_desc d = *desc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d.M <= 0 || d.N <= 0 || d.K <= 0) return SEER_EINVAL;
+    if (d.K % BK) return SEER_EINVAL;
+    if (!d.A || !d.W || !d.C) return SEER_EINVAL;
+    const bool geglu = (d.epilogue & SEER_EPI_GEGLU) != 0;
+    if (d.N % (geglu ? 32 : 4)) return SEER_EINVAL;
+    if (d.mode == SEER_GEMM_CONV3X3) {
+        if (d.Cin <= 0 || d.Cin % BK || d.K != 9 * d.Cin) return SEER_EINVAL;
+        if (d.stride != 1 && d.stride != 2) return SEER_EINVAL;
+        if (d.Hin <= 0 || d.Win <= 0 || d.Hout <= 0 || d.Wout <= 0) return SEER_EINVAL;
+        if (d.M % (d.Hout * d.Wout)) return SEER_EINVAL;
+        d.K1 = d.K;
+    } else if (d.mode == SEER_GEMM_PLAIN) {
+        if (!d.A2) { d.K1 = d.K; d.lda2 = 0; }
+        if (d.K1 % BK || d.K1 > d.K || d.lda % 8 || (d.A2 && d.lda2 % 8)) return SEER_EINVAL;
+    } else {
+        return SEER_EINVAL;
+    }
+    if (!(d.epilogue & SEER_EPI_TRANS_OUT) && (d.ldc % 4)) return SEER_EINVAL;
+    if (d.residual && (d.ldr % 4)) return SEER_EINVAL;
+    if (d.rowvec && d.rows_per_batch <= 0) return SEER_EINVAL;
+    if (d.batch <= 1) { d.batch = 1; }
+
+    int tile = d.tile;
+    if (tile == SEER_TILE_AUTO) {
+        const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch;
+        const long t12864 = (long)((d.M + 127) / 128) * ((d.N + 63) / 64) * d.batch;
+        if (t128 >= 448 && d.N % 128 == 0) tile = SEER_TILE_128x128;
+        else if (t12864 >= 384) tile = SEER_TILE_128x64;
+        else tile = SEER_TILE_64x64;
+    }
+    switch (tile) {
+        case SEER_TILE_128x128: return launch_tile<128, 128>(d, st);
+        case SEER_TILE_128x64: return launch_tile<128, 64>(d, st);
+        case SEER_TILE_64x64: return launch_tile<64, 64>(d, st);
+        default: return SEER_EINVAL;
+    }
+}

@@ -1,0 +1,296 @@
+// HBM-bound normalisation kernels for gfx950: GroupNorm over (C/G, F, H, W) on channels-last data (statistics and
+// apply, optional SiLU, optional two-source channel concat), LayerNorm per token row, row softmax.
+// All loads/stores are 16 bytes per lane (8 bf16); statistics are fp32.
+#include "seer_common.h"
+
+namespace {
+
+constexpr int GN_RPB = 64;   // rows per block
+
+struct GnGeom {
+    int ncols;          // 16-byte chunk columns = (C1+C2)/8
+    int ncols1;         // columns that come from x1
+    int C1, C2, cpg;
+};
+
+// thread -> (row lane, chunk column) with a FIXED column per pass so that per-column constants / partial sums stay in
+// registers.  cols_per_pass = min(ncols, 256); rows_par = 256 / cols_per_pass.
+__global__ void __launch_bounds__(256) gn_stats_kernel(const bf16* __restrict__ x1, const bf16* __restrict__ x2,
+                                                       GnGeom g, int64_t rows_per_batch, int groups,
+                                                       float* __restrict__ stats) {
+    __shared__ float bins[2 * 64];   // [groups][2], groups <= 64
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    for (int i = tid; i < 2 * groups; i += 256) bins[i] = 0.f;
+    __syncthreads();
+
+    const int64_t r0 = (int64_t)blockIdx.x * GN_RPB;
+    const int64_t r1 = min(r0 + GN_RPB, rows_per_batch);
+    const int cpp = g.ncols < 256 ? g.ncols : 256;
+    const int rows_par = 256 / cpp;
+    const int rl = tid / cpp;
+    const int cl = tid - rl * cpp;
+    if (rl < rows_par) {
+        for (int cb = 0; cb < g.ncols; cb += cpp) {
+            const int col = cb + cl;
+            if (col >= g.ncols) break;
+            const bool first = col < g.ncols1;
+            const bf16* src = first ? x1 + col * 8 : x2 + (col - g.ncols1) * 8;
+            const int ld = first ? g.C1 : g.C2;
+            const int c0 = col * 8;
+            const int ga = c0 / g.cpg;
+            const int split = (ga + 1) * g.cpg - c0;   // elements [0, split) belong to ga, the rest to ga+1
+            float sa = 0.f, qa = 0.f, sb = 0.f, qb = 0.f;
+            for (int64_t r = r0 + rl; r < r1; r += rows_par) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(src + ((int64_t)b * rows_per_batch + r) * ld);
+                float f[8];
+                unpack8(v, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (e < split) { sa += f[e]; qa += f[e] * f[e]; }
+                    else { sb += f[e]; qb += f[e] * f[e]; }
+                }
+            }
+            atomicAdd(&bins[2 * ga], sa);
+            atomicAdd(&bins[2 * ga + 1], qa);
+            if (split < 8) {
+                atomicAdd(&bins[2 * (ga + 1)], sb);
+                atomicAdd(&bins[2 * (ga + 1) + 1], qb);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * groups; i += 256) atomicAdd(&stats[(int64_t)b * groups * 2 + i], bins[i]);
+}
+
+__global__ void __launch_bounds__(256) gn_apply_kernel(const bf16* __restrict__ x1, const bf16* __restrict__ x2,
+                                                       GnGeom g, int64_t rows_per_batch, int groups,
+                                                       const float* __restrict__ stats, float inv_count, float eps,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       int silu, bf16* __restrict__ y) {
+    __shared__ float mean_s[64], rstd_s[64];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    if (tid < groups) {
+        const float s = stats[((int64_t)b * groups + tid) * 2];
+        const float q = stats[((int64_t)b * groups + tid) * 2 + 1];
+        const float mean = s * inv_count;
+        float var = q * inv_count - mean * mean;
+        var = var > 0.f ? var : 0.f;
+        mean_s[tid] = mean;
+        rstd_s[tid] = rsqrtf(var + eps);
+    }
+    __syncthreads();
+
+    const int64_t r0 = (int64_t)blockIdx.x * GN_RPB;
+    const int64_t r1 = min(r0 + GN_RPB, rows_per_batch);
+    const int cpp = g.ncols < 256 ? g.ncols : 256;
+    const int rows_par = 256 / cpp;
+    const int rl = tid / cpp;
+    const int cl = tid - rl * cpp;
+    if (rl >= rows_par) return;
+    const int C = g.C1 + g.C2;
+    for (int cb = 0; cb < g.ncols; cb += cpp) {
+        const int col = cb + cl;
+        if (col >= g.ncols) break;
+        const bool first = col < g.ncols1;
+        const bf16* src = first ? x1 + col * 8 : x2 + (col - g.ncols1) * 8;
+        const int ld = first ? g.C1 : g.C2;
+        const int c0 = col * 8;
+        float sc[8], sh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int grp = (c0 + e) / g.cpg;
+            const float a = rstd_s[grp] * gamma[c0 + e];
+            sc[e] = a;
+            sh[e] = beta[c0 + e] - mean_s[grp] * a;
+        }
+        for (int64_t r = r0 + rl; r < r1; r += rows_par) {
+            const int64_t row = (int64_t)b * rows_per_batch + r;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(src + row * ld);
+            float f[8];
+            unpack8(v, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float o = f[e] * sc[e] + sh[e];
+                if (silu) o = silu_f(o);
+                f[e] = o;
+            }
+            *reinterpret_cast<u32x4*>(y + row * C + c0) = pack8(f);
+        }
+    }
+}
+
+// LayerNorm: one wave per row, the row lives in registers (<= 3 chunks of 8 per lane: C <= 1536), two-pass statistics.
+template <int MAXC>
+__global__ void __launch_bounds__(256) layernorm_kernel(const bf16* __restrict__ x, int64_t rows, int C, int ldx,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float eps, bf16* __restrict__ y, int ldy) {
+    const int lane = threadIdx.x & 63;
+    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+    const int nch = C / 8;
+    float gm[MAXC][8], bt[MAXC][8];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { gm[i][e] = gamma[ch * 8 + e]; bt[i][e] = beta[ch * 8 + e]; }
+        }
+    }
+    const float invC = 1.0f / (float)C;
+    for (int64_t r = wave_global; r < rows; r += nwaves) {
+        float f[MAXC][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(x + r * ldx + ch * 8);
+                unpack8(v, f[i]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += f[i][e];
+            }
+        }
+        const float mean = wave_sum(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = f[i][e] - mean; q += d * d; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) * invC + eps);
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (f[i][e] - mean) * rstd * gm[i][e] + bt[i][e];
+                *reinterpret_cast<u32x4*>(y + r * ldy + ch * 8) = pack8(o);
+            }
+        }
+    }
+}
+
+// row softmax(x * scale): one wave per row, n <= 64*8*MAXC
+template <int MAXC>
+__global__ void __launch_bounds__(256) softmax_rows_kernel(const bf16* __restrict__ x, int64_t rows, int n, int ld,
+                                                           float scale, bf16* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int nch = n / 8;
+    float f[MAXC][8];
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(x + r * ld + ch * 8);
+            unpack8(v, f[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { f[i][e] *= scale; mx = fmaxf(mx, f[i][e]); }
+        }
+    }
+    mx = wave_max(mx);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { f[i][e] = __expf(f[i][e] - mx); s += f[i][e]; }
+        }
+    }
+    const float inv = 1.0f / wave_sum(s);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f[i][e] * inv;
+            *reinterpret_cast<u32x4*>(y + r * ld + ch * 8) = pack8(o);
+        }
+    }
+}
+
+bool gn_geom(int C1, int C2, int groups, GnGeom* g) {
+    const int C = C1 + C2;
+    if (C1 <= 0 || C2 < 0 || groups <= 0 || groups > 64) return false;
+    if (C % groups || C1 % 8 || C2 % 8) return false;
+    g->cpg = C / groups;
+    if (g->cpg < 4 || (g->cpg < 8 && 8 % g->cpg)) return false;
+    g->C1 = C1; g->C2 = C2;
+    g->ncols = C / 8;
+    g->ncols1 = C1 / 8;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int seer_groupnorm_stats(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t batch,
+                                    int64_t rows_per_batch, int32_t groups, float* stats, void* stream) {
+    GnGeom g;
+    if (!x1 || !stats || batch <= 0 || rows_per_batch <= 0) return SEER_EINVAL;
+    if (!x2) C2 = 0;
+    if (!gn_geom(C1, C2, groups, &g)) return SEER_EINVAL;
+    dim3 grid((unsigned)((rows_per_batch + GN_RPB - 1) / GN_RPB), batch);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const bf16*>(x1), reinterpret_cast<const bf16*>(x2), g, rows_per_batch, groups,
+                       stats);
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int seer_groupnorm_apply(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t batch,
+                                    int64_t rows_per_batch, int32_t groups, const float* stats, double count,
+                                    float eps, const float* gamma, const float* beta, int32_t silu, void* y,
+                                    void* stream) {
+    GnGeom g;
+    if (!x1 || !stats || !gamma || !beta || !y || batch <= 0 || rows_per_batch <= 0 || count <= 0) return SEER_EINVAL;
+    if (!x2) C2 = 0;
+    if (!gn_geom(C1, C2, groups, &g)) return SEER_EINVAL;
+    dim3 grid((unsigned)((rows_per_batch + GN_RPB - 1) / GN_RPB), batch);
+    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const bf16*>(x1), reinterpret_cast<const bf16*>(x2), g, rows_per_batch, groups,
+                       stats, (float)(1.0 / count), eps, gamma, beta, silu, reinterpret_cast<bf16*>(y));
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int seer_layernorm(const void* x, int64_t rows, int32_t C, int32_t ldx, const float* gamma,
+                              const float* beta, float eps, void* y, int32_t ldy, void* stream) {
+    if (!x || !y || !gamma || !beta || rows <= 0 || C <= 0 || C % 8 || ldx % 8 || ldy % 8) return SEER_EINVAL;
+    if (C > 64 * 8 * 3) return SEER_ENOSYS;
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bf16* xb = reinterpret_cast<const bf16*>(x);
+    bf16* yb = reinterpret_cast<bf16*>(y);
+    if (C <= 512) hipLaunchKernelGGL(layernorm_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, xb, rows, C, ldx, gamma, beta, eps, yb, ldy);
+    else if (C <= 1024) hipLaunchKernelGGL(layernorm_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, xb, rows, C, ldx, gamma, beta, eps, yb, ldy);
+    else hipLaunchKernelGGL(layernorm_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, st, xb, rows, C, ldx, gamma, beta, eps, yb, ldy);
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int seer_softmax_rows(const void* x, int64_t rows, int32_t n, int32_t ld, float scale, void* y,
+                                 void* stream) {
+    if (!x || !y || rows <= 0 || n <= 0 || n % 8 || ld % 8) return SEER_EINVAL;
+    if (n > 64 * 8 * 8) return SEER_ENOSYS;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bf16* xb = reinterpret_cast<const bf16*>(x);
+    bf16* yb = reinterpret_cast<bf16*>(y);
+    dim3 grid((unsigned)((rows + 3) / 4));
+    if (n <= 1024) hipLaunchKernelGGL(softmax_rows_kernel<2>, grid, dim3(256), 0, st, xb, rows, n, ld, scale, yb);
+    else if (n <= 2048) hipLaunchKernelGGL(softmax_rows_kernel<4>, grid, dim3(256), 0, st, xb, rows, n, ld, scale, yb);
+    else hipLaunchKernelGGL(softmax_rows_kernel<8>, grid, dim3(256), 0, st, xb, rows, n, ld, scale, yb);
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}

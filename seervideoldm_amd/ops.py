@@ -1,0 +1,326 @@
+"""Thin tensor-level wrappers over the C ABI (include/seer_hip.h).
+
+torch supplies device memory and the current stream; every FLOP below runs in libseer_hip.so.  Tensors must live
+on a ROCm device -- there is no CPU path (a CPU tensor raises).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import AttnDesc, GemmDesc, check
+
+bf16 = torch.bfloat16
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.SeerHipError("seervideoldm_amd kernels need tensors on a ROCm device (no CPU fallback)")
+    return t.data_ptr()
+
+
+def _req(t: torch.Tensor, dtype, name: str):
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_cuda:
+        raise _lib.SeerHipError(f"{name}: tensor must be on a ROCm device (no CPU fallback)")
+
+
+# ------------------------------------------------------------------------------------------------------------
+def gemm(a: torch.Tensor, w: torch.Tensor, *, bias=None, residual=None, rowvec=None, rows_per_batch=0,
+         a2: Optional[torch.Tensor] = None, geglu=False, silu=False, out_f32=False, out: Optional[torch.Tensor] = None,
+         tile=0) -> torch.Tensor:
+    """out[M,N] = epi(a[M,K1] | a2[M,K-K1]) @ w[N,K]^T ; a/a2 may be row-strided views (last dim contiguous)."""
+    _req(a, bf16, "a"); _req(w, bf16, "w")
+    assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.is_contiguous()
+    M, K1 = a.shape
+    N, K = w.shape
+    d = GemmDesc()
+    d.A, d.W = _p(a), _p(w)
+    d.lda = a.stride(0)
+    if a2 is not None:
+        _req(a2, bf16, "a2")
+        assert a2.shape[0] == M and a2.stride(1) == 1 and K1 + a2.shape[1] == K
+        d.A2, d.lda2 = _p(a2), a2.stride(0)
+    else:
+        assert K1 == K, f"K mismatch {K1} vs {K}"
+    d.M, d.N, d.K, d.K1 = M, N, K, K1
+    n_out = N // 2 if geglu else N
+    if out is None:
+        out = torch.empty((M, n_out), device=a.device, dtype=torch.float32 if out_f32 else bf16)
+    assert out.shape == (M, n_out) and out.stride(1) == 1
+    d.C, d.ldc = _p(out), out.stride(0)
+    if bias is not None:
+        _req(bias, torch.float32, "bias"); d.bias = _p(bias)
+    if residual is not None:
+        _req(residual, bf16, "residual")
+        assert residual.shape == (M, n_out) and residual.stride(1) == 1
+        d.residual, d.ldr = _p(residual), residual.stride(0)
+    if rowvec is not None:
+        _req(rowvec, torch.float32, "rowvec")
+        assert rowvec.dim() == 2 and rowvec.stride(1) == 1
+        d.rowvec, d.rowvec_ld, d.rows_per_batch = _p(rowvec), rowvec.stride(0), rows_per_batch
+    d.mode = _lib.SEER_GEMM_PLAIN
+    d.epilogue = (_lib.SEER_EPI_GEGLU if geglu else 0) | (_lib.SEER_EPI_SILU if silu else 0) | \
+                 (_lib.SEER_EPI_OUT_F32 if (out.dtype == torch.float32) else 0)
+    d.batch = 1
+    d.tile = tile
+    check(_lib.load().seer_gemm_bf16(C.byref(d), _stream()), "seer_gemm_bf16")
+    return out
+
+
+def gemm_batched(a: torch.Tensor, w: torch.Tensor, *, trans_out=False, out: Optional[torch.Tensor] = None,
+                 tile=0) -> torch.Tensor:
+    """a [Bt, M, K], w [Bt, N, K] (or [N, K] shared) -> out [Bt, M, N] (or [Bt, N, M] with trans_out)."""
+    _req(a, bf16, "a"); _req(w, bf16, "w")
+    assert a.dim() == 3 and a.is_contiguous() and w.is_contiguous()
+    Bt, M, K = a.shape
+    N = w.shape[-2]
+    d = GemmDesc()
+    d.A, d.W = _p(a), _p(w)
+    d.lda = K
+    d.M, d.N, d.K, d.K1 = M, N, K, K
+    if out is None:
+        out = torch.empty((Bt, N, M) if trans_out else (Bt, M, N), device=a.device, dtype=bf16)
+    d.C = _p(out)
+    d.ldc = M if trans_out else N
+    d.batch = Bt
+    d.strideA = M * K
+    d.strideW = N * K if w.dim() == 3 else 0
+    d.strideC = M * N
+    d.epilogue = _lib.SEER_EPI_TRANS_OUT if trans_out else 0
+    d.tile = tile
+    check(_lib.load().seer_gemm_bf16(C.byref(d), _stream()), "seer_gemm_bf16(batched)")
+    return out
+
+
+def conv3x3(x: torch.Tensor, w: torch.Tensor, n_img: int, Hin: int, Win: int, *, stride=1, upsample=False,
+            bias=None, residual=None, rowvec=None, rows_per_batch=0, out: Optional[torch.Tensor] = None,
+            tile=0) -> torch.Tensor:
+    """x: channels-last [n_img*Hin*Win, Cin] bf16; w: [Cout, 9*Cin] ((ky,kx,ci) order). Returns [n_img*Ho*Wo, Cout]."""
+    _req(x, bf16, "x"); _req(w, bf16, "w")
+    assert x.is_contiguous() and w.is_contiguous()
+    Cin = x.shape[1]
+    Cout, K = w.shape
+    assert K == 9 * Cin and x.shape[0] == n_img * Hin * Win
+    Hs, Ws = (2 * Hin, 2 * Win) if upsample else (Hin, Win)
+    Ho, Wo = (Hs + 2 - 3) // stride + 1, (Ws + 2 - 3) // stride + 1
+    M = n_img * Ho * Wo
+    d = GemmDesc()
+    d.A, d.W = _p(x), _p(w)
+    d.M, d.N, d.K, d.K1 = M, Cout, K, K
+    if out is None:
+        out = torch.empty((M, Cout), device=x.device, dtype=bf16)
+    d.C, d.ldc = _p(out), out.stride(0)
+    if bias is not None:
+        _req(bias, torch.float32, "bias"); d.bias = _p(bias)
+    if residual is not None:
+        _req(residual, bf16, "residual")
+        assert residual.shape == (M, Cout) and residual.stride(1) == 1
+        d.residual, d.ldr = _p(residual), residual.stride(0)
+    if rowvec is not None:
+        _req(rowvec, torch.float32, "rowvec")
+        d.rowvec, d.rowvec_ld, d.rows_per_batch = _p(rowvec), rowvec.stride(0), rows_per_batch
+    d.mode = _lib.SEER_GEMM_CONV3X3
+    d.Hin, d.Win, d.Cin, d.Hout, d.Wout, d.stride, d.upsample = Hin, Win, Cin, Ho, Wo, stride, int(upsample)
+    d.batch = 1
+    d.tile = tile
+    check(_lib.load().seer_gemm_bf16(C.byref(d), _stream()), "seer_gemm_bf16(conv3x3)")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *, batch: int, heads: int,
+              head_dim: int, Sq: int, Sk: int, causal=False, scale: Optional[float] = None,
+              window=None) -> torch.Tensor:
+    """q/k/v/out are 2-D token-major views [batch*S, >=heads*head_dim] (row stride = token stride, e.g. column slices
+    of a fused qkv buffer).  window = (ws, F, H, W) selects the temporal window form (S = F*H*W tokens per batch
+    element in memory, Sq = Sk = F*ws*ws per window)."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (out, "out")):
+        _req(t, bf16, n)
+        assert t.dim() == 2 and t.stride(1) == 1
+    d = AttnDesc()
+    d.Q, d.K, d.V, d.O = _p(q), _p(k), _p(v), _p(out)
+    d.q_ss, d.k_ss, d.v_ss, d.o_ss = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+    if window is None:
+        tq, tk = Sq, Sk
+    else:
+        ws, F, H, W = window
+        tq = tk = F * H * W
+        d.window_ws, d.F, d.H, d.W = ws, F, H, W
+    assert q.shape[0] == batch * tq and k.shape[0] == batch * tk and v.shape[0] == batch * tk
+    d.q_bs, d.o_bs = tq * q.stride(0), tq * out.stride(0)
+    d.k_bs, d.v_bs = tk * k.stride(0), tk * v.stride(0)
+    d.batch, d.heads, d.head_dim, d.Sq, d.Sk = batch, heads, head_dim, Sq, Sk
+    d.causal = int(causal)
+    d.scale = float(scale if scale is not None else head_dim ** -0.5)
+    check(_lib.load().seer_attn_fwd(C.byref(d), _stream()), "seer_attn_fwd")
+    return out
+
+
+def rotary_table(freqs: torch.Tensor, T: int) -> torch.Tensor:
+    _req(freqs, torch.float32, "freqs")
+    half = freqs.numel()
+    cs = torch.empty((T, half, 2), device=freqs.device, dtype=torch.float32)
+    check(_lib.load().seer_rotary_table(_p(freqs), T, half, _p(cs), _stream()), "seer_rotary_table")
+    return cs
+
+
+def rotary_inplace(x: torch.Tensor, col0_q: int, col0_k: int, heads: int, head_dim: int, rot_dim: int,
+                   tokens_per_batch: int, cos_sin: torch.Tensor, pos_offset: int = 0) -> None:
+    _req(x, bf16, "x")
+    assert x.dim() == 2 and x.stride(1) == 1
+    assert cos_sin.shape[0] >= tokens_per_batch + pos_offset
+    check(_lib.load().seer_rotary_inplace(_p(x), x.shape[0], x.stride(0), col0_q, col0_k, heads, head_dim, rot_dim,
+                                          tokens_per_batch, pos_offset, _p(cos_sin), _stream()), "seer_rotary_inplace")
+
+
+# ------------------------------------------------------------------------------------------------------------
+def groupnorm_stats(x1: torch.Tensor, x2: Optional[torch.Tensor], batch: int, groups: int,
+                    stats: torch.Tensor) -> torch.Tensor:
+    """accumulate (sum, sumsq) per (b, g) into stats [batch, groups, 2] fp32 (caller zeroes it)."""
+    _req(x1, bf16, "x1")
+    assert x1.is_contiguous() and (x2 is None or x2.is_contiguous())
+    rows = x1.shape[0] // batch
+    C2 = 0 if x2 is None else x2.shape[1]
+    check(_lib.load().seer_groupnorm_stats(_p(x1), x1.shape[1], _p(x2), C2, batch, rows, groups, _p(stats),
+                                           _stream()), "seer_groupnorm_stats")
+    return stats
+
+
+def groupnorm_apply(x1: torch.Tensor, x2: Optional[torch.Tensor], batch: int, groups: int, stats: torch.Tensor,
+                    count: float, eps: float, gamma: torch.Tensor, beta: torch.Tensor, silu: bool,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    rows = x1.shape[0] // batch
+    C2 = 0 if x2 is None else x2.shape[1]
+    Ct = x1.shape[1] + C2
+    if out is None:
+        out = torch.empty((x1.shape[0], Ct), device=x1.device, dtype=bf16)
+    _req(gamma, torch.float32, "gamma"); _req(beta, torch.float32, "beta")
+    check(_lib.load().seer_groupnorm_apply(_p(x1), x1.shape[1], _p(x2), C2, batch, rows, groups, _p(stats),
+                                           float(count), float(eps), _p(gamma), _p(beta), int(silu), _p(out),
+                                           _stream()), "seer_groupnorm_apply")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _req(x, bf16, "x")
+    assert x.dim() == 2 and x.stride(1) == 1
+    if out is None:
+        out = torch.empty((x.shape[0], x.shape[1]), device=x.device, dtype=bf16)
+    check(_lib.load().seer_layernorm(_p(x), x.shape[0], x.shape[1], x.stride(0), _p(gamma), _p(beta), float(eps),
+                                     _p(out), out.stride(0), _stream()), "seer_layernorm")
+    return out
+
+
+def softmax_rows(x: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _req(x, bf16, "x")
+    x2 = x.reshape(-1, x.shape[-1])
+    assert x2.is_contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.load().seer_softmax_rows(_p(x2), x2.shape[0], x2.shape[1], x2.stride(0), float(scale), _p(out),
+                                        _stream()), "seer_softmax_rows")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+def timestep_embedding(t: torch.Tensor, dim: int, flip_sin_to_cos: bool, freq_shift: float) -> torch.Tensor:
+    _req(t, torch.int64, "timestep")
+    out = torch.empty((t.numel(), dim), device=t.device, dtype=torch.float32)
+    check(_lib.load().seer_timestep_embedding(_p(t), t.numel(), dim, int(flip_sin_to_cos), float(freq_shift), _p(out),
+                                              _stream()), "seer_timestep_embedding")
+    return out
+
+
+def linear_smallm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, silu_in=False,
+                  silu_out=False) -> torch.Tensor:
+    _req(x, torch.float32, "x"); _req(w, bf16, "w")
+    assert x.is_contiguous() and w.is_contiguous()
+    B, K = x.shape
+    N = w.shape[0]
+    y = torch.empty((B, N), device=x.device, dtype=torch.float32)
+    check(_lib.load().seer_linear_smallm(_p(x), B, K, _p(w), _p(bias), N, int(silu_in), int(silu_out), _p(y),
+                                         _stream()), "seer_linear_smallm")
+    return y
+
+
+def conv_in(x: torch.Tensor, w_khwc: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """x [B, Cin, F, H, W] fp32 -> [B*F*H*W, Cout] bf16 ; w_khwc fp32 [3,3,Cin,Cout]."""
+    _req(x, torch.float32, "x"); _req(w_khwc, torch.float32, "w")
+    assert x.is_contiguous()
+    B, Cin, F, H, W = x.shape
+    Cout = w_khwc.shape[-1]
+    y = torch.empty((B * F * H * W, Cout), device=x.device, dtype=bf16)
+    check(_lib.load().seer_conv_in(_p(x), B, Cin, F, H, W, _p(w_khwc), _p(bias), Cout, _p(y), _stream()),
+          "seer_conv_in")
+    return y
+
+
+def conv_out(x: torch.Tensor, w_ohwc: torch.Tensor, bias: torch.Tensor, B: int, F: int, H: int, W: int) -> torch.Tensor:
+    """x [B*F*H*W, C0] bf16 -> [B, Cout, F, H, W] fp32 ; w fp32 [Cout,3,3,C0]."""
+    _req(x, bf16, "x"); _req(w_ohwc, torch.float32, "w")
+    Cout = w_ohwc.shape[0]
+    y = torch.empty((B, Cout, F, H, W), device=x.device, dtype=torch.float32)
+    check(_lib.load().seer_conv_out(_p(x), B, x.shape[1], F, H, W, _p(w_ohwc), _p(bias), Cout, _p(y), _stream()),
+          "seer_conv_out")
+    return y
+
+
+def cast_bf16(x: torch.Tensor) -> torch.Tensor:
+    _req(x, torch.float32, "x")
+    x = x.contiguous()
+    y = torch.empty(x.shape, device=x.device, dtype=bf16)
+    check(_lib.load().seer_cast_f32_bf16(_p(x), x.numel(), _p(y), _stream()), "seer_cast_f32_bf16")
+    return y
+
+
+def nchw_to_nhwc_bf16(x: torch.Tensor) -> torch.Tensor:
+    """[N, C, H, W] fp32 -> [N*H*W, C] bf16"""
+    _req(x, torch.float32, "x")
+    x = x.contiguous()
+    N, Cc = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * Cc)
+    y = torch.empty((N * HW, Cc), device=x.device, dtype=bf16)
+    check(_lib.load().seer_nchw_f32_to_nhwc_bf16(_p(x), N, Cc, HW, _p(y), _stream()), "seer_nchw_f32_to_nhwc_bf16")
+    return y
+
+
+def nhwc_to_nchw_f32(x: torch.Tensor, N: int, H: int, W: int) -> torch.Tensor:
+    _req(x, bf16, "x")
+    Cc = x.shape[1]
+    y = torch.empty((N, Cc, H, W), device=x.device, dtype=torch.float32)
+    check(_lib.load().seer_nhwc_bf16_to_nchw_f32(_p(x), N, Cc, H * W, _p(y), _stream()), "seer_nhwc_bf16_to_nchw_f32")
+    return y
+
+
+def cfg_ddim_step(eps: torch.Tensor, x: torch.Tensor, coef: torch.Tensor, index: int, *, cfg: bool, scale: float,
+                  cond_f: int, noise: Optional[torch.Tensor] = None, want_pred_x0=True):
+    """eps [2b or b, C, F_total, h, w] fp32 ; x [b, C, F_pred, h, w] fp32 -> (x_prev, pred_x0)."""
+    _req(eps, torch.float32, "eps"); _req(x, torch.float32, "x"); _req(coef, torch.float32, "coef")
+    assert eps.is_contiguous() and x.is_contiguous()
+    b, Cc, Fp, h, w = x.shape
+    Ft = eps.shape[2]
+    assert Ft == Fp + cond_f and eps.shape[0] == (2 * b if cfg else b)
+    x_prev = torch.empty_like(x)
+    pred = torch.empty_like(x) if want_pred_x0 else None
+    check(_lib.load().seer_cfg_ddim_step(_p(eps), int(cfg), b, Cc, Ft, cond_f, h * w, float(scale), _p(coef), index,
+                                         _p(x), _p(noise), _p(x_prev), _p(pred), _stream()), "seer_cfg_ddim_step")
+    return x_prev, pred
+
+
+def clamp01_(x: torch.Tensor) -> torch.Tensor:
+    _req(x, torch.float32, "x")
+    assert x.is_contiguous()
+    check(_lib.load().seer_clamp01(_p(x), x.numel(), _stream()), "seer_clamp01")
+    return x

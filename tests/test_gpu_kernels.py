@@ -1,0 +1,367 @@
+"""Per-kernel parity on a real MI355X: every entry point of libseer_hip.so against the fp32 formulas of the
+operator it replaces (the same formulas the CPU oracle in oracle/seer_oracle.py uses), on seeded inputs.
+
+Tolerances are for bf16 storage with fp32 accumulation: outputs are rounded once to bf16 (rel 2^-8), inputs are
+fed to the reference AFTER rounding to bf16 so only accumulation order and the final rounding differ.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as Fn
+
+pytestmark = pytest.mark.gpu
+
+bf16 = torch.bfloat16
+
+
+def _rand(shape, dev, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev)
+
+
+def _close(got, ref, rtol=2e-2, atol=2e-2, what=""):
+    got = got.float()
+    ref = ref.float()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = (err > tol)
+    if bad.any():
+        idx = bad.nonzero()[0].tolist()
+        raise AssertionError(f"{what}: {int(bad.sum())}/{bad.numel()} outside tol; max err {err.max().item():.4g} "
+                             f"(ref max {ref.abs().max().item():.4g}); first bad idx {idx} got {got[tuple(idx)].item():.5g} "
+                             f"ref {ref[tuple(idx)].item():.5g}")
+    return err.max().item()
+
+
+# ---------------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K,tile", [
+    (256, 128, 64, 1), (256, 128, 64, 2), (256, 128, 64, 3),
+    (384, 320, 320, 0), (1536, 1280, 1280, 0), (1848, 640, 768, 0), (6144, 640, 2560, 0),
+    (100, 64, 128, 2), (130, 68, 192, 3), (24576, 320, 320, 1),
+])
+def test_gemm_plain(device, M, N, K, tile):
+    from seervideoldm_amd import ops
+    a = _rand((M, K), device, 1).to(bf16)
+    w = _rand((N, K), device, 2, K ** -0.5).to(bf16)
+    bias = _rand((N,), device, 3)
+    res = _rand((M, N), device, 4).to(bf16)
+    out = ops.gemm(a, w, bias=bias, residual=res, tile=tile)
+    ref = a.float() @ w.float().t() + bias + res.float()
+    _close(out, ref, what=f"gemm {M}x{N}x{K} tile{tile}")
+    out32 = ops.gemm(a, w, out_f32=True, tile=tile)
+    _close(out32, a.float() @ w.float().t(), rtol=2e-3, atol=2e-3, what="gemm f32 out")
+
+
+def test_gemm_identity_asymmetric(device):
+    """A = I against an asymmetric W catches a transposed C write (cdna guide, MFMA section)."""
+    from seervideoldm_amd import ops
+    K = 128
+    a = torch.eye(K, device=device).to(bf16)
+    w = (torch.arange(192 * K, device=device).reshape(192, K) % 251).float().to(bf16)   # exact in bf16 (< 256)
+    out = ops.gemm(a, w, out_f32=True, tile=2)
+    assert torch.equal(out, w.float().t().contiguous())
+
+
+def test_gemm_dual_source_and_rowvec(device):
+    from seervideoldm_amd import ops
+    M, K1, K2, N = 768, 640, 320, 320
+    a1 = _rand((M, K1), device, 1).to(bf16)
+    a2 = _rand((M, K2), device, 2).to(bf16)
+    w = _rand((N, K1 + K2), device, 3, 0.03).to(bf16)
+    bias = _rand((N,), device, 4)
+    rv = _rand((2, N), device, 5)
+    out = ops.gemm(a1, w, a2=a2, bias=bias, rowvec=rv, rows_per_batch=M // 2)
+    ref = torch.cat([a1, a2], 1).float() @ w.float().t() + bias + rv.repeat_interleave(M // 2, 0)
+    _close(out, ref, what="dual-source gemm")
+
+
+@pytest.mark.parametrize("M,C", [(384, 1280), (1536, 320), (2048, 640)])
+def test_gemm_geglu(device, M, C):
+    from seervideoldm_amd import ops
+    from seervideoldm_amd.weights import interleave_geglu
+    N = 8 * C
+    a = _rand((M, C), device, 1).to(bf16)
+    w = _rand((N, C), device, 2, C ** -0.5).to(bf16)
+    bias = _rand((N,), device, 3, 0.5)
+    wi, bi = interleave_geglu(w, bias)
+    out = ops.gemm(a, wi, bias=bi, geglu=True)
+    h = a.float() @ w.float().t() + bias
+    val, gate = h.chunk(2, dim=-1)
+    ref = val * Fn.gelu(gate)
+    _close(out, ref, what="geglu")
+
+
+def test_gemm_strided_views(device):
+    """A and C as column slices of wider buffers (fused qkv layout)."""
+    from seervideoldm_amd import ops
+    M, K, N = 512, 320, 320
+    big = _rand((M, 3 * K), device, 1).to(bf16)
+    w = _rand((N, K), device, 2, 0.05).to(bf16)
+    outbig = torch.zeros((M, 2 * N), device=device, dtype=bf16)
+    ops.gemm(big[:, K:2 * K], w, out=outbig[:, N:])
+    _close(outbig[:, N:], big[:, K:2 * K].float() @ w.float().t(), what="strided gemm")
+    assert (outbig[:, :N] == 0).all()
+
+
+def test_gemm_batched_and_transposed(device):
+    from seervideoldm_amd import ops
+    Bt, M, N, K = 3, 256, 192, 128
+    a = _rand((Bt, M, K), device, 1).to(bf16)
+    w = _rand((Bt, N, K), device, 2, 0.1).to(bf16)
+    ref = torch.einsum("bmk,bnk->bmn", a.float(), w.float())
+    _close(ops.gemm_batched(a, w), ref, what="batched")
+    _close(ops.gemm_batched(a, w, trans_out=True), ref.transpose(1, 2), what="batched trans")
+
+
+# ---------------------------------------------------------------------------------------------------- conv
+@pytest.mark.parametrize("n_img,H,W,Ci,Co,stride,up", [
+    (2, 8, 8, 64, 64, 1, False), (3, 16, 16, 128, 64, 1, False), (2, 16, 16, 64, 128, 2, False),
+    (2, 8, 8, 64, 64, 1, True), (24, 32, 32, 320, 320, 1, False), (4, 4, 4, 1280, 1280, 1, False),
+    (2, 6, 10, 64, 68, 1, False),
+])
+def test_conv3x3(device, n_img, H, W, Ci, Co, stride, up):
+    from seervideoldm_amd import ops
+    from seervideoldm_amd.weights import pack_conv3x3
+    x = _rand((n_img, Ci, H, W), device, 1).to(bf16)
+    w = _rand((Co, Ci, 3, 3), device, 2, (9 * Ci) ** -0.5).to(bf16)
+    bias = _rand((Co,), device, 3)
+    x_cl = x.permute(0, 2, 3, 1).reshape(-1, Ci).contiguous()
+    out = ops.conv3x3(x_cl, pack_conv3x3(w), n_img, H, W, stride=stride, upsample=up, bias=bias)
+    xin = x.float()
+    if up:
+        xin = Fn.interpolate(xin, scale_factor=2.0, mode="nearest")
+    ref = Fn.conv2d(xin, w.float(), bias, stride=stride, padding=1)
+    ref_cl = ref.permute(0, 2, 3, 1).reshape(-1, Co)
+    _close(out, ref_cl, what=f"conv {Ci}->{Co} s{stride} up{up}")
+
+
+def test_conv3x3_epilogue(device):
+    from seervideoldm_amd import ops
+    from seervideoldm_amd.weights import pack_conv3x3
+    B, Fr, H, W, Ci, Co = 2, 3, 8, 8, 64, 128
+    n_img = B * Fr
+    x = _rand((n_img, Ci, H, W), device, 1).to(bf16)
+    w = _rand((Co, Ci, 3, 3), device, 2, 0.04).to(bf16)
+    bias = _rand((Co,), device, 3)
+    temb = _rand((B, Co), device, 4)
+    res = _rand((n_img * H * W, Co), device, 5).to(bf16)
+    x_cl = x.permute(0, 2, 3, 1).reshape(-1, Ci).contiguous()
+    out = ops.conv3x3(x_cl, pack_conv3x3(w), n_img, H, W, bias=bias, rowvec=temb, rows_per_batch=Fr * H * W,
+                      residual=res)
+    ref = Fn.conv2d(x.float(), w.float(), bias, padding=1) + temb.repeat_interleave(Fr, 0)[:, :, None, None]
+    ref_cl = ref.permute(0, 2, 3, 1).reshape(-1, Co) + res.float()
+    _close(out, ref_cl, what="conv epilogue")
+
+
+# ---------------------------------------------------------------------------------------------------- attention
+def _attn_ref(q, k, v, causal):
+    d = q.shape[-1]
+    s = torch.einsum("bhqd,bhkd->bhqk", q.float(), k.float()) * d ** -0.5
+    if causal:
+        m = torch.ones(s.shape[-2:], dtype=torch.bool, device=s.device).tril()
+        s = s.masked_fill(~m, float("-inf"))
+    return torch.einsum("bhqk,bhkd->bhqd", s.softmax(-1), v.float())
+
+
+@pytest.mark.parametrize("d,Sq,Sk,causal", [
+    (40, 128, 128, False), (40, 1024, 1024, False), (80, 256, 256, False), (160, 64, 64, False), (160, 16, 16, False),
+    (40, 1024, 77, False), (80, 256, 77, False), (160, 64, 77, False), (160, 16, 77, False),
+    (40, 768, 768, True), (80, 192, 192, True), (160, 192, 192, True), (40, 100, 100, True), (80, 272, 272, True),
+])
+def test_attention(device, d, Sq, Sk, causal):
+    from seervideoldm_amd import ops
+    B, Hh = 3, 8
+    C = Hh * d
+    q = _rand((B, Sq, Hh, d), device, 1).to(bf16)
+    k = _rand((B, Sk, Hh, d), device, 2).to(bf16)
+    v = _rand((B, Sk, Hh, d), device, 3).to(bf16)
+    out = torch.zeros((B * Sq, C), device=device, dtype=bf16)
+    ops.attention(q.reshape(B * Sq, C), k.reshape(B * Sk, C), v.reshape(B * Sk, C), out, batch=B, heads=Hh,
+                  head_dim=d, Sq=Sq, Sk=Sk, causal=causal)
+    ref = _attn_ref(q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3), causal)
+    ref = ref.permute(0, 2, 1, 3).reshape(B * Sq, C)
+    _close(out, ref, rtol=2e-2, atol=1e-2, what=f"attn d{d} {Sq}x{Sk} causal={causal}")
+
+
+def test_attention_fused_qkv_layout(device):
+    """q, k, v as column slices of one [tokens, 3C] buffer (what the fused projection GEMM writes)."""
+    from seervideoldm_amd import ops
+    B, S, Hh, d = 2, 256, 8, 80
+    C = Hh * d
+    qkv = _rand((B * S, 3 * C), device, 7).to(bf16)
+    out = torch.empty((B * S, C), device=device, dtype=bf16)
+    ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, batch=B, heads=Hh, head_dim=d, Sq=S, Sk=S)
+    q, k, v = [t.reshape(B, S, Hh, d).permute(0, 2, 1, 3) for t in qkv.split(C, dim=1)]
+    ref = _attn_ref(q, k, v, False).permute(0, 2, 1, 3).reshape(B * S, C)
+    _close(out, ref, rtol=2e-2, atol=1e-2, what="fused-qkv attention")
+
+
+def test_attention_softmax_spike(device):
+    """force a late running-max jump (online-softmax rescale path) with a spiked key."""
+    from seervideoldm_amd import ops
+    B, S, Hh, d = 1, 256, 8, 40
+    C = Hh * d
+    q = _rand((B, S, Hh, d), device, 1).to(bf16)
+    k = _rand((B, S, Hh, d), device, 2).to(bf16)
+    v = _rand((B, S, Hh, d), device, 3).to(bf16)
+    k[:, 200] = (q[:, 5] * 4).to(bf16)        # key 200 dominates query 5 only in a late tile
+    out = torch.empty((B * S, C), device=device, dtype=bf16)
+    ops.attention(q.reshape(S, C), k.reshape(S, C), v.reshape(S, C), out, batch=B, heads=Hh, head_dim=d, Sq=S, Sk=S)
+    ref = _attn_ref(q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3), False)
+    _close(out, ref.permute(0, 2, 1, 3).reshape(S, C), rtol=2e-2, atol=1e-2, what="spiked softmax")
+
+
+@pytest.mark.parametrize("d,Fr,H,W,ws", [(40, 4, 32, 32, 8), (80, 12, 16, 16, 4), (160, 3, 8, 8, 4)])
+def test_window_attention(device, d, Fr, H, W, ws):
+    """temporal window attention == window_partition -> causal attention -> window_reverse (attention.py:42-69,661-703)."""
+    from seervideoldm_amd import ops
+    B, Hh = 2, 8
+    C = Hh * d
+    T = Fr * H * W
+    qkv = _rand((B * T, 3 * C), device, 11).to(bf16)
+    out = torch.zeros((B * T, C), device=device, dtype=bf16)
+    ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, batch=B, heads=Hh, head_dim=d,
+                  Sq=Fr * ws * ws, Sk=Fr * ws * ws, causal=True, window=(ws, Fr, H, W))
+
+    def part(t):   # [B*T, C] -> [nW*B, heads, F*ws*ws, d]
+        t = t.float().reshape(B, Fr, H // ws, ws, W // ws, ws, Hh, d)
+        t = t.permute(2, 4, 0, 6, 1, 3, 5, 7)      # nwy nwx B heads F wy wx d
+        return t.reshape(-1, Hh, Fr * ws * ws, d)
+    q, k, v = [part(t) for t in qkv.split(C, dim=1)]
+    o = _attn_ref(q, k, v, True)                   # [nW*B, heads, S, d]
+    o = o.reshape(H // ws, W // ws, B, Hh, Fr, ws, ws, d).permute(2, 4, 0, 5, 1, 6, 3, 7).reshape(B * T, C)
+    _close(out, o, rtol=2e-2, atol=1e-2, what="window attention")
+
+
+def test_rotary(device):
+    from seervideoldm_amd import ops
+    B, T, Hh, d = 2, 640, 8, 40
+    C = Hh * d
+    x = _rand((B * T, 3 * C), device, 1).to(bf16)
+    freqs = (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))).to(device)
+    cs = ops.rotary_table(freqs, T)
+    y = x.clone()
+    ops.rotary_inplace(y, 0, C, Hh, d, 32, T, cs)
+    pos = torch.arange(T, device=device).float()
+    ang = torch.einsum("t,f->tf", pos, freqs).repeat_interleave(2, dim=-1)       # [T, 32]
+    def rot(t):    # [B*T, C]
+        t = t.float().reshape(B, T, Hh, d)
+        tr = t[..., :32]
+        x1, x2 = tr[..., 0::2], tr[..., 1::2]
+        rh = torch.stack((-x2, x1), dim=-1).flatten(-2)
+        tr = tr * ang.cos()[None, :, None, :] + rh * ang.sin()[None, :, None, :]
+        return torch.cat([tr, t[..., 32:]], -1).reshape(B * T, C)
+    _close(y[:, :C], rot(x[:, :C]), what="rotary q")
+    _close(y[:, C:2 * C], rot(x[:, C:2 * C]), what="rotary k")
+    assert torch.equal(y[:, 2 * C:], x[:, 2 * C:])
+
+
+# ---------------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("B,rows,C1,C2,silu", [(2, 768, 320, 0, True), (2, 200, 1280, 640, True), (1, 64, 2560, 0, False),
+                                               (3, 1000, 128, 0, True), (2, 192, 640, 320, False)])
+def test_groupnorm(device, B, rows, C1, C2, silu):
+    from seervideoldm_amd import ops
+    x1 = (_rand((B * rows, C1), device, 1) * 2 + 0.5).to(bf16)
+    x2 = (_rand((B * rows, C2), device, 2) - 1.0).to(bf16) if C2 else None
+    Ct = C1 + C2
+    gamma = _rand((Ct,), device, 3) + 1.0
+    beta = _rand((Ct,), device, 4)
+    stats = torch.zeros((B, 32, 2), device=device, dtype=torch.float32)
+    ops.groupnorm_stats(x1, x2, B, 32, stats)
+    y = ops.groupnorm_apply(x1, x2, B, 32, stats, rows * (Ct // 32), 1e-5, gamma, beta, silu)
+    xc = x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], 1)
+    xr = xc.reshape(B, rows, Ct).permute(0, 2, 1)            # [B, C, rows]
+    ref = Fn.group_norm(xr, 32, gamma, beta, eps=1e-5)
+    if silu:
+        ref = Fn.silu(ref)
+    _close(y, ref.permute(0, 2, 1).reshape(B * rows, Ct), what="groupnorm")
+
+
+@pytest.mark.parametrize("rows,C", [(1000, 320), (513, 640), (77, 1280)])
+def test_layernorm(device, rows, C):
+    from seervideoldm_amd import ops
+    x = (_rand((rows, C), device, 1) * 3 + 1).to(bf16)
+    gamma = _rand((C,), device, 2) + 1.0
+    beta = _rand((C,), device, 3)
+    y = ops.layernorm(x, gamma, beta)
+    _close(y, Fn.layer_norm(x.float(), (C,), gamma, beta), what="layernorm")
+
+
+def test_softmax_rows(device):
+    from seervideoldm_amd import ops
+    x = (_rand((300, 1024), device, 1) * 4).to(bf16)
+    y = ops.softmax_rows(x, 0.37)
+    _close(y, (x.float() * 0.37).softmax(-1), rtol=2e-2, atol=1e-4, what="softmax")
+
+
+# ---------------------------------------------------------------------------------------------------- small kernels
+def test_timestep_embedding_and_small_linear(device):
+    from seervideoldm_amd import ops
+    t = torch.tensor([751, 1], device=device, dtype=torch.int64)
+    emb = ops.timestep_embedding(t, 320, True, 0.0)
+    half = 160
+    expo = -math.log(10000) * torch.arange(half, dtype=torch.float32, device=device) / half
+    arg = t[:, None].float() * expo.exp()[None]
+    ref = torch.cat([arg.cos(), arg.sin()], -1)
+    _close(emb, ref, rtol=0, atol=2e-4, what="timestep embedding")
+    w = _rand((1280, 320), device, 1, 0.05).to(bf16)
+    b = _rand((1280,), device, 2)
+    y = ops.linear_smallm(emb, w, b, silu_out=True)
+    _close(y, Fn.silu(emb @ w.float().t() + b), rtol=1e-3, atol=1e-3, what="small linear")
+    y2 = ops.linear_smallm(y, _rand((777, 1280), device, 3, 0.03).to(bf16), None, silu_in=True)
+    _close(y2, Fn.silu(y) @ _rand((777, 1280), device, 3, 0.03).to(bf16).float().t(), rtol=1e-3, atol=1e-3,
+           what="small linear silu_in")
+
+
+def test_conv_in_out(device):
+    from seervideoldm_amd import ops
+    B, Fr, H, W = 2, 3, 16, 16
+    x = _rand((B, 4, Fr, H, W), device, 1)
+    w = _rand((320, 4, 3, 3), device, 2, 0.2)
+    bias = _rand((320,), device, 3)
+    y = ops.conv_in(x, w.permute(2, 3, 1, 0).contiguous(), bias)
+    x2 = x.permute(0, 2, 1, 3, 4).reshape(B * Fr, 4, H, W)
+    ref = Fn.conv2d(x2, w, bias, padding=1).permute(0, 2, 3, 1).reshape(-1, 320)
+    _close(y, ref, what="conv_in")
+    wo = _rand((4, 320, 3, 3), device, 4, 0.02)
+    bo = _rand((4,), device, 5)
+    z = ops.conv_out(y, wo.permute(0, 2, 3, 1).contiguous(), bo, B, Fr, H, W)
+    yin = y.float().reshape(B * Fr, H, W, 320).permute(0, 3, 1, 2)
+    refo = Fn.conv2d(yin, wo, bo, padding=1).reshape(B, Fr, 4, H, W).permute(0, 2, 1, 3, 4)
+    _close(z, refo, rtol=1e-3, atol=1e-3, what="conv_out")
+
+
+def test_layout_and_cast(device):
+    from seervideoldm_amd import ops
+    x = _rand((3, 37, 5, 9), device, 1)
+    y = ops.nchw_to_nhwc_bf16(x)
+    assert torch.equal(y, x.permute(0, 2, 3, 1).reshape(-1, 37).to(bf16))
+    z = ops.nhwc_to_nchw_f32(y, 3, 5, 9)
+    assert torch.equal(z, x.to(bf16).float())
+    c = _rand((1001,), device, 2)
+    assert torch.equal(ops.cast_bf16(c), c.to(bf16))
+
+
+def test_cfg_ddim_step(device):
+    from seervideoldm_amd import ops
+    b, C, Fp, cf, h, w = 2, 4, 5, 2, 8, 8
+    eps = _rand((2 * b, C, Fp + cf, h, w), device, 1)
+    x = _rand((b, C, Fp, h, w), device, 2)
+    noise = _rand((b, C, Fp, h, w), device, 3)
+    coef = torch.tensor([[0.5, 0.7, 0.1, math.sqrt(0.5)], [0.0376981, 0.329366, 0.0, math.sqrt(1 - 0.0376981)]],
+                        device=device)
+    for idx, nz in ((0, noise), (1, None)):
+        xp, x0 = ops.cfg_ddim_step(eps, x, coef, idx, cfg=True, scale=7.5, cond_f=cf, noise=nz)
+        eu, ec = eps.chunk(2)
+        e = eu[:, :, cf:] + 7.5 * (ec[:, :, cf:] - eu[:, :, cf:])
+        a_t, a_p, sg, s1 = coef[idx].tolist()
+        rx0 = (x - s1 * e) / math.sqrt(a_t)
+        rxp = math.sqrt(a_p) * rx0 + math.sqrt(1 - a_p - sg * sg) * e + (sg * noise if nz is not None else 0)
+        _close(x0, rx0, rtol=1e-5, atol=1e-5, what="pred_x0")
+        _close(xp, rxp, rtol=1e-5, atol=1e-5, what="x_prev")
+    img = _rand((1000,), device, 4) * 2
+    ref = ((img + 1) / 2).clamp(0, 1)
+    assert torch.allclose(ops.clamp01_(img.clone()), ref)
