@@ -1,0 +1,148 @@
+"""TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.npz by running the REAL reference modules (imported from
+/root/reference through oracle/ref_import.py) on CPU fp32.  Run in the build container:
+
+    python -m oracle.make_goldens
+
+Weights come from seervideoldm_amd.synth (closed form, not stored); inputs and the reference's outputs are stored.
+Every fixture is data: inputs + expected outputs.  Nothing of the reference's source is written anywhere.
+"""
+from __future__ import annotations
+
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+from oracle import ref_import  # noqa: E402
+from seervideoldm_amd import synth  # noqa: E402
+
+OUT = ROOT / "tests" / "golden"
+
+TINY_UNET = dict(sample_size=16, in_channels=4, out_channels=4, block_out_channels=(32, 64, 64, 64),
+                 cross_attention_dim=64, attention_head_dim=8, layers_per_block=2)
+TINY_VAE = dict(ch=32, ch_mult=(1, 2, 2, 2), num_res_blocks=1, z_channels=4, out_ch=3)
+
+
+def _save(name, **arrs):
+    OUT.mkdir(parents=True, exist_ok=True)
+    np.savez_compressed(OUT / name, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                       for k, v in arrs.items()})
+    print(f"wrote {name}: " + ", ".join(f"{k}{tuple(np.shape(v))}" for k, v in arrs.items()))
+
+
+def _randn(shape, seed):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+
+
+def _load_synth(module, prefix=""):
+    shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+    sd = synth.synth_state_dict({prefix + k: s for k, s in shapes.items()})
+    module.load_state_dict({k[len(prefix):]: v for k, v in sd.items()}, strict=True)
+    return sd
+
+
+@torch.no_grad()
+def main():
+    ref = ref_import.load_reference()
+
+    # ---- 1. schedule tables (ddim_video.py:27-68)
+    for S in (4, 30, 50):
+        smp = ref.ddim.DDIMSampler("cpu")
+        smp.make_schedule(ddim_num_steps=S, ddim_eta=0.0, verbose=False)
+        n = len(smp.ddim_timesteps)
+        _save(f"schedule_S{S}.npz", ddim_timesteps=np.asarray(smp.ddim_timesteps),
+              alphas=np.asarray([float(smp.ddim_alphas[i]) for i in range(n)]),
+              alphas_prev=np.asarray([float(smp.ddim_alphas_prev[i]) for i in range(n)]),
+              sigmas=np.asarray([float(smp.ddim_sigmas[i]) for i in range(n)]),
+              sqrt_one_minus_alphas=np.asarray([float(smp.ddim_sqrt_one_minus_alphas[i]) for i in range(n)]),
+              betas_0_999=np.asarray([float(smp.betas[0]), float(smp.betas[999])]),
+              alphas_cumprod_0_999=np.asarray([float(smp.alphas_cumprod[0]), float(smp.alphas_cumprod[999])]))
+
+    # ---- 2. per-op: ResnetBlock3D (resnet.py:106-208)
+    for tag, cin, cout in (("same", 64, 64), ("widen", 96, 64)):
+        blk = ref.resnet.ResnetBlock3D(in_channels=cin, out_channels=cout, temb_channels=128, eps=1e-5, groups=32,
+                                       non_linearity="silu").eval()
+        _load_synth(blk, f"resnet_{tag}.")
+        x, temb = _randn((2, cin, 3, 8, 8), 1), _randn((2, 128), 2)
+        _save(f"op_resnet_{tag}.npz", x=x, temb=temb, y=blk(x, temb))
+
+    # ---- per-op: SpatialTransformer3D text block (attention.py:97-145,265-327)
+    st = ref.attention.SpatialTransformer3D(64, 8, 8, depth=1, context_dim=48, text_frame_condition=True).eval()
+    ref_import.enable_xformers_path(st)
+    _load_synth(st, "st_text.")
+    x, ctx = _randn((2, 64, 3, 8, 8), 3), _randn((2, 3, 77, 48), 4)
+    _save("op_transformer_text.npz", x=x, context=ctx, y=st(x, context=ctx))
+
+    # ---- per-op: temporal SpatialTransformer3D in the three window regimes x cond_frame (attention.py:181-248,632-703)
+    for H, C, Fr in ((32, 64, 2), (16, 64, 3), (8, 64, 4), (4, 64, 5)):
+        tt = ref.attention.SpatialTransformer3D(C, 8, C // 8, depth=1, context_dim=None, temporal=True, causal=True).eval()
+        ref_import.enable_xformers_path(tt)
+        _load_synth(tt, "st_temporal.")
+        x = _randn((1 if H >= 16 else 2, C, Fr, H, H), 10 + H)
+        ys = {f"y_cond{cf}": tt(x, cond_frame=cf) for cf in (0, 2 if Fr > 2 else 1)}
+        _save(f"op_transformer_temporal_H{H}.npz", x=x, **ys)
+
+    # ---- per-op: Downsample3D / Upsample3D (resnet.py:18-104)
+    dn = ref.resnet.Downsample3D(64, use_conv=True, out_channels=64, padding=1, name="op").eval()
+    _load_synth(dn, "down.")
+    up = ref.resnet.Upsample3D(64, use_conv=True, out_channels=64).eval()
+    _load_synth(up, "up.")
+    x = _randn((2, 64, 2, 8, 8), 20)
+    _save("op_updown.npz", x=x, y_down=dn(x), y_up=up(x))
+
+    # ---- 3. tiny SeerUNet end to end (unet_3d_condition.py:283-376)
+    unet = ref.unet.SeerUNet(**TINY_UNET).eval()
+    ref_import.enable_xformers_path(unet)
+    shapes = synth.unet_param_shapes(TINY_UNET)
+    assert set(shapes) == set(unet.state_dict().keys())
+    unet.load_state_dict(synth.synth_state_dict(shapes), strict=True)
+    x, ctx = _randn((2, 4, 4, 16, 16), 30), _randn((2, 4, 77, 64), 31)
+    t = torch.tensor([501, 501])
+    _save("unet_tiny.npz", sample=x, timestep=t, context=ctx, y_cond0=unet(x, t, ctx, cond_frame=0),
+          y_cond2=unet(x, t, ctx, 2), y_scalar_t=unet(x, 7, ctx))
+
+    # ---- 4. VAE decoder (vendored twin, model.py:462-568) + post_quant_conv
+    dec = ref.vae.Decoder(ch=TINY_VAE["ch"], out_ch=3, ch_mult=TINY_VAE["ch_mult"], num_res_blocks=TINY_VAE["num_res_blocks"],
+                          attn_resolutions=[], in_channels=3, resolution=64, z_channels=4).eval()
+    vshapes = synth.vae_param_shapes(**TINY_VAE)
+    vsd = synth.synth_state_dict(vshapes)
+    dec.load_state_dict({k[len("decoder."):]: v for k, v in vsd.items() if k.startswith("decoder.")}, strict=True)
+    pq = torch.nn.Conv2d(4, 4, 1)
+    pq.load_state_dict({"weight": vsd["post_quant_conv.weight"], "bias": vsd["post_quant_conv.bias"]})
+    z = _randn((3, 4, 8, 8), 40)
+    _save("vae_tiny.npz", z=z, y=dec(pq(z)))
+
+    # ---- 5. sampler: one p_sample_ddim step with CFG and a full 4-step ddim_sample incl. decode
+    class _Vae:   # diffusers AutoencoderKL.decode(z).sample surface over the vendored decoder
+        def decode(self, zz):
+            import types
+            return types.SimpleNamespace(sample=dec(pq(zz)))
+
+    smp = ref.ddim.DDIMSampler("cpu")
+    b, f1, Fp = 1, 2, 2
+    x0_emb = _randn((b, 4, f1, 16, 16), 50) * 0.9
+    c = _randn((b, f1 + Fp, 77, 64), 51)
+    uc = _randn((b, 1, 77, 64), 52).expand(-1, f1 + Fp, -1, -1).contiguous()
+    noise = _randn((b, 4, Fp, 16, 16), 53)
+    smp.make_schedule(ddim_num_steps=4, ddim_eta=0.0, verbose=False)
+    ts = torch.full((b,), 751, dtype=torch.long)
+    torch.manual_seed(123)
+    x_prev, pred_x0 = smp.p_sample_ddim(unet, noise, c, ts, index=3, is_3d=True, x0_emb=x0_emb,
+                                        unconditional_guidance_scale=7.5, unconditional_conditioning=uc)
+    _save("ddim_step.npz", x=noise, x0_emb=x0_emb, c=c, uc=uc, x_prev=x_prev, pred_x0=pred_x0)
+    torch.manual_seed(123)
+    clip = ref.glue.ddim_sample(smp, unet, _Vae(), shape=(b, 4, Fp, 16, 16), c=c, start_code=noise, x0_emb=x0_emb,
+                                ddim_steps=4, scale=7.5, uc=uc)
+    torch.manual_seed(123)
+    lat, _ = smp.sample(unet=unet, S=4, conditioning=c, batch_size=b, shape=(4, Fp, 16, 16), x0_emb=x0_emb,
+                        verbose=False, unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=0.0,
+                        x_T=noise, is_3d=True)
+    _save("ddim_sample_tiny.npz", start_code=noise, x0_emb=x0_emb, c=c, uc=uc, latent=lat, clip=clip)
+
+
+if __name__ == "__main__":
+    main()

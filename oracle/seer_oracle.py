@@ -1,0 +1,358 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU oracle of the Seer DDIM denoising hot path (plain torch, fp32, functional).
+
+A restatement of the reference's algorithm for the path BASELINE.json names, written against a flat state dict with the
+reference's checkpoint key names.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it;
+the product package (seervideoldm_amd/) never does.
+
+Pinning: tests/test_oracle_vs_reference.py (build container only) runs the REAL reference modules (imported through
+oracle/ref_import.py) on the same weights/inputs; tests/golden/*.npz hold outputs of those reference modules, produced by
+oracle/make_goldens.py, and tests/test_oracle_golden.py checks this file against them everywhere (also on the GPU box).
+Third-party arithmetic (diffusers Timesteps/TimestepEmbedding, rotary-embedding-torch, xformers MEA, diffusers
+AutoencoderKL) is restated from the pinned versions' published behaviour: parity unpinned for those pieces.
+
+Each function cites the reference lines it follows (paths relative to the reference repo).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+SD = Dict[str, torch.Tensor]
+
+DEFAULT_CFG = dict(in_channels=4, out_channels=4, center_input_sample=False, flip_sin_to_cos=True, freq_shift=0,
+                   block_out_channels=(320, 640, 1280, 1280), layers_per_block=2, norm_num_groups=32, norm_eps=1e-5,
+                   cross_attention_dim=768, attention_head_dim=8)
+
+MAX_WIN_SIZE, MAX_RATIO, MIN_WIN_SIZE = 8, 4, 4      # seer/models/attention.py:31-33
+
+
+# ------------------------------------------------------------------------------------------------ primitives
+def _lin(sd: SD, p: str, x):
+    return F.linear(x, sd[p + ".weight"], sd.get(p + ".bias"))
+
+
+def conv_frames(sd: SD, p: str, x, stride=1, padding=1):
+    """InflatedConv3d: fold frames into batch, conv2d, unfold (seer/models/resnet.py:8-16)."""
+    b, c, f, h, w = x.shape
+    y = F.conv2d(x.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w), sd[p + ".weight"], sd.get(p + ".bias"),
+                 stride=stride, padding=padding)
+    return y.reshape(b, f, *y.shape[1:]).permute(0, 2, 1, 3, 4)
+
+
+def group_norm5d(sd: SD, p: str, x, groups, eps):
+    """nn.GroupNorm on the 5-D tensor: statistics over (C/G, F, H, W) (resnet.py:179; attention.py:133)."""
+    return F.group_norm(x, groups, sd[p + ".weight"], sd[p + ".bias"], eps)
+
+
+def timestep_embedding(t, dim, flip_sin_to_cos, freq_shift):
+    """diffusers 0.10.2 Timesteps (unet_3d_condition.py:97,307)."""
+    half = dim // 2
+    exponent = -math.log(10000) * torch.arange(0, half, dtype=torch.float32) / (half - freq_shift)
+    arg = t[:, None].float() * torch.exp(exponent)[None, :]
+    emb = torch.cat([arg.sin(), arg.cos()], dim=-1)
+    if flip_sin_to_cos:
+        emb = torch.cat([emb[:, half:], emb[:, :half]], dim=-1)
+    return emb
+
+
+def rotary(t, freqs):
+    """rotary-embedding-torch 0.1.5 rotate_queries_or_keys on [BH, S, d] (attention.py:649-651)."""
+    S = t.shape[-2]
+    ang = torch.einsum("s,f->sf", torch.arange(S, dtype=freqs.dtype), freqs).repeat_interleave(2, dim=-1)
+    rd = ang.shape[-1]
+    tr, rest = t[..., :rd], t[..., rd:]
+    x1, x2 = tr[..., 0::2], tr[..., 1::2]
+    half = torch.stack((-x2, x1), dim=-1).flatten(-2)
+    return torch.cat([tr * ang.cos() + half * ang.sin(), rest], dim=-1)
+
+
+def mea(q, k, v, causal):
+    """xformers 0.0.13 memory_efficient_attention on [BH, S, d] (+ LowerTriangularMask) (attention.py:622-630)."""
+    s = torch.einsum("bqd,bkd->bqk", q, k) * q.shape[-1] ** -0.5
+    if causal:
+        m = torch.ones(s.shape[-2:], dtype=torch.bool).tril()
+        s = s.masked_fill(~m, float("-inf"))
+    return torch.einsum("bqk,bkd->bqd", s.softmax(-1), v)
+
+
+def _heads(x, heads):    # [B, S, C] -> [B*heads, S, d]   (attention.py:492-497)
+    B, S, C = x.shape
+    return x.reshape(B, S, heads, C // heads).permute(0, 2, 1, 3).reshape(B * heads, S, C // heads)
+
+
+def _unheads(x, heads):  # [B*heads, S, d] -> [B, S, C]   (attention.py:499-504)
+    BH, S, d = x.shape
+    return x.reshape(BH // heads, heads, S, d).permute(0, 2, 1, 3).reshape(BH // heads, S, heads * d)
+
+
+def cross_attention(sd: SD, p: str, x, context, heads):
+    """CrossAttention.forward, xformers path, non-temporal (attention.py:512-554)."""
+    ctx = x if context is None else context
+    q, k, v = _lin(sd, p + ".to_q", x), _lin(sd, p + ".to_k", ctx), _lin(sd, p + ".to_v", ctx)
+    o = _unheads(mea(_heads(q, heads), _heads(k, heads), _heads(v, heads), False), heads)
+    return _lin(sd, p + ".to_out.0", o)
+
+
+def window_partition(x, ws):     # [B, F, H, W, C] -> [nW*B, F*ws*ws, C]   (attention.py:42-53)
+    B, Fr, H, W, C = x.shape
+    x = x.reshape(B, Fr, H // ws, ws, W // ws, ws, C)
+    return x.permute(2, 4, 0, 1, 3, 5, 6).reshape(-1, Fr * ws * ws, C)
+
+
+def window_reverse(win, ws, Fr, H, W):   # -> [B, F*H*W, C]   (attention.py:55-69)
+    C = win.shape[-1]
+    B = win.shape[0] // ((H // ws) * (W // ws))
+    x = win.reshape(H // ws, W // ws, B, Fr, ws, ws, C)
+    return x.permute(2, 3, 0, 4, 1, 5, 6).reshape(B, Fr * H * W, C)
+
+
+def window_temporal_attention(sd: SD, p: str, x, heads):
+    """WindowSTempAttention.forward (attention.py:632-703): x [b, f, h, w, C]; rotary over the flat (f,h,w) index, window
+    partition, causal attention over window tokens ordered (f, wy, wx), window reverse."""
+    b, f, h, w, C = x.shape
+    hs = x.reshape(b, f * h * w, C)
+    q = rotary(_heads(_lin(sd, p + ".to_q", hs), heads), sd[p + ".rotary_emb.freqs"])
+    k = rotary(_heads(_lin(sd, p + ".to_k", hs), heads), sd[p + ".rotary_emb.freqs"])
+    v = _heads(_lin(sd, p + ".to_v", hs), heads)
+    d = q.shape[-1]
+    if h > MIN_WIN_SIZE:
+        ws = MAX_WIN_SIZE if (h // MAX_WIN_SIZE) >= MAX_RATIO else MIN_WIN_SIZE
+        q, k, v = [window_partition(t.reshape(-1, f, h, w, d), ws) for t in (q, k, v)]
+    o = _unheads(mea(q, k, v, True), heads)
+    o = _lin(sd, p + ".to_out.0", o)
+    if h > MIN_WIN_SIZE:
+        o = window_reverse(o, ws, f, h, w)
+    return o
+
+
+def feed_forward(sd: SD, p: str, x):
+    """FeedForward with GEGLU, exact-erf GELU (attention.py:744-747,791-793)."""
+    hgate = _lin(sd, p + ".net.0.proj", x)
+    hval, gate = hgate.chunk(2, dim=-1)
+    return _lin(sd, p + ".net.2", hval * F.gelu(gate))
+
+
+def _ln(sd: SD, p: str, x):
+    return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], 1e-5)
+
+
+def spatial_transformer(sd: SD, p: str, x, context, heads, temporal, cond_frame, groups):
+    """SpatialTransformer3D.forward (attention.py:129-145) with its single transformer block:
+    text: BasicTextTransformerBlock3D (attention.py:308-327); temporal: BasicTransformerBlock3D (attention.py:231-248)."""
+    b, c, f, h, w = x.shape
+    x_in = x
+    x = group_norm5d(sd, p + ".norm", x, groups, 1e-6)
+    x = conv_frames(sd, p + ".proj_in", x, padding=0)
+    tb = p + ".transformer_blocks.0"
+    if not temporal:
+        t = x.permute(0, 2, 3, 4, 1).reshape(b * f, h * w, c)
+        t = cross_attention(sd, tb + ".attn1", _ln(sd, tb + ".norm1", t), None, heads) + t
+        if context is not None:
+            ctx = context.reshape(b * f, -1, context.shape[-1])
+            t = cross_attention(sd, tb + ".attn2", _ln(sd, tb + ".norm2", t), ctx, heads) + t
+        t = feed_forward(sd, tb + ".ff", _ln(sd, tb + ".norm3", t)) + t
+    else:
+        t = x.permute(0, 2, 3, 4, 1).reshape(b, f * h * w, c)
+        t = window_temporal_attention(sd, tb + ".attn1", _ln(sd, tb + ".norm1", t).reshape(b, f, h, w, c), heads) + t
+        if cond_frame > 0:
+            t0, t = t[:, :cond_frame * h * w], t[:, cond_frame * h * w:]
+        t = feed_forward(sd, tb + ".ff", _ln(sd, tb + ".norm3", t)) + t
+        if cond_frame > 0:
+            t = torch.cat([t0, t], dim=1)
+    x = t.reshape(b, f, h, w, c).permute(0, 4, 1, 2, 3)
+    return conv_frames(sd, p + ".proj_out", x, padding=0) + x_in
+
+
+def resnet_block(sd: SD, p: str, x, temb, groups, eps):
+    """ResnetBlock3D.forward (resnet.py:174-208), output_scale_factor 1."""
+    h = F.silu(group_norm5d(sd, p + ".norm1", x, groups, eps))
+    h = conv_frames(sd, p + ".conv1", h)
+    h = h + _lin(sd, p + ".time_emb_proj", F.silu(temb))[:, :, None, None, None]
+    h = F.silu(group_norm5d(sd, p + ".norm2", h, groups, eps))
+    h = conv_frames(sd, p + ".conv2", h)
+    if (p + ".conv_shortcut.weight") in sd:
+        x = conv_frames(sd, p + ".conv_shortcut", x, padding=0)
+    return x + h
+
+
+def upsample(sd: SD, p: str, x):
+    """Upsample3D: nearest (1,2,2) then conv (resnet.py:47-61)."""
+    x = F.interpolate(x, scale_factor=(1.0, 2.0, 2.0), mode="nearest")
+    return conv_frames(sd, p + ".conv", x)
+
+
+# ------------------------------------------------------------------------------------------------ UNet
+def unet_forward(sd: SD, cfg: dict, sample, timestep, context, cond_frame: int = 0):
+    """SeerUNet.forward (seer/models/unet_3d_condition.py:283-376) incl. block wiring of unet_3d_blocks.py
+    (:210-279 mid, :364-431 down, :484-508, :590-658 up, :707-728)."""
+    c = dict(DEFAULT_CFG); c.update(cfg)
+    boc, lpb, heads = tuple(c["block_out_channels"]), c["layers_per_block"], c["attention_head_dim"]
+    G, eps = c["norm_num_groups"], c["norm_eps"]
+    if c["center_input_sample"]:
+        sample = 2 * sample - 1.0
+    t = timestep
+    if not torch.is_tensor(t):
+        t = torch.tensor([t], dtype=torch.long)
+    elif t.dim() == 0:
+        t = t[None]
+    t = t.broadcast_to(sample.shape[0])
+    emb = timestep_embedding(t, boc[0], c["flip_sin_to_cos"], c["freq_shift"])
+    emb = _lin(sd, "time_embedding.linear_2", F.silu(_lin(sd, "time_embedding.linear_1", emb)))
+
+    x = conv_frames(sd, "conv_in", sample)
+    skips = [x]
+    nlev = len(boc)
+    for i in range(nlev):
+        has_attn = i < nlev - 1                       # ctor hard-wires 3 x CrossAttnDownBlock3D + DownBlock3D (:90)
+        for j in range(lpb):
+            p = f"down_blocks.{i}"
+            x = resnet_block(sd, f"{p}.resnets.{j}", x, emb, G, eps)
+            if has_attn:
+                x = spatial_transformer(sd, f"{p}.attentions.{j}", x, context, heads, False, cond_frame, G)
+                x = spatial_transformer(sd, f"{p}.temporal_attentions.{j}", x, None, heads, True, cond_frame, G)
+            skips.append(x)
+        if i < nlev - 1:
+            x = conv_frames(sd, f"down_blocks.{i}.downsamplers.0.conv", x, stride=2, padding=1)
+            skips.append(x)
+    x = resnet_block(sd, "mid_block.resnets.0", x, emb, G, eps)
+    x = spatial_transformer(sd, "mid_block.attentions.0", x, context, heads, False, cond_frame, G)
+    x = spatial_transformer(sd, "mid_block.temporal_attentions.0", x, None, heads, True, cond_frame, G)
+    x = resnet_block(sd, "mid_block.resnets.1", x, emb, G, eps)
+    for i in range(nlev):
+        has_attn = i > 0                               # UpBlock3D then 3 x CrossAttnUpBlock3D (:91)
+        p = f"up_blocks.{i}"
+        for j in range(lpb + 1):
+            x = torch.cat([x, skips.pop()], dim=1)
+            x = resnet_block(sd, f"{p}.resnets.{j}", x, emb, G, eps)
+            if has_attn:
+                x = spatial_transformer(sd, f"{p}.attentions.{j}", x, context, heads, False, cond_frame, G)
+                x = spatial_transformer(sd, f"{p}.temporal_attentions.{j}", x, None, heads, True, cond_frame, G)
+        if i < nlev - 1:
+            x = upsample(sd, f"{p}.upsamplers.0", x)
+    x = F.silu(group_norm5d(sd, "conv_norm_out", x, G, eps))
+    return conv_frames(sd, "conv_out", x)
+
+
+# ------------------------------------------------------------------------------------------------ DDIM
+def make_schedule(S: int, eta: float = 0.0, timesteps: int = 1000, linear_start=1e-4, linear_end=2e-2):
+    """DDIMSampler.make_schedule (ldm/models/diffusion/ddim_video.py:27-68) + util.py:21-25,46-60,63-74.
+    Returns dict(ddim_timesteps int64[S'], alphas, alphas_prev, sigmas, sqrt_one_minus_alphas) as float64 numpy,
+    exactly the values the reference indexes per step (it converts them with torch.full -> float32)."""
+    betas = (torch.linspace(linear_start ** 0.5, linear_end ** 0.5, timesteps, dtype=torch.float64) ** 2).numpy()
+    alphas_cumprod = np.cumprod(1.0 - betas, axis=0)
+    ac32 = torch.tensor(alphas_cumprod, dtype=torch.float32)            # the reference stores float32 (:40-45)
+    c = timesteps // S
+    ddim_timesteps = np.asarray(list(range(0, timesteps, c))) + 1
+    a32 = ac32[ddim_timesteps].numpy()                                   # float32 values (util.py:65)
+    alphas = a32.astype(np.float64)
+    alphas_prev = np.asarray([float(ac32[0])] + ac32[ddim_timesteps[:-1]].tolist())   # (util.py:66)
+    sigmas = eta * np.sqrt((1 - alphas_prev) / (1 - alphas) * (1 - alphas / alphas_prev))
+    # np.sqrt(1. - ddim_alphas) runs on the float32 tensor, i.e. in float32 (ddim_video.py:63)
+    s1m = np.sqrt(np.float32(1.0) - a32).astype(np.float64)
+    return dict(ddim_timesteps=ddim_timesteps, alphas=alphas, alphas_prev=alphas_prev, sigmas=sigmas,
+                sqrt_one_minus_alphas=s1m)
+
+
+def p_sample_ddim(unet_fn, x, c, t, index, sched, x0_emb=None, scale=1.0, uc=None, cond_frames=0, noise=None):
+    """DDIMSampler.p_sample_ddim (ddim_video.py:183-238), is_3d, batched-CFG branch (:200-204)."""
+    b = x.shape[0]
+    cond_f = 0
+    x_cat = x
+    if x0_emb is not None:
+        cond_f = x0_emb.shape[2]
+        x_cat = torch.cat([x0_emb, x], dim=2)
+    if uc is None or scale == 1.0:
+        e_t = unet_fn(x_cat, t, c, 0)
+        e_t = e_t[:, :, cond_f:]
+    else:
+        assert uc.shape[2] == c.shape[2]
+        e_uc, e_c = unet_fn(torch.cat([x_cat] * 2), torch.cat([t] * 2), torch.cat([uc, c]), cond_frames).chunk(2)
+        e_uc, e_c = e_uc[:, :, cond_f:], e_c[:, :, cond_f:]
+        e_t = e_uc + scale * (e_c - e_uc)
+    f32 = lambda v: torch.full((b, 1, 1, 1, 1), float(v), dtype=torch.float32)
+    a_t, a_prev = f32(sched["alphas"][index]), f32(sched["alphas_prev"][index])
+    sigma_t, s1m = f32(sched["sigmas"][index]), f32(sched["sqrt_one_minus_alphas"][index])
+    pred_x0 = (x - s1m * e_t) / a_t.sqrt()
+    dir_xt = (1.0 - a_prev - sigma_t ** 2).sqrt() * e_t
+    if noise is None:
+        noise = torch.randn(x.shape)                                   # drawn every step even when sigma == 0 (:234)
+    return a_prev.sqrt() * pred_x0 + dir_xt + sigma_t * noise, pred_x0
+
+
+def ddim_sampling(unet_fn, S, shape, c, x_T, x0_emb=None, scale=1.0, uc=None, eta=0.0, cond_frames=0):
+    """DDIMSampler.sample / ddim_sampling (ddim_video.py:71-180): returns (samples, intermediates)."""
+    sched = make_schedule(S, eta)
+    ts = sched["ddim_timesteps"]
+    img = x_T if x_T is not None else torch.randn(shape)
+    inter = {"x_inter": [img], "pred_x0": [img]}
+    total = ts.shape[0]
+    for i, step in enumerate(np.flip(ts)):
+        index = total - i - 1
+        t = torch.full((shape[0],), int(step), dtype=torch.long)
+        img, pred_x0 = p_sample_ddim(unet_fn, img, c, t, index, sched, x0_emb=x0_emb, scale=scale, uc=uc,
+                                     cond_frames=cond_frames)
+        if index % 100 == 0 or index == total - 1:
+            inter["x_inter"].append(img)
+            inter["pred_x0"].append(pred_x0)
+    return img, inter
+
+
+# ------------------------------------------------------------------------------------------------ VAE decoder
+def _vae_norm(sd, p, x):
+    return F.group_norm(x, 32, sd[p + ".weight"], sd[p + ".bias"], 1e-6)      # Normalize (model.py:38-39)
+
+
+def _vae_resnet(sd, p, x):
+    """ResnetBlock.forward, temb None (ldm/modules/diffusionmodules/model.py:121-141)."""
+    h = F.conv2d(F.silu(_vae_norm(sd, p + ".norm1", x)), sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], padding=1)
+    h = F.conv2d(F.silu(_vae_norm(sd, p + ".norm2", h)), sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], padding=1)
+    if (p + ".nin_shortcut.weight") in sd:
+        x = F.conv2d(x, sd[p + ".nin_shortcut.weight"], sd[p + ".nin_shortcut.bias"])
+    return x + h
+
+
+def _vae_attn(sd, p, x):
+    """AttnBlock.forward: single head, scale C^-1/2 (model.py:178-202)."""
+    h = _vae_norm(sd, p + ".norm", x)
+    q, k, v = [F.conv2d(h, sd[f"{p}.{n}.weight"], sd[f"{p}.{n}.bias"]) for n in ("q", "k", "v")]
+    b, c, hh, ww = q.shape
+    w_ = torch.bmm(q.reshape(b, c, -1).permute(0, 2, 1), k.reshape(b, c, -1)) * (int(c) ** -0.5)
+    w_ = w_.softmax(dim=2)
+    o = torch.bmm(v.reshape(b, c, -1), w_.permute(0, 2, 1)).reshape(b, c, hh, ww)
+    return x + F.conv2d(o, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"])
+
+
+def vae_decode(sd: SD, z, ch_mult=(1, 2, 4, 4), num_res_blocks=2):
+    """post_quant_conv (ldm/models/autoencoder.py:330-333) + Decoder.forward (model.py:535-568); ldm key names,
+    `decoder.` prefix for the decoder, `post_quant_conv.` for the 1x1."""
+    z = F.conv2d(z, sd["post_quant_conv.weight"], sd["post_quant_conv.bias"])
+    P = "decoder."
+    h = F.conv2d(z, sd[P + "conv_in.weight"], sd[P + "conv_in.bias"], padding=1)
+    h = _vae_resnet(sd, P + "mid.block_1", h)
+    h = _vae_attn(sd, P + "mid.attn_1", h)
+    h = _vae_resnet(sd, P + "mid.block_2", h)
+    nres = len(ch_mult)
+    for lvl in reversed(range(nres)):
+        for j in range(num_res_blocks + 1):
+            h = _vae_resnet(sd, f"{P}up.{lvl}.block.{j}", h)
+        if lvl != 0:
+            h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+            h = F.conv2d(h, sd[f"{P}up.{lvl}.upsample.conv.weight"], sd[f"{P}up.{lvl}.upsample.conv.bias"], padding=1)
+    h = F.silu(_vae_norm(sd, P + "norm_out", h))
+    return F.conv2d(h, sd[P + "conv_out.weight"], sd[P + "conv_out.bias"], padding=1)
+
+
+def ddim_sample(unet_fn, vae_sd, shape, c, start_code, x0_emb, ddim_steps=10, scale=1.0, uc=None, vae_kwargs=None):
+    """ddim_sample (utils/ddim_sampling_utils.py:21-42): sampler -> 1/0.18215 -> vae.decode -> clamp((x+1)/2, 0, 1)."""
+    if scale == 1.0:
+        uc = None
+    samples, _ = ddim_sampling(unet_fn, ddim_steps, shape, c, start_code, x0_emb=x0_emb, scale=scale, uc=uc, eta=0.0)
+    n, ch, f, h, w = samples.shape
+    z = samples.permute(0, 2, 1, 3, 4).reshape(n * f, ch, h, w) * (1 / 0.18215)
+    x = vae_decode(vae_sd, z, **(vae_kwargs or {}))
+    x = x.reshape(n, f, *x.shape[1:]).permute(0, 2, 1, 3, 4)
+    return torch.clamp((x + 1.0) / 2.0, min=0.0, max=1.0), samples
