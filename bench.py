@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""bench.py -- UNet denoising steps/sec of the Seer DDIM hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one `DDIMSampler.p_sample_ddim`: one CFG-batched SeerUNet forward (B = 2b), CFG combine and the DDIM
+update, on synthetic latents that are already resident in HBM.  Workload = BASELINE config 2 (Sthv2): b=1 (CFG batch 2),
+12 frames total (2 conditioning + 10 predicted), 32x32 latent (256^2 pixels), full-width SD-v1-5-shaped SeerUNet
+(1.08 G parameters, closed-form synthetic weights: there is no network for checkpoints), bf16 storage / fp32 accumulate.
+N > 1 shards ONE clip's step (strong scaling): CFG halves first, then frames (seervideoldm_amd/parallel.py).
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel class (the MFMA GEMM / implicit-GEMM conv template,
+93 % of the step's FLOPs) from HIP-event timings taken inside this process; `cpu_baseline` times the CPU oracle
+(oracle/seer_oracle.py, a port of the reference algorithm) on the host cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+
+MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16
+WORKLOAD = dict(b=1, cond_frames=2, frames=12, latent=32, ddim_steps=50, scale=7.5)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--cpu-budget-s", type=float, default=25.0)
+    return ap.parse_args()
+
+
+def build_inputs(device, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    w = WORKLOAD
+    b, f1, F, h = w["b"], w["cond_frames"], w["frames"], w["latent"]
+    x_T = torch.randn((b, 4, F - f1, h, h), generator=g)
+    x0_emb = torch.randn((b, 4, f1, h, h), generator=g) * 0.18215 * 5
+    c = torch.randn((b, F, 77, 768), generator=g)
+    uc = torch.randn((b, 1, 77, 768), generator=g).expand(-1, F, -1, -1).contiguous()
+    return [t.to(device) for t in (x_T, x0_emb, c, uc)]
+
+
+def gpu_busy(ms: float, device):
+    """queue ~ms of GPU work so that the host runs ahead of the device during event-bracketed launches"""
+    from seervideoldm_amd import ops
+    a = torch.randn(8192, 8192, device=device).to(torch.bfloat16)
+    out = torch.empty(8192, 8192, device=device, dtype=torch.bfloat16)
+    for _ in range(max(1, int(ms / 1.3))):
+        ops.gemm(a, a, out=out, tile=1)
+
+
+def cpu_baseline(sd_cpu, cfg, budget_s):
+    """time the CPU oracle on a bounded sample of the same workload (rank 0, N=1 only)."""
+    from oracle import seer_oracle as O
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    w = WORKLOAD
+    h = w["latent"]
+
+    def one(F):
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn((2, 4, F, h, h), generator=g)
+        c = torch.randn((2, F, 77, 768), generator=g)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            O.unet_forward(sd_cpu, cfg, x, torch.tensor([981, 981]), c, 0)
+        return time.perf_counter() - t0
+
+    t1 = one(1)                                   # also the warm-up
+    F = int(max(1, min(w["frames"], budget_s / max(t1, 1e-3))))
+    tF = one(F) if F > 1 else t1
+    est_full = tF * w["frames"] / F
+    return dict(value=1.0 / est_full, unit="steps/s", cores=ncores, kind="port",
+                sample=f"1 CFG-batched UNet forward (B=2, 32x32 latent, fp32) at F={F} of {w['frames']} frames in "
+                       f"{tF:.1f}s, scaled linearly in F to the full step")
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a ROCm device"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    from seervideoldm_amd import DDIMSampler, SeerUNet, synth
+    from seervideoldm_amd.profiler import TimedOps
+
+    cfg = dict(synth.SD15_UNET_CFG)
+    model = SeerUNet(**cfg).to(device)
+    sd = synth.synth_state_dict(synth.unet_param_shapes(cfg), device=device)
+    model.load_state_dict(sd, strict=True)
+    sd_cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sd_cpu = {k: v.cpu() for k, v in sd.items()}
+    del sd
+    model.eval()
+    shard = None
+    if world > 1:
+        from seervideoldm_amd import parallel
+        shard = parallel.attach(model, world, rank)
+    model.use_graph = not args.no_graph and world == 1
+
+    x_T, x0_emb, c, uc = build_inputs(device)
+    w = WORKLOAD
+    sampler = DDIMSampler(device)
+    sampler.make_schedule(ddim_num_steps=w["ddim_steps"], ddim_eta=0.0, verbose=False)
+    nidx = len(sampler.ddim_timesteps)
+
+    def step(i, x):
+        index = nidx - 1 - (i % nidx)
+        ts = sampler._t_table[index].expand(w["b"])
+        x, _ = sampler.p_sample_ddim(model, x, c, ts, index=index, x0_emb=x0_emb, unconditional_guidance_scale=w["scale"],
+                                     unconditional_conditioning=uc)
+        return x
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    x = x_T
+    for i in range(args.warmup):
+        x = step(i, x)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        x = step(args.warmup + i, x)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(x).all(), "non-finite latent after the timed steps"
+    ms_per_step = dt / args.steps * 1e3
+
+    # ---- roofline of the dominant kernel class: event-bracketed launches, device kept ahead of the host
+    roofline = None
+    if rank == 0:
+        eng = model._engine
+        timed = TimedOps()
+        eng.ops = timed
+        model.use_graph = False
+        reps = 3
+        step(0, x_T)                       # warm (eager path)
+        torch.cuda.synchronize()
+        timed.reset()
+        gpu_busy(60.0, device)
+        for r in range(reps):
+            step(r, x_T)
+        torch.cuda.synchronize()
+        summ = timed.summary()
+        from seervideoldm_amd import ops as plain_ops
+        eng.ops = plain_ops
+        gm = summ["gemm"]
+        per_launch_flops = gm["flops"] / gm["launches"]
+        avg_launch_ms = gm["ms"] / gm["launches"]
+        roofline = dict(bound="mfma", kernel="seer_gemm_kernel (bf16 MFMA GEMM / implicit-GEMM conv3x3, all tiles)",
+                        achieved=round(gm["tflops"], 2), peak=MFMA_BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=round(gm["tflops"] / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), traffic=None,
+                        launches_per_step=gm["launches"] // reps, avg_launch_us=round(avg_launch_ms * 1e3, 2),
+                        algorithmic_gflop_per_launch=round(per_launch_flops / 1e9, 3),
+                        step_breakdown_ms={k: round(v["ms"] / reps, 3) for k, v in summ.items()},
+                        attention_tflops=round(summ.get("attention", {}).get("tflops", 0.0), 2))
+
+    cpu = None
+    if sd_cpu is not None:
+        cpu = cpu_baseline(sd_cpu, cfg, args.cpu_budget_s)
+
+    if rank == 0:
+        par = "single" if world == 1 else shard.describe()
+        line = {
+            "metric": "UNet denoising steps/sec (12-frame 256^2 latent, 50-step DDIM)",
+            "value": round(1e3 / ms_per_step, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "Sthv2 config: CFG batch 2 x 12 frames (2 cond + 10 predicted) x 32x32 latent, "
+                                   "full-width SeerUNet 1.08G params, 50-step DDIM, scale 7.5",
+                       "parallelism": par, "hip_graph": bool(not args.no_graph and world == 1)},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -135,8 +135,10 @@ int seer_groupnorm_apply(const void* x1, int32_t C1, const void* x2, int32_t C2,
 int seer_layernorm(const void* x, int64_t rows, int32_t C, int32_t ldx, const float* gamma, const float* beta,
                    float eps, void* y, int32_t ldy, void* stream);
 
-/* softmax over rows of a bf16 [rows, n] matrix with scale (VAE mid attention, ldm/modules/diffusionmodules/model.py:186-197) */
-int seer_softmax_rows(const void* x, int64_t rows, int32_t n, int32_t ld, float scale, void* y, void* stream);
+/* y = softmax(scale * x) over rows of a [rows, n] matrix, x bf16 or fp32, y bf16 (VAE mid attention,
+ * ldm/modules/diffusionmodules/model.py:186-197) */
+int seer_softmax_rows(const void* x, int32_t x_is_f32, int64_t rows, int32_t n, int32_t ld, float scale, void* y,
+                      int32_t ldy, void* stream);
 
 /* ---- small / boundary kernels ----------------------------------------------------------- */
 /* diffusers Timesteps(320, flip_sin_to_cos, freq_shift) (unet_3d_condition.py:97,307): out[b] = [cos | sin](t*f_i)
@@ -157,6 +159,11 @@ int seer_conv_in(const float* x, int32_t B, int32_t Cin, int32_t F, int32_t H, i
  * (unet_3d_condition.py:205,370).  W fp32 [Cout][3][3][C0]. */
 int seer_conv_out(const void* x, int32_t B, int32_t C0, int32_t F, int32_t H, int32_t W_, const float* Wt,
                   const float* bias, int32_t Cout, float* y, void* stream);
+
+/* pointwise channel mix on NCHW fp32: the VAE's post_quant_conv (1x1, 4->4; ldm/models/autoencoder.py:330-333).
+ * W fp32 [Cout][Cin]. */
+int seer_conv1x1_nchw_f32(const float* x, int32_t N, int32_t Cin, int32_t Cout, int32_t HW, const float* Wt,
+                          const float* bias, float* y, void* stream);
 
 /* layout / dtype conversion: fp32 [rows, C] -> bf16 (context, weights) */
 int seer_cast_f32_bf16(const float* x, int64_t n, void* y, void* stream);

@@ -69,7 +69,8 @@ SIGNATURES = {
     "seer_groupnorm_stats": ([_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _vp], C.c_int),
     "seer_groupnorm_apply": ([_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _f64, _f32, _vp, _vp, _i32, _vp, _vp], C.c_int),
     "seer_layernorm": ([_vp, _i64, _i32, _i32, _vp, _vp, _f32, _vp, _i32, _vp], C.c_int),
-    "seer_softmax_rows": ([_vp, _i64, _i32, _i32, _f32, _vp, _vp], C.c_int),
+    "seer_softmax_rows": ([_vp, _i32, _i64, _i32, _i32, _f32, _vp, _i32, _vp], C.c_int),
+    "seer_conv1x1_nchw_f32": ([_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp], C.c_int),
     "seer_timestep_embedding": ([_vp, _i32, _i32, _i32, _f32, _vp, _vp], C.c_int),
     "seer_linear_smallm": ([_vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp], C.c_int),
     "seer_conv_in": ([_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp], C.c_int),

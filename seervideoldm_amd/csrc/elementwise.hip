@@ -259,6 +259,19 @@ __global__ void cfg_ddim_kernel(const float* __restrict__ eps, int cfg, int b, i
     if (pred_x0) pred_x0[i] = x0;
 }
 
+// pointwise channel mix on NCHW fp32 (VAE post_quant_conv, 4 -> 4): y[n,co,p] = sum_ci W[co,ci] x[n,ci,p] + b[co]
+__global__ void conv1x1_nchw_kernel(const float* __restrict__ x, int N, int Cin, int Cout, int HW,
+                                    const float* __restrict__ Wt, const float* __restrict__ bias, float* __restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * Cout * HW) return;
+    const int p = (int)(i % HW);
+    const int co = (int)((i / HW) % Cout);
+    const int n = (int)(i / ((int64_t)HW * Cout));
+    float acc = bias ? bias[co] : 0.f;
+    for (int ci = 0; ci < Cin; ++ci) acc += Wt[co * Cin + ci] * x[((int64_t)n * Cin + ci) * HW + p];
+    y[i] = acc;
+}
+
 __global__ void clamp01_kernel(float* __restrict__ x, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
@@ -367,6 +380,16 @@ extern "C" int seer_cfg_ddim_step(const float* eps, int32_t cfg, int32_t b, int3
     const int64_t n = (int64_t)b * C * (F_total - cond_f) * HW;
     hipLaunchKernelGGL(cfg_ddim_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), eps, cfg, b, C,
                        F_total, cond_f, HW, scale, coef, index, x, noise, x_prev, pred_x0);
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int seer_conv1x1_nchw_f32(const float* x, int32_t N, int32_t Cin, int32_t Cout, int32_t HW, const float* Wt,
+                                     const float* bias, float* y, void* stream) {
+    if (!x || !Wt || !y || N <= 0 || Cin <= 0 || Cout <= 0 || HW <= 0) return SEER_EINVAL;
+    const int64_t n = (int64_t)N * Cout * HW;
+    hipLaunchKernelGGL(conv1x1_nchw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), x, N, Cin, Cout,
+                       HW, Wt, bias, y);
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }

@@ -178,9 +178,9 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const bf16* __restrict__
 }
 
 // row softmax(x * scale): one wave per row, n <= 64*8*MAXC
-template <int MAXC>
-__global__ void __launch_bounds__(256) softmax_rows_kernel(const bf16* __restrict__ x, int64_t rows, int n, int ld,
-                                                           float scale, bf16* __restrict__ y) {
+template <int MAXC, bool IN_F32>
+__global__ void __launch_bounds__(256) softmax_rows_kernel(const void* __restrict__ xv, int64_t rows, int n, int ld,
+                                                           float scale, bf16* __restrict__ y, int ldy) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
@@ -191,8 +191,15 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(const bf16* __restric
     for (int i = 0; i < MAXC; ++i) {
         const int ch = lane + 64 * i;
         if (ch < nch) {
-            const u32x4 v = *reinterpret_cast<const u32x4*>(x + r * ld + ch * 8);
-            unpack8(v, f[i]);
+            if constexpr (IN_F32) {
+                const float* x = reinterpret_cast<const float*>(xv) + r * ld + ch * 8;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(x), b = *reinterpret_cast<const f32x4*>(x + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { f[i][e] = a[e]; f[i][4 + e] = b[e]; }
+            } else {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16*>(xv) + r * ld + ch * 8);
+                unpack8(v, f[i]);
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) { f[i][e] *= scale; mx = fmaxf(mx, f[i][e]); }
         }
@@ -215,7 +222,7 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(const bf16* __restric
             float o[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = f[i][e] * inv;
-            *reinterpret_cast<u32x4*>(y + r * ld + ch * 8) = pack8(o);
+            *reinterpret_cast<u32x4*>(y + r * ldy + ch * 8) = pack8(o);
         }
     }
 }
@@ -280,17 +287,22 @@ extern "C" int seer_layernorm(const void* x, int64_t rows, int32_t C, int32_t ld
     return SEER_OK;
 }
 
-extern "C" int seer_softmax_rows(const void* x, int64_t rows, int32_t n, int32_t ld, float scale, void* y,
-                                 void* stream) {
-    if (!x || !y || rows <= 0 || n <= 0 || n % 8 || ld % 8) return SEER_EINVAL;
+extern "C" int seer_softmax_rows(const void* x, int32_t x_is_f32, int64_t rows, int32_t n, int32_t ld, float scale,
+                                 void* y, int32_t ldy, void* stream) {
+    if (!x || !y || rows <= 0 || n <= 0 || n % 8 || ld % 8 || ldy % 8) return SEER_EINVAL;
     if (n > 64 * 8 * 8) return SEER_ENOSYS;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const bf16* xb = reinterpret_cast<const bf16*>(x);
     bf16* yb = reinterpret_cast<bf16*>(y);
     dim3 grid((unsigned)((rows + 3) / 4));
-    if (n <= 1024) hipLaunchKernelGGL(softmax_rows_kernel<2>, grid, dim3(256), 0, st, xb, rows, n, ld, scale, yb);
-    else if (n <= 2048) hipLaunchKernelGGL(softmax_rows_kernel<4>, grid, dim3(256), 0, st, xb, rows, n, ld, scale, yb);
-    else hipLaunchKernelGGL(softmax_rows_kernel<8>, grid, dim3(256), 0, st, xb, rows, n, ld, scale, yb);
+#define SEER_SM(MC)                                                                                                   \
+    do {                                                                                                              \
+        if (x_is_f32) hipLaunchKernelGGL((softmax_rows_kernel<MC, true>), grid, dim3(256), 0, st, x, rows, n, ld, scale, yb, ldy); \
+        else hipLaunchKernelGGL((softmax_rows_kernel<MC, false>), grid, dim3(256), 0, st, x, rows, n, ld, scale, yb, ldy);         \
+    } while (0)
+    if (n <= 1024) SEER_SM(2);
+    else if (n <= 2048) SEER_SM(4);
+    else SEER_SM(8);
+#undef SEER_SM
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }

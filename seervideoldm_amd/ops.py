@@ -79,7 +79,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias=None, residual=None, rowvec=N
 
 
 def gemm_batched(a: torch.Tensor, w: torch.Tensor, *, trans_out=False, out: Optional[torch.Tensor] = None,
-                 tile=0) -> torch.Tensor:
+                 bias: Optional[torch.Tensor] = None, out_f32=False, tile=0) -> torch.Tensor:
     """a [Bt, M, K], w [Bt, N, K] (or [N, K] shared) -> out [Bt, M, N] (or [Bt, N, M] with trans_out)."""
     _req(a, bf16, "a"); _req(w, bf16, "w")
     assert a.dim() == 3 and a.is_contiguous() and w.is_contiguous()
@@ -90,14 +90,17 @@ def gemm_batched(a: torch.Tensor, w: torch.Tensor, *, trans_out=False, out: Opti
     d.lda = K
     d.M, d.N, d.K, d.K1 = M, N, K, K
     if out is None:
-        out = torch.empty((Bt, N, M) if trans_out else (Bt, M, N), device=a.device, dtype=bf16)
+        out = torch.empty((Bt, N, M) if trans_out else (Bt, M, N), device=a.device,
+                          dtype=torch.float32 if out_f32 else bf16)
     d.C = _p(out)
+    if bias is not None:
+        _req(bias, torch.float32, "bias"); d.bias = _p(bias)
     d.ldc = M if trans_out else N
     d.batch = Bt
     d.strideA = M * K
     d.strideW = N * K if w.dim() == 3 else 0
     d.strideC = M * N
-    d.epilogue = _lib.SEER_EPI_TRANS_OUT if trans_out else 0
+    d.epilogue = (_lib.SEER_EPI_TRANS_OUT if trans_out else 0) | (_lib.SEER_EPI_OUT_F32 if out.dtype == torch.float32 else 0)
     d.tile = tile
     check(_lib.load().seer_gemm_bf16(C.byref(d), _stream()), "seer_gemm_bf16(batched)")
     return out
@@ -224,14 +227,28 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
 
 
 def softmax_rows(x: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    _req(x, bf16, "x")
+    """softmax(scale * x) over the last dim; x bf16 or fp32 -> bf16."""
+    assert x.dtype in (bf16, torch.float32) and x.is_cuda
     x2 = x.reshape(-1, x.shape[-1])
     assert x2.is_contiguous()
     if out is None:
-        out = torch.empty_like(x)
-    check(_lib.load().seer_softmax_rows(_p(x2), x2.shape[0], x2.shape[1], x2.stride(0), float(scale), _p(out),
-                                        _stream()), "seer_softmax_rows")
+        out = torch.empty(x.shape, device=x.device, dtype=bf16)
+    check(_lib.load().seer_softmax_rows(_p(x2), int(x.dtype == torch.float32), x2.shape[0], x2.shape[1], x2.stride(0),
+                                        float(scale), _p(out), x2.shape[1], _stream()), "seer_softmax_rows")
     return out
+
+
+def conv1x1_nchw(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """pointwise conv on NCHW fp32 (VAE post_quant_conv); w fp32 [Cout, Cin]."""
+    _req(x, torch.float32, "x"); _req(w, torch.float32, "w")
+    x = x.contiguous()
+    N, Cin = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * Cin)
+    Cout = w.shape[0]
+    y = torch.empty((N, Cout) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
+    check(_lib.load().seer_conv1x1_nchw_f32(_p(x), N, Cin, Cout, HW, _p(w), _p(bias), _p(y), _stream()),
+          "seer_conv1x1_nchw_f32")
+    return y
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -1,0 +1,88 @@
+"""Per-kernel-class timing for the roofline line of bench.py: a drop-in proxy for `seervideoldm_amd.ops` that brackets
+every launch with HIP events on the launch stream (torch's current stream IS the stream the C ABI launches on) and
+accounts the ALGORITHMIC work of the call (GEMM 2MNK, conv 2*M*Co*9*Ci, attention 4*BH*Sq*Sk*d dense,
+norms 2 passes * 2 bytes)."""
+from __future__ import annotations
+
+from collections import defaultdict
+
+import torch
+
+from . import ops as _ops
+
+
+class TimedOps:
+    def __init__(self, base=_ops):
+        self._base = base
+        self.records = defaultdict(list)      # class -> [(start_evt, end_evt, flops, bytes)]
+
+    def _timed(self, cls, flops, nbytes, fn, *a, **k):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = fn(*a, **k)
+        e.record()
+        self.records[cls].append((s, e, flops, nbytes))
+        return out
+
+    # --- MFMA GEMM family (one kernel template: seer_gemm_kernel) ---------------------------------------------
+    def gemm(self, a, w, **k):
+        M, N, K = a.shape[0], w.shape[0], w.shape[1]
+        n_out = N // 2 if k.get("geglu") else N
+        nbytes = 2 * (M * K + N * K + M * n_out) + (2 * M * n_out if k.get("residual") is not None else 0)
+        return self._timed("gemm", 2.0 * M * N * K, nbytes, self._base.gemm, a, w, **k)
+
+    def gemm_batched(self, a, w, **k):
+        Bt, M, K = a.shape
+        N = w.shape[-2]
+        return self._timed("gemm", 2.0 * Bt * M * N * K, 2 * Bt * (M * K + N * K + M * N), self._base.gemm_batched, a, w, **k)
+
+    def conv3x3(self, x, w, n_img, Hin, Win, **k):
+        stride, up = k.get("stride", 1), k.get("upsample", False)
+        Hs, Ws = (2 * Hin, 2 * Win) if up else (Hin, Win)
+        Ho, Wo = (Hs - 1) // stride + 1, (Ws - 1) // stride + 1
+        M, Co, K = n_img * Ho * Wo, w.shape[0], w.shape[1]
+        nbytes = 2 * (x.numel() + w.numel() + M * Co)
+        return self._timed("gemm", 2.0 * M * Co * K, nbytes, self._base.conv3x3, x, w, n_img, Hin, Win, **k)
+
+    def attention(self, q, k_, v, out, **k):
+        nb = k["batch"]
+        if k.get("window") is not None:
+            ws, F, H, W = k["window"]
+            nb *= (H // ws) * (W // ws)
+        flops = 4.0 * nb * k["heads"] * k["Sq"] * k["Sk"] * k["head_dim"]
+        nbytes = 2 * k["heads"] * k["head_dim"] * nb * (2 * k["Sq"] + 2 * k["Sk"])
+        return self._timed("attention", flops, nbytes, self._base.attention, q, k_, v, out, **k)
+
+    def _bw(self, name, passes_bytes):
+        def f(*a, **k):
+            return self._timed(name, 0.0, passes_bytes(*a, **k), getattr(self._base, name), *a, **k)
+        return f
+
+    def __getattr__(self, name):
+        base = getattr(self._base, name)
+        if name in ("groupnorm_stats",):
+            return self._bw(name, lambda x1, x2, *a, **k: 2 * (x1.numel() + (0 if x2 is None else x2.numel())))
+        if name in ("groupnorm_apply",):
+            return self._bw(name, lambda x1, x2, *a, **k: 4 * (x1.numel() + (0 if x2 is None else x2.numel())))
+        if name in ("layernorm",):
+            return self._bw(name, lambda x, *a, **k: 4 * x.numel())
+        if name in ("rotary_inplace",):
+            return self._bw(name, lambda x, *a, **k: 0)
+        if callable(base) and name in ("conv_in", "conv_out", "linear_smallm", "timestep_embedding", "cast_bf16"):
+            return self._bw(name, lambda *a, **k: 0)
+        return base
+
+    def summary(self):
+        """class -> dict(launches, ms, flops, bytes, tflops, gbps); call after torch.cuda.synchronize()."""
+        out = {}
+        for cls, recs in self.records.items():
+            ms = sum(s.elapsed_time(e) for s, e, _, _ in recs)
+            fl = sum(r[2] for r in recs)
+            by = sum(r[3] for r in recs)
+            out[cls] = dict(launches=len(recs), ms=ms, flops=fl, bytes=by,
+                            tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                            gbps=by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0)
+        return out
+
+    def reset(self):
+        self.records.clear()

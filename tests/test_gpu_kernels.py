@@ -294,6 +294,7 @@ def test_softmax_rows(device):
     from seervideoldm_amd import ops
     x = (_rand((300, 1024), device, 1) * 4).to(bf16)
     y = ops.softmax_rows(x, 0.37)
+    _close(ops.softmax_rows(x.float(), 0.37), (x.float() * 0.37).softmax(-1), rtol=2e-2, atol=1e-4, what="softmax f32 in")
     _close(y, (x.float() * 0.37).softmax(-1), rtol=2e-2, atol=1e-4, what="softmax")
 
 
