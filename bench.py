@@ -65,10 +65,36 @@ def gpu_busy(ms: float, device):
         ops.gemm(a, a, out=out, tile=1)
 
 
+def host_threads() -> int:
+    """threads for the CPU baseline: the CPUs this process may actually use (affinity and cgroup quota), then the count
+    that runs a probe matmul fastest (256 logical CPUs oversubscribed by a small quota run an order of magnitude slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    a = torch.randn(1536, 1536)
+    best, best_t = 1, float("inf")
+    for c in (4, 8, 16, 32, 64, 128):
+        if c > n:
+            break
+        torch.set_num_threads(c)
+        a @ a
+        t0 = time.perf_counter()
+        for _ in range(3):
+            a @ a
+        dt = time.perf_counter() - t0
+        if dt < best_t * 0.9:
+            best, best_t = c, dt
+    return best
+
+
 def cpu_baseline(sd_cpu, cfg, budget_s):
     """time the CPU oracle on a bounded sample of the same workload (rank 0, N=1 only)."""
     from oracle import seer_oracle as O
-    ncores = os.cpu_count() or 1
+    ncores = host_threads()
     torch.set_num_threads(ncores)
     w = WORKLOAD
     h = w["latent"]

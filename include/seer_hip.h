@@ -101,8 +101,12 @@ typedef struct seer_attn_desc {
     int32_t Sq, Sk;
     int32_t causal;
     float scale;
-    /* temporal windows (0 = off) */
+    /* temporal windows (0 = off): K/V hold F frames per batch element, Q/O hold Fq (== F unless frame-sharded) */
     int32_t window_ws, F, H, W;
+    int32_t Fq;
+    /* causal: key j visible to query i iff j <= i + causal_offset (0 unless the queries are a frame shard whose first
+     * query sits at sequence position causal_offset of the key sequence) */
+    int32_t causal_offset;
 } seer_attn_desc;
 
 int seer_attn_fwd(const seer_attn_desc* desc /* host */, void* stream);
@@ -121,12 +125,15 @@ int seer_rotary_inplace(void* x, int64_t rows, int32_t ld, int32_t col0_q, int32
 /* ---- normalisation ---------------------------------------------------------------------- */
 /* GroupNorm over (C/G, F, H, W) per (b, g) on channels-last data -- torch.nn.GroupNorm applied to the 5-D
  * tensor (resnet.py:179,197; attention.py:133; unet_3d_condition.py:368).  Two sources = channel concat.
- * stats: accumulates (sum, sumsq) into stats[b][g][2] (fp32, must be zeroed by the caller: one arena memset
- * per UNet forward).  Under frame sharding the caller all-reduces `stats` between the two calls.
+ * stats: writes (sum, sumsq) per (b, g) to stats[b][g][2] (fp32).  Deterministic: per-block partials go to `workspace`
+ * (seer_groupnorm_workspace_floats(...) floats) and are added in block order -- no float atomics, so two runs, or two
+ * identical batch elements, give bit-identical statistics.  Under frame sharding the caller all-reduces `stats`
+ * between the two calls.
  * apply: y = (x-mean)*rstd*gamma+beta, optional SiLU, bf16 out [rows, C1+C2]; count = elements per group over
  * ALL shards (so mean = sum/count). */
+int64_t seer_groupnorm_workspace_floats(int32_t C, int32_t batch, int64_t rows_per_batch, int32_t groups);
 int seer_groupnorm_stats(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t batch,
-                         int64_t rows_per_batch, int32_t groups, float* stats, void* stream);
+                         int64_t rows_per_batch, int32_t groups, float* stats, float* workspace, void* stream);
 int seer_groupnorm_apply(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t batch,
                          int64_t rows_per_batch, int32_t groups, const float* stats, double count, float eps,
                          const float* gamma, const float* beta, int32_t silu, void* y, void* stream);

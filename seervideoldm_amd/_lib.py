@@ -13,7 +13,7 @@ _PKG = Path(__file__).resolve().parent
 _LIB_PATH = _PKG / "lib" / "libseer_hip.so"
 _lib = None
 
-ABI_VERSION = 1
+ABI_VERSION = 3
 
 SEER_GEMM_PLAIN = 0
 SEER_GEMM_CONV3X3 = 1
@@ -52,6 +52,7 @@ class AttnDesc(C.Structure):
         ("batch", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32),
         ("Sq", C.c_int32), ("Sk", C.c_int32), ("causal", C.c_int32), ("scale", C.c_float),
         ("window_ws", C.c_int32), ("F", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+        ("Fq", C.c_int32), ("causal_offset", C.c_int32),
     ]
 
 
@@ -66,7 +67,8 @@ SIGNATURES = {
     "seer_attn_fwd": ([C.POINTER(AttnDesc), _vp], C.c_int),
     "seer_rotary_table": ([_vp, _i32, _i32, _vp, _vp], C.c_int),
     "seer_rotary_inplace": ([_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp], C.c_int),
-    "seer_groupnorm_stats": ([_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _vp], C.c_int),
+    "seer_groupnorm_workspace_floats": ([_i32, _i32, _i64, _i32], C.c_int64),
+    "seer_groupnorm_stats": ([_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _vp], C.c_int),
     "seer_groupnorm_apply": ([_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _f64, _f32, _vp, _vp, _i32, _vp, _vp], C.c_int),
     "seer_layernorm": ([_vp, _i64, _i32, _i32, _vp, _vp, _f32, _vp, _i32, _vp], C.c_int),
     "seer_softmax_rows": ([_vp, _i32, _i64, _i32, _i32, _f32, _vp, _i32, _vp], C.c_int),

@@ -118,10 +118,12 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
     const float cscale = p.scale * 1.4426950408889634f;
 
     // keys this block needs: causal -> up to the last query of the block
+    // causal: key j is visible to query i iff j <= i + q_off (q_off = sequence position of this shard's first query)
+    const int q_off = p.causal_offset;
     int k_end = p.Sk;
     if (p.causal) {
         const int lastq = min(qblk0 + 127, p.Sq - 1);
-        k_end = min(p.Sk, lastq + 1);
+        k_end = min(p.Sk, lastq + q_off + 1);
     }
     const int ntiles = (k_end + KT - 1) / KT;
 
@@ -167,7 +169,7 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
         for (int sub = 0; sub < 2; ++sub) {
             const int kb = kt0 + sub * 32;                 // first key of this 32-key sub tile
             if (kb >= k_end) continue;
-            if (p.causal && kb > q0 + 31) continue;        // wave-uniform: fully above the diagonal
+            if (p.causal && kb > q0 + 31 + q_off) continue; // wave-uniform: fully above the diagonal
 
             // ---- S^T = K Q^T  (rows = keys, cols = queries)
             f32x16 sacc;
@@ -181,13 +183,13 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
             }
 
             // ---- scale (+ mask on boundary tiles)
-            const bool need_mask = (kb + 31 >= p.Sk) || (p.causal && (kb + 31 > q0));
+            const bool need_mask = (kb + 31 >= p.Sk) || (p.causal && (kb + 31 > q0 + q_off));
             float mx = kNegInf;
             if (need_mask) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const bool ok = (key < p.Sk) && (!p.causal || key <= qi);
+                    const bool ok = (key < p.Sk) && (!p.causal || key <= qi + q_off);
                     const float x = ok ? sacc[r] * cscale : kNegInf;
                     sacc[r] = x;
                     mx = fmaxf(mx, x);
@@ -296,8 +298,9 @@ extern "C" int seer_attn_fwd(const seer_attn_desc* desc, void* stream) {
         if (d.window_ws != 4 && d.window_ws != 8) return SEER_EINVAL;
         ws_log2 = d.window_ws == 4 ? 2 : 3;
         if (d.H % d.window_ws || d.W % d.window_ws) return SEER_EINVAL;
-        if (d.Sq != d.F * d.window_ws * d.window_ws || d.Sk != d.Sq) return SEER_EINVAL;
+        if (d.Fq <= 0 || d.Sq != d.Fq * d.window_ws * d.window_ws || d.Sk != d.F * d.window_ws * d.window_ws) return SEER_EINVAL;
     }
+    if (d.causal_offset < 0 || (d.causal && d.Sq + d.causal_offset > d.Sk)) return SEER_EINVAL;
     switch (d.head_dim) {
         case 40: return launch_attn<40>(d, ws_log2, st);
         case 80: return launch_attn<80>(d, ws_log2, st);

@@ -5,27 +5,30 @@
 
 namespace {
 
-constexpr int GN_RPB = 64;   // rows per block
+constexpr int GN_MAX_RPB = 64;   // rows per block (upper bound)
 
 struct GnGeom {
     int ncols;          // 16-byte chunk columns = (C1+C2)/8
     int ncols1;         // columns that come from x1
     int C1, C2, cpg;
+    int rpb;            // rows per block
+    int nblk;           // blocks per batch element
 };
 
-// thread -> (row lane, chunk column) with a FIXED column per pass so that per-column constants / partial sums stay in
+// thread -> (row lane rl, chunk column) with a FIXED column per pass so that per-column constants / partial sums stay in
 // registers.  cols_per_pass = min(ncols, 256); rows_par = 256 / cols_per_pass.
+//
+// Statistics are DETERMINISTIC (no float atomics): every thread parks its per-column partial sums in LDS, `groups`
+// threads then add the contributions of their group in a fixed order and the block writes its partial
+// (sum, sumsq)[groups] to `partials[b][blk]`; gn_finalize_kernel adds the per-block partials in block order.
 __global__ void __launch_bounds__(256) gn_stats_kernel(const bf16* __restrict__ x1, const bf16* __restrict__ x2,
                                                        GnGeom g, int64_t rows_per_batch, int groups,
-                                                       float* __restrict__ stats) {
-    __shared__ float bins[2 * 64];   // [groups][2], groups <= 64
+                                                       float* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) float slots[];   // [rows_par][ncols][4] = (sa, qa, sb, qb)
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
-    for (int i = tid; i < 2 * groups; i += 256) bins[i] = 0.f;
-    __syncthreads();
-
-    const int64_t r0 = (int64_t)blockIdx.x * GN_RPB;
-    const int64_t r1 = min(r0 + GN_RPB, rows_per_batch);
+    const int64_t r0 = (int64_t)blockIdx.x * g.rpb;
+    const int64_t r1 = min(r0 + g.rpb, rows_per_batch);
     const int cpp = g.ncols < 256 ? g.ncols : 256;
     const int rows_par = 256 / cpp;
     const int rl = tid / cpp;
@@ -41,6 +44,7 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const bf16* __restrict__ 
             const int ga = c0 / g.cpg;
             const int split = (ga + 1) * g.cpg - c0;   // elements [0, split) belong to ga, the rest to ga+1
             float sa = 0.f, qa = 0.f, sb = 0.f, qb = 0.f;
+#pragma unroll 4
             for (int64_t r = r0 + rl; r < r1; r += rows_par) {
                 const u32x4 v = *reinterpret_cast<const u32x4*>(src + ((int64_t)b * rows_per_batch + r) * ld);
                 float f[8];
@@ -51,16 +55,45 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const bf16* __restrict__ 
                     else { sb += f[e]; qb += f[e] * f[e]; }
                 }
             }
-            atomicAdd(&bins[2 * ga], sa);
-            atomicAdd(&bins[2 * ga + 1], qa);
-            if (split < 8) {
-                atomicAdd(&bins[2 * (ga + 1)], sb);
-                atomicAdd(&bins[2 * (ga + 1) + 1], qb);
-            }
+            *reinterpret_cast<f32x4*>(slots + ((int64_t)rl * g.ncols + col) * 4) = f32x4{sa, qa, sb, qb};
         }
     }
     __syncthreads();
-    for (int i = tid; i < 2 * groups; i += 256) atomicAdd(&stats[(int64_t)b * groups * 2 + i], bins[i]);
+    if (tid < groups) {
+        const int c_lo = tid * g.cpg, c_hi = c_lo + g.cpg - 1;
+        float s = 0.f, q = 0.f;
+        for (int col = c_lo / 8; col <= c_hi / 8; ++col) {
+            const bool is_a = (col * 8) / g.cpg == tid;          // this group is the column's first group
+            for (int r = 0; r < rows_par; ++r) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(slots + ((int64_t)r * g.ncols + col) * 4);
+                s += is_a ? v[0] : v[2];
+                q += is_a ? v[1] : v[3];
+            }
+        }
+        float* o = partials + (((int64_t)b * g.nblk + blockIdx.x) * groups + tid) * 2;
+        o[0] = s;
+        o[1] = q;
+    }
+}
+
+// stats[b][g][2] = sum over blocks (fixed order: 4 contiguous slices, then the 4 slice sums in order)
+__global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ partials, int nblk, int groups,
+                                                          float* __restrict__ stats) {
+    __shared__ float part[4][128];
+    const int b = blockIdx.x;
+    const int n = groups * 2;                 // <= 128
+    const int s = threadIdx.x & 127, slice = threadIdx.x >> 7;    // 2 slices x 128 stats with 256 threads
+    float acc = 0.f;
+    if (s < n) {
+        const int per = (nblk + 1) / 2;
+        const int k0 = slice * per, k1 = min(nblk, k0 + per);
+        const float* p = partials + ((int64_t)b * nblk) * n + s;
+#pragma unroll 8
+        for (int k = k0; k < k1; ++k) acc += p[(int64_t)k * n];
+        part[slice][s] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < n) stats[(int64_t)b * n + threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x];
 }
 
 __global__ void __launch_bounds__(256) gn_apply_kernel(const bf16* __restrict__ x1, const bf16* __restrict__ x2,
@@ -82,8 +115,8 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const bf16* __restrict__ 
     }
     __syncthreads();
 
-    const int64_t r0 = (int64_t)blockIdx.x * GN_RPB;
-    const int64_t r1 = min(r0 + GN_RPB, rows_per_batch);
+    const int64_t r0 = (int64_t)blockIdx.x * g.rpb;
+    const int64_t r1 = min(r0 + g.rpb, rows_per_batch);
     const int cpp = g.ncols < 256 ? g.ncols : 256;
     const int rows_par = 256 / cpp;
     const int rl = tid / cpp;
@@ -105,6 +138,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const bf16* __restrict__ 
             sc[e] = a;
             sh[e] = beta[c0 + e] - mean_s[grp] * a;
         }
+#pragma unroll 4
         for (int64_t r = r0 + rl; r < r1; r += rows_par) {
             const int64_t row = (int64_t)b * rows_per_batch + r;
             const u32x4 v = *reinterpret_cast<const u32x4*>(src + row * ld);
@@ -227,7 +261,7 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(const void* __restric
     }
 }
 
-bool gn_geom(int C1, int C2, int groups, GnGeom* g) {
+bool gn_geom(int C1, int C2, int groups, int batch, int64_t rows_per_batch, GnGeom* g) {
     const int C = C1 + C2;
     if (C1 <= 0 || C2 < 0 || groups <= 0 || groups > 64) return false;
     if (C % groups || C1 % 8 || C2 % 8) return false;
@@ -236,21 +270,42 @@ bool gn_geom(int C1, int C2, int groups, GnGeom* g) {
     g->C1 = C1; g->C2 = C2;
     g->ncols = C / 8;
     g->ncols1 = C1 / 8;
+    // rows per block: aim at ~1024 blocks so that small (deep-level) tensors still fill the 256 CUs
+    const int cpp = g->ncols < 256 ? g->ncols : 256;
+    const int rows_par = 256 / cpp;
+    int64_t rpb = (rows_per_batch * batch + 1023) / 1024;
+    rpb = (rpb + rows_par - 1) / rows_par * rows_par;
+    if (rpb < rows_par) rpb = rows_par;
+    if (rpb > GN_MAX_RPB) rpb = GN_MAX_RPB / rows_par * rows_par;
+    if (rpb < 1) rpb = 1;
+    g->rpb = (int)rpb;
+    g->nblk = (int)((rows_per_batch + rpb - 1) / rpb);
     return true;
 }
 
 }  // namespace
 
-extern "C" int seer_groupnorm_stats(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t batch,
-                                    int64_t rows_per_batch, int32_t groups, float* stats, void* stream) {
+extern "C" int64_t seer_groupnorm_workspace_floats(int32_t C, int32_t batch, int64_t rows_per_batch, int32_t groups) {
     GnGeom g;
-    if (!x1 || !stats || batch <= 0 || rows_per_batch <= 0) return SEER_EINVAL;
+    if (!gn_geom(C, 0, groups, batch, rows_per_batch, &g)) return SEER_EINVAL;
+    return (int64_t)batch * g.nblk * groups * 2;
+}
+
+extern "C" int seer_groupnorm_stats(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t batch,
+                                    int64_t rows_per_batch, int32_t groups, float* stats, float* workspace,
+                                    void* stream) {
+    GnGeom g;
+    if (!x1 || !stats || !workspace || batch <= 0 || rows_per_batch <= 0) return SEER_EINVAL;
     if (!x2) C2 = 0;
-    if (!gn_geom(C1, C2, groups, &g)) return SEER_EINVAL;
-    dim3 grid((unsigned)((rows_per_batch + GN_RPB - 1) / GN_RPB), batch);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       reinterpret_cast<const bf16*>(x1), reinterpret_cast<const bf16*>(x2), g, rows_per_batch, groups,
-                       stats);
+    if (!gn_geom(C1, C2, groups, batch, rows_per_batch, &g)) return SEER_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int cpp = g.ncols < 256 ? g.ncols : 256;
+    const size_t lds = (size_t)(256 / cpp) * g.ncols * 4 * sizeof(float);
+    dim3 grid((unsigned)g.nblk, batch);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), lds, st, reinterpret_cast<const bf16*>(x1),
+                       reinterpret_cast<const bf16*>(x2), g, rows_per_batch, groups, workspace);
+    SEER_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(256), 0, st, workspace, g.nblk, groups, stats);
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }
@@ -262,8 +317,8 @@ extern "C" int seer_groupnorm_apply(const void* x1, int32_t C1, const void* x2, 
     GnGeom g;
     if (!x1 || !stats || !gamma || !beta || !y || batch <= 0 || rows_per_batch <= 0 || count <= 0) return SEER_EINVAL;
     if (!x2) C2 = 0;
-    if (!gn_geom(C1, C2, groups, &g)) return SEER_EINVAL;
-    dim3 grid((unsigned)((rows_per_batch + GN_RPB - 1) / GN_RPB), batch);
+    if (!gn_geom(C1, C2, groups, batch, rows_per_batch, &g)) return SEER_EINVAL;
+    dim3 grid((unsigned)g.nblk, batch);
     hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        reinterpret_cast<const bf16*>(x1), reinterpret_cast<const bf16*>(x2), g, rows_per_batch, groups,
                        stats, (float)(1.0 / count), eps, gamma, beta, silu, reinterpret_cast<bf16*>(y));

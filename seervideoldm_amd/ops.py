@@ -144,22 +144,25 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, n_img: int, Hin: int, Win: int, *,
 # ------------------------------------------------------------------------------------------------------------
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *, batch: int, heads: int,
               head_dim: int, Sq: int, Sk: int, causal=False, scale: Optional[float] = None,
-              window=None) -> torch.Tensor:
+              window=None, Fq: Optional[int] = None, causal_offset: int = 0) -> torch.Tensor:
     """q/k/v/out are 2-D token-major views [batch*S, >=heads*head_dim] (row stride = token stride, e.g. column slices
-    of a fused qkv buffer).  window = (ws, F, H, W) selects the temporal window form (S = F*H*W tokens per batch
-    element in memory, Sq = Sk = F*ws*ws per window)."""
+    of a fused qkv buffer).  window = (ws, F, H, W) selects the temporal window form (K/V: F*H*W tokens per batch
+    element in memory, Sk = F*ws*ws per window; Q/O hold Fq frames, Fq = F unless frame-sharded).  causal_offset is the
+    sequence position of query 0 in the key sequence (frame shards)."""
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (out, "out")):
         _req(t, bf16, n)
         assert t.dim() == 2 and t.stride(1) == 1
     d = AttnDesc()
     d.Q, d.K, d.V, d.O = _p(q), _p(k), _p(v), _p(out)
     d.q_ss, d.k_ss, d.v_ss, d.o_ss = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+    d.causal_offset = causal_offset
     if window is None:
         tq, tk = Sq, Sk
     else:
         ws, F, H, W = window
-        tq = tk = F * H * W
-        d.window_ws, d.F, d.H, d.W = ws, F, H, W
+        Fq = F if Fq is None else Fq
+        tq, tk = Fq * H * W, F * H * W
+        d.window_ws, d.F, d.H, d.W, d.Fq = ws, F, H, W, Fq
     assert q.shape[0] == batch * tq and k.shape[0] == batch * tk and v.shape[0] == batch * tk
     d.q_bs, d.o_bs = tq * q.stride(0), tq * out.stride(0)
     d.k_bs, d.v_bs = tk * k.stride(0), tk * v.stride(0)
@@ -190,13 +193,18 @@ def rotary_inplace(x: torch.Tensor, col0_q: int, col0_k: int, heads: int, head_d
 # ------------------------------------------------------------------------------------------------------------
 def groupnorm_stats(x1: torch.Tensor, x2: Optional[torch.Tensor], batch: int, groups: int,
                     stats: torch.Tensor) -> torch.Tensor:
-    """accumulate (sum, sumsq) per (b, g) into stats [batch, groups, 2] fp32 (caller zeroes it)."""
+    """(sum, sumsq) per (b, g) -> stats [batch, groups, 2] fp32 (overwritten; deterministic two-stage reduction)."""
     _req(x1, bf16, "x1")
     assert x1.is_contiguous() and (x2 is None or x2.is_contiguous())
     rows = x1.shape[0] // batch
     C2 = 0 if x2 is None else x2.shape[1]
-    check(_lib.load().seer_groupnorm_stats(_p(x1), x1.shape[1], _p(x2), C2, batch, rows, groups, _p(stats),
-                                           _stream()), "seer_groupnorm_stats")
+    lib = _lib.load()
+    nws = lib.seer_groupnorm_workspace_floats(x1.shape[1] + C2, batch, rows, groups)
+    if nws < 0:
+        check(int(nws), "seer_groupnorm_workspace_floats")
+    ws = torch.empty((nws,), device=x1.device, dtype=torch.float32)
+    check(lib.seer_groupnorm_stats(_p(x1), x1.shape[1], _p(x2), C2, batch, rows, groups, _p(stats), _p(ws),
+                                   _stream()), "seer_groupnorm_stats")
     return stats
 
 

@@ -1,0 +1,142 @@
+"""Multi-GPU sharding of ONE denoising step across the GPUs of a node (one process per GPU, torch.distributed:
+backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+The reference has no model parallelism (DDP only).  The north-star partition shards the batch x frame
+axis of the per-step UNet:
+
+  * batch groups first: the CFG-doubled batch B = 2b splits with ZERO per-layer communication (uc half / c half);
+  * frame shards inside a batch group: each rank keeps F/P frames of every activation.  Per-frame work (convs, spatial
+    and text attention, LayerNorm, FF) stays local.  Two exchanges are REQUIRED for parity (SURVEY finding 3, 8(e)):
+      - every GroupNorm spans all frames -> all-reduce of the (sum, sumsq) statistics, B_local*32*2 floats, 77 per step;
+      - temporal attention is causal over frames -> all-gather of the (rotary-applied) K|V of the frame group, 16 per step;
+        the local queries then attend with `causal_offset` = sequence position of their first frame.
+  * the epsilon prediction [B,4,F,h,w] (tiny) is all-gathered so every rank runs the same DDIM update.
+
+rank r -> (batch group g = r // P, frame shard s = r % P): a frame group is P consecutive ranks.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+MAX_WIN_SIZE, MAX_RATIO, MIN_WIN_SIZE = 8, 4, 4
+
+
+def split_counts(n: int, parts: int) -> List[int]:
+    return [n // parts + (1 if i < n % parts else 0) for i in range(parts)]
+
+
+def choose_groups(world: int, batch: int) -> Tuple[int, int]:
+    """(batch_groups G, frame_shards P) with G*P == world: the largest G that divides both world and batch."""
+    g = 1
+    for cand in range(1, min(world, batch) + 1):
+        if world % cand == 0 and batch % cand == 0:
+            g = cand
+    return g, world // g
+
+
+class FrameShard:
+    def __init__(self, world: int, rank: int, batch_groups: Optional[int] = None):
+        self.world, self.rank = world, rank
+        self.forced_G = batch_groups
+        self._pgs = {}
+        self.G = self.P = None
+        self.total_frames = self.frame_offset = self.local_frames = 0
+
+    # ---- geometry --------------------------------------------------------------------------------------------
+    def plan(self, B: int, F: int):
+        G, P = (self.forced_G, self.world // self.forced_G) if self.forced_G else choose_groups(self.world, B)
+        if G * P != self.world or B % G:
+            raise ValueError(f"cannot split batch {B} over {G} batch groups x {P} frame shards = {self.world} ranks")
+        if P > F:
+            raise ValueError(f"{P} frame shards but only {F} frames")
+        self.G, self.P = G, P
+        self.g, self.s = self.rank // P, self.rank % P
+        self.frame_counts = split_counts(F, P)
+        self.frame_starts = [sum(self.frame_counts[:i]) for i in range(P)]
+        self.total_frames = F
+        self.frame_offset = self.frame_starts[self.s]
+        self.local_frames = self.frame_counts[self.s]
+        bpg = B // G
+        self.batch_range = (self.g * bpg, (self.g + 1) * bpg)
+        self.frame_range = (self.frame_offset, self.frame_offset + self.local_frames)
+        return self.batch_range, self.frame_range
+
+    def frame_group(self):
+        """process group of the P ranks that share this rank's batch rows (every rank creates every group)."""
+        key = (self.G, self.P)
+        if key not in self._pgs:
+            groups = [dist.new_group(list(range(g * self.P, (g + 1) * self.P))) for g in range(self.G)]
+            self._pgs[key] = groups
+        return self._pgs[key][self.g]
+
+    def describe(self) -> str:
+        return f"batch_groups{self.G}xframe_shards{self.P}" if self.G else "unplanned"
+
+    # ---- hooks used by unet._Engine ----------------------------------------------------------------------------
+    def reduce_gn_stats(self, stats: torch.Tensor, count_local: float) -> float:
+        if self.P > 1:
+            dist.all_reduce(stats, group=self.frame_group())
+        return count_local / self.local_frames * self.total_frames
+
+    def local_cond_frames(self, cond_frame: int) -> int:
+        return max(0, min(self.local_frames, cond_frame - self.frame_offset))
+
+    def _gather_frames(self, x: torch.Tensor, B: int, rows_per_frame: int) -> torch.Tensor:
+        """x [B*F_local*rows_per_frame, C] of this rank -> [B*F_total*rows_per_frame, C] in global frame order"""
+        if self.P == 1:
+            return x
+        C = x.shape[1]
+        fmax = max(self.frame_counts)
+        send = x.reshape(B, self.local_frames * rows_per_frame, C)
+        if self.local_frames != fmax:
+            pad = torch.zeros((B, (fmax - self.local_frames) * rows_per_frame, C), device=x.device, dtype=x.dtype)
+            send = torch.cat([send, pad], 1)
+        send = send.contiguous()
+        recv = [torch.empty_like(send) for _ in range(self.P)]
+        dist.all_gather(recv, send, group=self.frame_group())
+        parts = [recv[i][:, : self.frame_counts[i] * rows_per_frame] for i in range(self.P)]
+        return torch.cat(parts, 1).reshape(B * self.total_frames * rows_per_frame, C)
+
+    def temporal_attention(self, ops, qkv: torch.Tensor, out: torch.Tensor, B: int, heads: int, d: int, H: int, W: int):
+        """causal (window) attention of the local frames' queries over the gathered K|V of frames [0, F_total)."""
+        C = heads * d
+        HW = H * W
+        Fl, Ft, f0 = self.local_frames, self.total_frames, self.frame_offset
+        kv = self._gather_frames(qkv[:, C:].contiguous(), B, HW)             # [B*Ft*HW, 2C]
+        if H > MIN_WIN_SIZE:
+            ws = MAX_WIN_SIZE if (H // MAX_WIN_SIZE) >= MAX_RATIO else MIN_WIN_SIZE
+            ops.attention(qkv[:, :C], kv[:, :C], kv[:, C:], out, batch=B, heads=heads, head_dim=d, Sq=Fl * ws * ws,
+                          Sk=Ft * ws * ws, causal=True, window=(ws, Ft, H, W), Fq=Fl, causal_offset=f0 * ws * ws)
+        else:
+            ops.attention(qkv[:, :C], kv[:, :C], kv[:, C:], out, batch=B, heads=heads, head_dim=d, Sq=Fl * HW,
+                          Sk=Ft * HW, causal=True, causal_offset=f0 * HW)
+
+    # ---- whole-step plumbing --------------------------------------------------------------------------------------
+    def gather_output(self, local: torch.Tensor, B: int, F: int) -> torch.Tensor:
+        """local eps [B_l, C, F_l, h, w] -> full [B, C, F, h, w] on every rank"""
+        if self.world == 1:
+            return local
+        Bl, Cc, _, h, w = local.shape
+        fmax = max(self.frame_counts)
+        send = torch.zeros((Bl, Cc, fmax, h, w), device=local.device, dtype=local.dtype)
+        send[:, :, : self.local_frames] = local
+        recv = [torch.empty_like(send) for _ in range(self.world)]
+        dist.all_gather(recv, send)
+        full = torch.empty((B, Cc, F, h, w), device=local.device, dtype=local.dtype)
+        bpg = B // self.G
+        for r in range(self.world):
+            g, s = r // self.P, r % self.P
+            f0, n = self.frame_starts[s], self.frame_counts[s]
+            full[g * bpg:(g + 1) * bpg, :, f0:f0 + n] = recv[r][:, :, :n]
+        return full
+
+
+def attach(model, world: int, rank: int, batch_groups: Optional[int] = None) -> FrameShard:
+    """make `model.forward` run sharded: every rank passes the FULL (sample, timestep, context) and gets the FULL output."""
+    shard = FrameShard(world, rank, batch_groups)
+    model._shard = shard
+    model._engine = None
+    return shard

@@ -16,12 +16,12 @@ class TimedOps:
         self._base = base
         self.records = defaultdict(list)      # class -> [(start_evt, end_evt, flops, bytes)]
 
-    def _timed(self, cls, flops, nbytes, fn, *a, **k):
+    def _timed(self, cls, flops, nbytes, fn, *a, _tag=None, **k):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         out = fn(*a, **k)
         e.record()
-        self.records[cls].append((s, e, flops, nbytes))
+        self.records[cls].append((s, e, flops, nbytes, _tag))
         return out
 
     # --- MFMA GEMM family (one kernel template: seer_gemm_kernel) ---------------------------------------------
@@ -29,7 +29,8 @@ class TimedOps:
         M, N, K = a.shape[0], w.shape[0], w.shape[1]
         n_out = N // 2 if k.get("geglu") else N
         nbytes = 2 * (M * K + N * K + M * n_out) + (2 * M * n_out if k.get("residual") is not None else 0)
-        return self._timed("gemm", 2.0 * M * N * K, nbytes, self._base.gemm, a, w, **k)
+        tag = f"gemm M{M} N{N} K{K}" + (" geglu" if k.get("geglu") else "") + (" +res" if k.get("residual") is not None else "")
+        return self._timed("gemm", 2.0 * M * N * K, nbytes, self._base.gemm, a, w, _tag=tag, **k)
 
     def gemm_batched(self, a, w, **k):
         Bt, M, K = a.shape
@@ -42,7 +43,8 @@ class TimedOps:
         Ho, Wo = (Hs - 1) // stride + 1, (Ws - 1) // stride + 1
         M, Co, K = n_img * Ho * Wo, w.shape[0], w.shape[1]
         nbytes = 2 * (x.numel() + w.numel() + M * Co)
-        return self._timed("gemm", 2.0 * M * Co * K, nbytes, self._base.conv3x3, x, w, n_img, Hin, Win, **k)
+        tag = f"conv n{n_img} {Hin}x{Win} {x.shape[1]}->{Co} s{stride} up{int(bool(up))}"
+        return self._timed("gemm", 2.0 * M * Co * K, nbytes, self._base.conv3x3, x, w, n_img, Hin, Win, _tag=tag, **k)
 
     def attention(self, q, k_, v, out, **k):
         nb = k["batch"]
@@ -51,7 +53,8 @@ class TimedOps:
             nb *= (H // ws) * (W // ws)
         flops = 4.0 * nb * k["heads"] * k["Sq"] * k["Sk"] * k["head_dim"]
         nbytes = 2 * k["heads"] * k["head_dim"] * nb * (2 * k["Sq"] + 2 * k["Sk"])
-        return self._timed("attention", flops, nbytes, self._base.attention, q, k_, v, out, **k)
+        tag = f"attn b{nb} Sq{k['Sq']} Sk{k['Sk']} d{k['head_dim']} causal{int(bool(k.get('causal')))}"
+        return self._timed("attention", flops, nbytes, self._base.attention, q, k_, v, out, _tag=tag, **k)
 
     def _bw(self, name, passes_bytes):
         def f(*a, **k):
@@ -76,13 +79,26 @@ class TimedOps:
         """class -> dict(launches, ms, flops, bytes, tflops, gbps); call after torch.cuda.synchronize()."""
         out = {}
         for cls, recs in self.records.items():
-            ms = sum(s.elapsed_time(e) for s, e, _, _ in recs)
+            ms = sum(r[0].elapsed_time(r[1]) for r in recs)
             fl = sum(r[2] for r in recs)
             by = sum(r[3] for r in recs)
             out[cls] = dict(launches=len(recs), ms=ms, flops=fl, bytes=by,
                             tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
                             gbps=by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0)
         return out
+
+    def shape_summary(self):
+        """per-shape totals: [(tag, calls, total_ms, tflops)] sorted by time (call after synchronize)."""
+        agg = {}
+        for cls, recs in self.records.items():
+            for r in recs:
+                tag = r[4] or cls
+                a = agg.setdefault(tag, [0, 0.0, 0.0])
+                a[0] += 1
+                a[1] += r[0].elapsed_time(r[1])
+                a[2] += r[2]
+        rows = [(t, n, ms, (fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)) for t, (n, ms, fl) in agg.items()]
+        return sorted(rows, key=lambda x: -x[2])
 
     def reset(self):
         self.records.clear()

@@ -83,6 +83,9 @@ class SeerUNet(nn.Module):
         self._engine: Optional[_Engine] = None
         self._slice_size = None
         self.use_graph = False
+        self._shard = None              # parallel.FrameShard when attached (seervideoldm_amd/parallel.py)
+        self._ops_backend = hip_ops     # tests may inject tests/torch_ops_backend.py to exercise the host logic on CPU
+        self._ctx_slice = None
 
     # ---- construction / weights -------------------------------------------------------------------------------
     @classmethod
@@ -120,7 +123,7 @@ class SeerUNet(nn.Module):
 
     def prepare(self):
         """(re)build the packed device weights from the current parameters; call after editing parameters in place."""
-        self._engine = _Engine(self)
+        self._engine = _Engine(self, ops=self._ops_backend, shard=self._shard)
         return self
 
     # ---- toggles of the reference surface (SURVEY 8(b)) ---------------------------------------------------------
@@ -148,7 +151,7 @@ class SeerUNet(nn.Module):
                 cond_frame: int = 0, return_attn: bool = False) -> torch.Tensor:
         if return_attn:
             raise NotImplementedError("return_attn materialises attention maps; not on the inference hot path")
-        if not sample.is_cuda:
+        if not sample.is_cuda and self._ops_backend is hip_ops:
             raise hip_ops._lib.SeerHipError("SeerUNet.forward needs ROCm tensors: the HIP kernels are the only compute path")
         if self._engine is None or self._engine.device != sample.device:
             self.prepare()
@@ -160,8 +163,21 @@ class SeerUNet(nn.Module):
         elif t.dim() == 0:
             t = t[None].to(sample.device)
         t = t.to(torch.long).broadcast_to((sample.shape[0],)).contiguous()
-        out = self._engine.run(sample.float().contiguous(), t, context, int(cond_frame), use_graph=self.use_graph)
-        return out.to(sample.dtype)
+        if self._shard is None:
+            out = self._engine.run(sample.float().contiguous(), t, context, int(cond_frame), use_graph=self.use_graph)
+            return out.to(sample.dtype)
+        # sharded step: every rank holds the full inputs, computes its (batch rows, frames) block, all ranks get the full eps
+        sh = self._shard
+        B, _, Fr = sample.shape[:3]
+        if context.dim() == 3:
+            context = context[:, None].expand(-1, Fr, -1, -1)
+        (b0, b1), (f0, f1) = sh.plan(B, Fr)
+        key = (context.data_ptr(), context._version, tuple(context.shape), b0, b1, f0, f1)
+        if self._ctx_slice is None or self._ctx_slice[0] != key:
+            self._ctx_slice = (key, context[b0:b1, f0:f1].contiguous())
+        local = self._engine.run(sample[b0:b1, :, f0:f1].float().contiguous(), t[b0:b1].contiguous(),
+                                 self._ctx_slice[1], int(cond_frame), use_graph=False)
+        return sh.gather_output(local, B, Fr).to(sample.dtype)
 
 
 # =====================================================================================================================
@@ -369,7 +385,7 @@ class _Engine:
         B, Cin, Fr, H, W = sample.shape
         boc, lpb, n = self.boc, self.lpb, len(self.boc)
         self._ctx, self._ctx_len = ctx_bf16, ctx_len
-        self._stats_arena = torch.zeros((self.n_groupnorms(), B, self.G, 2), device=sample.device, dtype=torch.float32)
+        self._stats_arena = torch.empty((self.n_groupnorms(), B, self.G, 2), device=sample.device, dtype=torch.float32)
         self._stats_i = 0
         emb = ops.timestep_embedding(t, boc[0], self.cfg.flip_sin_to_cos, self.cfg.freq_shift)
         emb = ops.linear_smallm(emb, w["time_embedding.linear_1.weight"], w["time_embedding.linear_1.bias"], silu_out=True)

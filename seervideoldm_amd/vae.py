@@ -143,7 +143,7 @@ class AutoencoderKL(nn.Module):
     def _gn(self, x, N, rows, name, silu):
         ops = hip_ops
         G = self.config.norm_num_groups
-        stats = torch.zeros((N, G, 2), device=x.device, dtype=torch.float32)
+        stats = torch.empty((N, G, 2), device=x.device, dtype=torch.float32)
         ops.groupnorm_stats(x, None, N, G, stats)
         return ops.groupnorm_apply(x, None, N, G, stats, rows * (x.shape[1] // G), 1e-6, self._w[name + ".weight"],
                                    self._w[name + ".bias"], silu)

@@ -1,0 +1,101 @@
+"""C-ABI checks that need no GPU: libseer_hip.so builds for gfx950, loads, and exports every symbol that
+include/seer_hip.h declares; the ctypes binding covers exactly that set; the product has no CPU fallback."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+HEADER = ROOT / "include" / "seer_hip.h"
+
+
+def _declared():
+    text = re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
+    return sorted(set(re.findall(r"\b(seer_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    from seervideoldm_amd.build import build_library
+    return build_library()
+
+
+def test_library_exports_every_declared_symbol(lib_path):
+    names = _declared()
+    assert len(names) >= 20
+    lib = ctypes.CDLL(str(lib_path))
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in seer_hip.h but not exported"
+
+
+def test_binding_matches_header(lib_path):
+    from seervideoldm_amd import _lib
+    assert sorted(_lib.SIGNATURES) == _declared()
+    lib = _lib.load()
+    assert lib.seer_abi_version() == _lib.ABI_VERSION
+    assert lib.seer_build_arch() == b"gfx950"
+    assert b"invalid" in lib.seer_strerror(-22)
+
+
+def test_desc_struct_layout_matches_header():
+    """field order of the ctypes structs == field order of the C structs (parsed from the header)."""
+    from seervideoldm_amd import _lib
+    text = HEADER.read_text()
+    for cname, cls in (("seer_gemm_desc", _lib.GemmDesc), ("seer_attn_desc", _lib.AttnDesc)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), text, flags=re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        fields = []
+        for stmt in body.split(";"):
+            stmt = stmt.strip()
+            if not stmt:
+                continue
+            names = stmt.split(None, 1)[1] if not stmt.startswith("const") else stmt.split(None, 2)[2]
+            for nm in names.split(","):
+                fields.append(nm.strip().lstrip("*").strip())
+        assert fields == [f[0] for f in cls._fields_], cname
+
+
+def test_argument_validation_without_gpu(lib_path):
+    """entry points reject bad descriptors before touching the device (no compute calls here)."""
+    from seervideoldm_amd import _lib
+    lib = _lib.load()
+    assert lib.seer_gemm_bf16(None, None) == -22
+    d = _lib.GemmDesc()
+    d.M, d.N, d.K = 128, 128, 100          # K not a multiple of 64
+    d.A = d.W = d.C = 1
+    assert lib.seer_gemm_bf16(ctypes.byref(d), None) == -22
+    a = _lib.AttnDesc()
+    a.Q = a.K = a.V = a.O = 1
+    a.batch, a.heads, a.head_dim, a.Sq, a.Sk = 1, 8, 64, 16, 16     # head_dim 64 is not built
+    assert lib.seer_attn_fwd(ctypes.byref(a), None) == -38
+
+
+def test_no_cpu_fallback():
+    from seervideoldm_amd import SeerUNet, _lib, ops
+    with pytest.raises(_lib.SeerHipError):
+        ops.layernorm(torch.zeros(4, 8, dtype=torch.bfloat16), torch.ones(8), torch.zeros(8))
+    m = SeerUNet(block_out_channels=(32, 64, 64, 64), cross_attention_dim=64)
+    with pytest.raises(_lib.SeerHipError):
+        m(torch.zeros(1, 4, 2, 16, 16), 3, torch.zeros(1, 2, 77, 64))
+
+
+def test_product_never_imports_oracle():
+    for p in (ROOT / "seervideoldm_amd").rglob("*.py"):
+        src = p.read_text()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{p} imports the oracle"
+    assert not re.search(r"/root/reference", (ROOT / "bench.py").read_text())
+
+
+def test_state_dict_surface_matches_reference_inventory():
+    """SURVEY section 4 pins: 1006 keys / 1082.77 M params for the SD-v1-5-shaped SeerUNet, 223.25 M temporal."""
+    from seervideoldm_amd import synth
+    sh = synth.unet_param_shapes({})
+    assert len(sh) == 1006
+    n = lambda keys: sum(int(torch.Size(sh[k]).numel()) for k in keys if not k.endswith("freqs"))
+    assert abs(n(sh) / 1e6 - 1082.77) < 0.01
+    assert abs(n([k for k in sh if "temporal_attentions" in k]) / 1e6 - 223.25) < 0.01
+    assert sum(k.startswith("down_blocks") for k in sh) == 366 and sum(k.startswith("mid_block") for k in sh) == 66
+    assert sum(k.startswith("up_blocks") for k in sh) == 564
+    assert sh["down_blocks.0.temporal_attentions.0.transformer_blocks.0.attn1.rotary_emb.freqs"] == (16,)

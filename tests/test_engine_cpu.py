@@ -1,0 +1,51 @@
+"""Host-logic tests (CPU): the product's kernel schedule (`seervideoldm_amd.unet._Engine`: weight packing, fused q|k|v,
+interleaved GEGLU, skip/concat wiring, window + rotary parameters, cond_frame handling) driven through a plain-torch
+stand-in for the kernel library (tests/torch_ops_backend.py, same signatures and bf16 storage rounding) must reproduce
+the oracle.  This is NOT a product path -- on a GPU box the same schedule runs on libseer_hip.so (tests/test_gpu_unet.py).
+"""
+import pytest
+import torch
+
+from oracle import seer_oracle as O
+from seervideoldm_amd import SeerUNet, synth
+from seervideoldm_amd.unet import _Engine
+from tests import torch_ops_backend as tob
+
+CFG_MINI = dict(block_out_channels=(320, 320, 320, 320), layers_per_block=1, cross_attention_dim=256, attention_head_dim=8)
+
+
+def _randn(shape, seed):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+
+
+@pytest.fixture(scope="module")
+def mini():
+    sd = synth.synth_state_dict(synth.unet_param_shapes(CFG_MINI))
+    m = SeerUNet(**CFG_MINI)
+    m.load_state_dict(sd, strict=True)
+    return sd, m
+
+
+@pytest.mark.parametrize("B,Fr,H,cond_frame", [(1, 2, 16, 0), (2, 3, 8, 1)])
+def test_engine_schedule_matches_oracle(mini, B, Fr, H, cond_frame):
+    sd, m = mini
+    eng = _Engine(m, ops=tob)
+    x = _randn((B, 4, Fr, H, H), 1)
+    ctx = _randn((B, Fr, 77, 256), 2)
+    t = torch.tensor([501] * B)
+    with torch.no_grad():
+        got = eng.run(x, t, ctx, cond_frame)
+        ref = O.unet_forward(sd, CFG_MINI, x, t, ctx, cond_frame=cond_frame)
+    rel = ((got - ref).norm() / ref.norm()).item()
+    assert rel < 3e-2, rel
+
+
+def test_engine_counts_groupnorms(mini):
+    _, m = mini
+    eng = _Engine(m, ops=tob)
+    # lpb=1: down 4 resnets*2 + 3 levels * 2 transformers; mid 2*2 + 2; up 8 resnets*2 + 3 levels*2 blocks*2; + out
+    assert eng.n_groupnorms() == 8 + 6 + 6 + 16 + 12 + 1
+    full = synth.unet_param_shapes({})
+    n = sum(1 for k in full if k.endswith(".weight") and (k.endswith("norm1.weight") or k.endswith("norm2.weight")
+            or k.endswith(".norm.weight") or k == "conv_norm_out.weight") and "transformer_blocks" not in k)
+    assert n == 77          # SURVEY finding 3: 77 cross-frame GroupNorms per forward

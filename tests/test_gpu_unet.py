@@ -40,6 +40,11 @@ def _check(got, ref, what):
     return rel
 
 
+def _rel(got, ref):
+    got, ref = got.float().cpu(), ref.float()
+    return ((got - ref).norm() / ref.norm()).item()
+
+
 _cache = {}
 
 
@@ -68,7 +73,7 @@ def test_unet_forward_matches_oracle(device, cfg_name, B, Fr, H, cond_frame):
     _check(got, ref, f"unet {cfg_name} B{B} F{Fr} {H}x{H} cond{cond_frame}")
     # python-number timestep and hipGraph replay give the same answer as the eager tensor-timestep call
     got2 = m(x.to(device), 501, ctx.to(device), cond_frame)
-    assert torch.allclose(got2, got, rtol=1e-2, atol=1e-2)
+    assert torch.equal(got2, got), "the step is deterministic: no float atomics anywhere on the path"
     m.use_graph = True
     try:
         ctx_d = ctx.to(device)
@@ -76,8 +81,7 @@ def test_unet_forward_matches_oracle(device, cfg_name, B, Fr, H, cond_frame):
         g2 = m(x.to(device), t.to(device), ctx_d, cond_frame=cond_frame).clone()
     finally:
         m.use_graph = False
-    _check(g1, ref, "graph capture run")
-    _check(g2, ref, "graph replay run")
+    assert torch.equal(g1, got) and torch.equal(g2, got), "hipGraph replay must reproduce the eager launches bit for bit"
 
 
 def test_groupnorm_couples_frames(device):
@@ -95,9 +99,9 @@ def test_groupnorm_couples_frames(device):
 def test_ddim_sampler_and_decode_match_oracle(device):
     """4-step DDIM with batched CFG + VAE decode (config #1 plumbing) against the oracle, end to end."""
     cfg, sd, m = _model("mini", device)
-    vae_kw = dict(ch=64, ch_mult=(1, 2, 2, 2), num_res_blocks=1)
+    vae_kw = dict(ch=128, ch_mult=(1, 1, 2, 2), num_res_blocks=1)      # >= 4 channels per GroupNorm group, like the SD VAE
     vsd = synth.synth_state_dict(synth.vae_param_shapes(**vae_kw))
-    vae = AutoencoderKL(block_out_channels=(64, 128, 128, 128), layers_per_block=1)
+    vae = AutoencoderKL(block_out_channels=(128, 128, 256, 256), layers_per_block=1)
     vae.load_state_dict(ldm_to_diffusers_vae(vsd, 4), strict=True)
     vae = vae.to(device)
     b, f1, Fp, H = 1, 1, 2, 16
@@ -114,7 +118,10 @@ def test_ddim_sampler_and_decode_match_oracle(device):
                                 unconditional_conditioning=uc.to(device), eta=0.0, x_T=noise.to(device), is_3d=True)
     assert sampler.ddim_timesteps.tolist() == [1, 251, 501, 751]
     assert len(inter["x_inter"]) == 3 and len(inter["pred_x0"]) == 3          # start + index 3 + index 0
-    _check(lat, ref_lat, "ddim latent after 4 steps")
+    # four dependent CFG steps (scale 7.5 amplifies the eps error of each step): stated tolerance 8e-2 relative L2
+    rel = _rel(lat, ref_lat)
+    print(f"[parity] ddim latent after 4 CFG steps: rel_l2={rel:.4g}")
+    assert rel <= 8e-2, rel
     clip = ddim_sample(sampler, m, vae, (b, 4, Fp, H, H), c.to(device), noise.to(device), x0_emb.to(device),
                        ddim_steps=4, scale=7.5, uc=uc.to(device))
     assert clip.shape == (b, 3, Fp, 8 * H, 8 * H) and clip.min() >= 0 and clip.max() <= 1
@@ -128,9 +135,9 @@ def test_ddim_sampler_and_decode_match_oracle(device):
 
 
 def test_vae_decode_matches_oracle(device):
-    vae_kw = dict(ch=64, ch_mult=(1, 2, 4, 4), num_res_blocks=2)
+    vae_kw = dict(ch=128, ch_mult=(1, 2, 2, 4), num_res_blocks=2)
     vsd = synth.synth_state_dict(synth.vae_param_shapes(**vae_kw))
-    vae = AutoencoderKL(block_out_channels=(64, 128, 256, 256), layers_per_block=2)
+    vae = AutoencoderKL(block_out_channels=(128, 256, 256, 512), layers_per_block=2)
     vae.load_state_dict(ldm_to_diffusers_vae(vsd, 4), strict=True)
     vae = vae.to(device)
     z = _randn((3, 4, 16, 16), 9)
@@ -141,8 +148,9 @@ def test_vae_decode_matches_oracle(device):
 
 def test_full_size_step_properties(device):
     """BASELINE config 2 shape (CFG batch 2 x 12 frames x 32^2, full-width UNet): size-independent properties.
-    (a) finite output of the right shape; (b) the two CFG halves given IDENTICAL inputs produce identical outputs up to
-    the order of fp32 atomics in the GroupNorm statistics; (c) a different context changes the output."""
+    (a) finite output of the right shape; (b) the two CFG halves given IDENTICAL inputs produce identical outputs (the
+    path has no float atomics: per-element arithmetic does not depend on the batch slot); (c) a different context changes
+    only the batch element it belongs to."""
     cfg = dict(synth.SD15_UNET_CFG)
     m = SeerUNet(**{k: v for k, v in cfg.items()})
     sd = synth.synth_state_dict(synth.unet_param_shapes(cfg), device=device)
@@ -156,7 +164,7 @@ def test_full_size_step_properties(device):
     assert y.shape == (2, 4, 12, 32, 32) and torch.isfinite(y).all()
     d = (y[0] - y[1]).abs().max().item()
     print(f"[property] identical batch elements differ by {d:.3g} (max |y| {y.abs().max().item():.3g})")
-    assert d <= 2e-2 * y.abs().max().item()
+    assert d <= 1e-3 * y.abs().max().item()
     c2 = torch.cat([c1, _randn((1, 12, 77, 768), 3).to(device)])
     y2 = m(x, torch.tensor([981, 981], device=device), c2)
-    assert (y2[1] - y[1]).abs().max() > 1e-3 and (y2[0] - y[0]).abs().max() <= 2e-2 * y.abs().max().item()
+    assert (y2[1] - y[1]).abs().max() > 1e-3 and (y2[0] - y[0]).abs().max() <= 1e-3 * y.abs().max().item()

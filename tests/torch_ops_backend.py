@@ -1,0 +1,203 @@
+"""TEST INFRASTRUCTURE ONLY -- a plain-torch (CPU) stand-in for `seervideoldm_amd.ops` with the SAME call signatures
+and the same storage rounding (bf16 tensors in/out, fp32 math inside).
+
+It lets the CPU test-suite exercise the HOST logic of the product (weight packing, kernel schedule of `_Engine`, skip /
+concat wiring, window and rotary parameters, frame sharding and its collectives over gloo) against the oracle without a
+GPU.  It is never imported by the product package; the product's only backend is libseer_hip.so.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+bf16 = torch.bfloat16
+
+
+def _deinterleave_geglu(acc):
+    M, N = acc.shape
+    a = acc.reshape(M, N // 32, 2, 16)
+    return a[:, :, 0].reshape(M, N // 2), a[:, :, 1].reshape(M, N // 2)
+
+
+def _epilogue(acc, bias, geglu, rowvec, rows_per_batch, silu, residual, out_f32, out):
+    if bias is not None:
+        acc = acc + bias
+    if geglu:
+        val, gate = _deinterleave_geglu(acc)
+        acc = val * F.gelu(gate)
+    if rowvec is not None:
+        acc = acc + rowvec.repeat_interleave(rows_per_batch, 0)[: acc.shape[0]]
+    if silu:
+        acc = F.silu(acc)
+    if residual is not None:
+        acc = acc + residual.float()
+    res = acc if (out_f32 or (out is not None and out.dtype == torch.float32)) else acc.to(bf16)
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
+
+
+def gemm(a, w, *, bias=None, residual=None, rowvec=None, rows_per_batch=0, a2=None, geglu=False, silu=False,
+         out_f32=False, out=None, tile=0):
+    A = a.float() if a2 is None else torch.cat([a.float(), a2.float()], 1)
+    assert A.shape[1] % 64 == 0 and w.dtype == bf16 and a.dtype == bf16
+    return _epilogue(A @ w.float().t(), bias, geglu, rowvec, rows_per_batch, silu, residual, out_f32, out)
+
+
+def gemm_batched(a, w, *, trans_out=False, out=None, bias=None, out_f32=False, tile=0):
+    acc = torch.einsum("bmk,bnk->bmn" if w.dim() == 3 else "bmk,nk->bmn", a.float(), w.float())
+    if bias is not None:
+        acc = acc + bias
+    if trans_out:
+        acc = acc.transpose(1, 2).contiguous()
+    return acc if out_f32 else acc.to(bf16)
+
+
+def conv3x3(x, w, n_img, Hin, Win, *, stride=1, upsample=False, bias=None, residual=None, rowvec=None,
+            rows_per_batch=0, out=None, tile=0):
+    Ci, Co = x.shape[1], w.shape[0]
+    assert Ci % 64 == 0 and w.shape[1] == 9 * Ci
+    xi = x.float().reshape(n_img, Hin, Win, Ci).permute(0, 3, 1, 2)
+    if upsample:
+        xi = F.interpolate(xi, scale_factor=2.0, mode="nearest")
+    wt = w.float().reshape(Co, 3, 3, Ci).permute(0, 3, 1, 2)
+    y = F.conv2d(xi, wt, None, stride=stride, padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
+    return _epilogue(y, bias, False, rowvec, rows_per_batch, False, residual, False, out)
+
+
+def _tok_index(batch, ws, Fr, H, W):
+    """token index [nW, Fr*ws*ws] of every window position, order (f, wy, wx); windows ordered (wy_blk, wx_blk)"""
+    f = torch.arange(Fr)[:, None, None]
+    wy = torch.arange(ws)[None, :, None]
+    wx = torch.arange(ws)[None, None, :]
+    idx = []
+    for by in range(H // ws):
+        for bx in range(W // ws):
+            idx.append((f * H * W + (by * ws + wy) * W + bx * ws + wx).reshape(-1))
+    return torch.stack(idx)
+
+
+def attention(q, k, v, out, *, batch, heads, head_dim, Sq, Sk, causal=False, scale=None, window=None, Fq=None,
+              causal_offset=0):
+    assert head_dim in (40, 80, 160), "the flash kernels are built for head_dim 40/80/160"
+    C = heads * head_dim
+    scale = head_dim ** -0.5 if scale is None else scale
+    if window is None:
+        qq = q[:, :C].float().reshape(batch, Sq, heads, head_dim).permute(0, 2, 1, 3)
+        kk = k[:, :C].float().reshape(batch, Sk, heads, head_dim).permute(0, 2, 1, 3)
+        vv = v[:, :C].float().reshape(batch, Sk, heads, head_dim).permute(0, 2, 1, 3)
+    else:
+        ws, Fr, H, W = window
+        Fq = Fr if Fq is None else Fq
+        assert Sq == Fq * ws * ws and Sk == Fr * ws * ws
+        iq, ik = _tok_index(batch, ws, Fq, H, W), _tok_index(batch, ws, Fr, H, W)      # [nW, S]
+        gat = lambda t, idx, Ft: t[:, :C].float().reshape(batch, Ft * H * W, heads, head_dim)[:, idx]  # [B,nW,S,h,d]
+        qq = gat(q, iq, Fq).permute(1, 0, 3, 2, 4).reshape(-1, heads, Sq, head_dim)
+        kk = gat(k, ik, Fr).permute(1, 0, 3, 2, 4).reshape(-1, heads, Sk, head_dim)
+        vv = gat(v, ik, Fr).permute(1, 0, 3, 2, 4).reshape(-1, heads, Sk, head_dim)
+    s = torch.einsum("bhqd,bhkd->bhqk", qq, kk) * scale
+    if causal:
+        i = torch.arange(Sq)[:, None] + causal_offset
+        j = torch.arange(Sk)[None, :]
+        s = s.masked_fill(~(j <= i), float("-inf"))
+    o = torch.einsum("bhqk,bhkd->bhqd", s.softmax(-1), vv)              # [nb, heads, Sq, d]
+    if window is None:
+        res = o.permute(0, 2, 1, 3).reshape(batch * Sq, C)
+    else:
+        nW = iq.shape[0]
+        o = o.reshape(nW, batch, heads, Sq, head_dim).permute(1, 0, 3, 2, 4)           # [B, nW, S, h, d]
+        res = torch.zeros(batch, Fq * H * W, C)
+        res[:, iq.reshape(-1)] = o.reshape(batch, nW * Sq, C)
+        res = res.reshape(-1, C)
+    out[:, :C].copy_(res.to(bf16))
+    return out
+
+
+def rotary_table(freqs, T):
+    ang = torch.arange(T, dtype=torch.float32)[:, None] * freqs[None, :]
+    return torch.stack([ang.cos(), ang.sin()], -1)
+
+
+def rotary_inplace(x, col0_q, col0_k, heads, head_dim, rot_dim, tokens_per_batch, cos_sin, pos_offset=0):
+    rows = x.shape[0]
+    pos = (torch.arange(rows) % tokens_per_batch) + pos_offset
+    c, s = cos_sin[pos, :, 0], cos_sin[pos, :, 1]                     # [rows, half]
+    for col0 in (col0_q, col0_k):
+        t = x[:, col0:col0 + heads * head_dim].float().reshape(rows, heads, head_dim)
+        tr = t[..., :rot_dim]
+        a, b = tr[..., 0::2], tr[..., 1::2]
+        ra = a * c[:, None] - b * s[:, None]
+        rb = b * c[:, None] + a * s[:, None]
+        t = torch.cat([torch.stack([ra, rb], -1).flatten(-2), t[..., rot_dim:]], -1)
+        x[:, col0:col0 + heads * head_dim] = t.reshape(rows, -1).to(bf16)
+
+
+def groupnorm_stats(x1, x2, batch, groups, stats):
+    xc = x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], 1)
+    C = xc.shape[1]
+    xg = xc.reshape(batch, -1, groups, C // groups)
+    stats[..., 0] = xg.sum(dim=(1, 3))
+    stats[..., 1] = (xg * xg).sum(dim=(1, 3))
+    return stats
+
+
+def groupnorm_apply(x1, x2, batch, groups, stats, count, eps, gamma, beta, silu, out=None):
+    xc = x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], 1)
+    C = xc.shape[1]
+    mean = stats[..., 0] / count
+    var = (stats[..., 1] / count - mean * mean).clamp_min(0)
+    rstd = torch.rsqrt(var + eps)
+    xg = xc.reshape(batch, -1, groups, C // groups)
+    y = ((xg - mean[:, None, :, None]) * rstd[:, None, :, None]).reshape(-1, C) * gamma + beta
+    if silu:
+        y = F.silu(y)
+    return y.to(bf16)
+
+
+def layernorm(x, gamma, beta, eps=1e-5, out=None):
+    y = F.layer_norm(x.float(), (x.shape[1],), gamma, beta, eps).to(bf16)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def softmax_rows(x, scale, out=None):
+    return (x.float() * scale).softmax(-1).to(bf16)
+
+
+def timestep_embedding(t, dim, flip_sin_to_cos, freq_shift):
+    half = dim // 2
+    exponent = -math.log(10000) * torch.arange(0, half, dtype=torch.float32) / (half - freq_shift)
+    arg = t[:, None].float() * torch.exp(exponent)[None]
+    return torch.cat([arg.cos(), arg.sin()], -1) if flip_sin_to_cos else torch.cat([arg.sin(), arg.cos()], -1)
+
+
+def linear_smallm(x, w, bias, *, silu_in=False, silu_out=False):
+    xi = F.silu(x) if silu_in else x
+    y = xi @ w.float().t()
+    if bias is not None:
+        y = y + bias
+    return F.silu(y) if silu_out else y
+
+
+def conv_in(x, w_khwc, bias):
+    B, Cin, Fr, H, W = x.shape
+    wt = w_khwc.permute(3, 2, 0, 1)
+    y = F.conv2d(x.permute(0, 2, 1, 3, 4).reshape(B * Fr, Cin, H, W), wt, bias, padding=1)
+    return y.permute(0, 2, 3, 1).reshape(-1, y.shape[1]).to(bf16)
+
+
+def conv_out(x, w_ohwc, bias, B, Fr, H, W):
+    C0 = x.shape[1]
+    xi = x.float().reshape(B * Fr, H, W, C0).permute(0, 3, 1, 2)
+    y = F.conv2d(xi, w_ohwc.permute(0, 3, 1, 2), bias, padding=1)
+    return y.reshape(B, Fr, -1, H, W).permute(0, 2, 1, 3, 4).contiguous()
+
+
+def cast_bf16(x):
+    return x.to(bf16)
