@@ -73,6 +73,12 @@ typedef struct seer_gemm_desc {
     int64_t strideA, strideW, strideC;
     /* tile selection: 0 = auto, else SEER_TILE_* */
     int32_t tile;
+    /* split-K (small M, long K: the 4x4 / 8x8 level convs): 0 = auto, 1 = off, n = n slices of the K loop.  Slices write
+     * fp32 partial tiles to `workspace` ([splits][M][N] floats) and a second kernel adds them IN SLICE ORDER (deterministic,
+     * no atomics) and applies the epilogue.  Ignored (no split) when workspace is NULL or too small. */
+    int32_t splits;
+    void* workspace;
+    int64_t workspace_bytes;
 } seer_gemm_desc;
 
 #define SEER_TILE_AUTO 0
@@ -81,6 +87,8 @@ typedef struct seer_gemm_desc {
 #define SEER_TILE_128x64 3
 
 int seer_gemm_bf16(const seer_gemm_desc* desc /* host */, void* stream);
+/* bytes of workspace the call would use for split-K with this descriptor (0: it will not split) */
+int64_t seer_gemm_workspace_bytes(const seer_gemm_desc* desc /* host */);
 
 /* ---- attention -------------------------------------------------------------------------- */
 /* Replaces xformers.ops.memory_efficient_attention as called from CrossAttention

@@ -68,6 +68,32 @@ def bench_conv():
         print(line, flush=True)
 
 
+def bench_split():
+    """split-K sweep on the deep-level shapes (M = 384 / 1536)"""
+    gemms = [(384, 1280, 1280), (384, 1280, 5120), (384, 1280, 2560), (384, 3840, 1280), (1536, 1280, 1280),
+             (1536, 1280, 5120), (1536, 3840, 1280), (1536, 1280, 2560)]
+    for M, N, K in gemms:
+        a = torch.randn(M, K, device=dev).to(bf16)
+        w = (torch.randn(N, K, device=dev) * K ** -0.5).to(bf16)
+        bias = torch.randn(N, device=dev)
+        line = f"gemm M{M} N{N} K{K}:"
+        for s in (1, 0, 2, 4, 8, 16):
+            t = timeit(lambda: ops.gemm(a, w, bias=bias, splits=s, tile=(2 if s != 1 else 0)))
+            line += f"  s{s} {t * 1e6:6.1f}us"
+        print(line, flush=True)
+    convs = [(24, 4, 4, 1280, 1280, 1), (24, 4, 4, 2560, 1280, 1), (24, 8, 8, 1280, 1280, 2), (24, 8, 8, 1280, 1280, 1),
+             (24, 8, 8, 2560, 1280, 1), (24, 8, 8, 1920, 1280, 1)]
+    for n, H, W, Ci, Co, st in convs:
+        x = torch.randn(n * H * W, Ci, device=dev).to(bf16)
+        w = (torch.randn(Co, 9 * Ci, device=dev) * (9 * Ci) ** -0.5).to(bf16)
+        bias = torch.randn(Co, device=dev)
+        line = f"conv n{n} {H}x{W} {Ci}->{Co} s{st}:"
+        for s in (1, 0, 2, 4, 8, 16):
+            t = timeit(lambda: ops.conv3x3(x, w, n, H, W, stride=st, bias=bias, splits=s, tile=(2 if s != 1 else 0)))
+            line += f"  s{s} {t * 1e6:6.1f}us"
+        print(line, flush=True)
+
+
 def bench_attn():
     cases = [  # name, batch, S_q, S_k, d, causal, window
         ("spatial L0", 24, 1024, 1024, 40, False, None), ("spatial L1", 24, 256, 256, 80, False, None),
@@ -114,6 +140,8 @@ if __name__ == "__main__":
         bench_gemm()
     if what in ("conv", "all"):
         bench_conv()
+    if what in ("split", "all"):
+        bench_split()
     if what in ("attn", "all"):
         bench_attn()
     if what in ("norm", "all"):

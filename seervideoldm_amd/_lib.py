@@ -13,7 +13,7 @@ _PKG = Path(__file__).resolve().parent
 _LIB_PATH = _PKG / "lib" / "libseer_hip.so"
 _lib = None
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 SEER_GEMM_PLAIN = 0
 SEER_GEMM_CONV3X3 = 1
@@ -40,7 +40,7 @@ class GemmDesc(C.Structure):
         ("stride", C.c_int32), ("upsample", C.c_int32),
         ("batch", C.c_int32),
         ("strideA", C.c_int64), ("strideW", C.c_int64), ("strideC", C.c_int64),
-        ("tile", C.c_int32),
+        ("tile", C.c_int32), ("splits", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 
@@ -64,6 +64,7 @@ SIGNATURES = {
     "seer_strerror": ([C.c_int], C.c_char_p),
     "seer_build_arch": ([], C.c_char_p),
     "seer_gemm_bf16": ([C.POINTER(GemmDesc), _vp], C.c_int),
+    "seer_gemm_workspace_bytes": ([C.POINTER(GemmDesc)], C.c_int64),
     "seer_attn_fwd": ([C.POINTER(AttnDesc), _vp], C.c_int),
     "seer_rotary_table": ([_vp, _i32, _i32, _vp, _vp], C.c_int),
     "seer_rotary_inplace": ([_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp], C.c_int),

@@ -18,7 +18,7 @@ namespace {
 
 constexpr int BK = 64;
 
-template <int BM, int BN, bool CONV, bool GEGLU>
+template <int BM, int BN, bool CONV, bool GEGLU, bool SPLIT>
 __global__ void __launch_bounds__(256) seer_gemm_kernel(const seer_gemm_desc p) {
     constexpr int WTM = BM / 2, WTN = BN / 2;
     constexpr int TM = WTM / 16, TN = WTN / 16;
@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(256) seer_gemm_kernel(const seer_gemm_desc p) 
     const int tn = (wg % (GM * tiles_n)) / gsz;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    const int z = blockIdx.z;
+    const int z = SPLIT ? 0 : blockIdx.z;          // SPLIT: blockIdx.z is the K slice, not a batch index
     const bf16* __restrict__ A = reinterpret_cast<const bf16*>(p.A) + (int64_t)z * p.strideA;
     const bf16* __restrict__ A2 = reinterpret_cast<const bf16*>(p.A2);
     const bf16* __restrict__ W = reinterpret_cast<const bf16*>(p.W) + (int64_t)z * p.strideW;
@@ -143,16 +143,18 @@ __global__ void __launch_bounds__(256) seer_gemm_kernel(const seer_gemm_desc p) 
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / BK;
+    const int nk_all = p.K / BK;
+    const int kt0 = SPLIT ? (int)((int64_t)nk_all * blockIdx.z / p.splits) : 0;
+    const int nk = SPLIT ? (int)((int64_t)nk_all * (blockIdx.z + 1) / p.splits) : nk_all;
     const int frow = lane & 15;        // operand row inside a 16-row fragment
     const int fq = lane >> 4;          // 16-byte chunk inside a 32-wide k-step
 
-    load_tile(0);
+    load_tile(kt0);
     store_tile(0);
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int buf = (kt - kt0) & 1;
         if (kt + 1 < nk) load_tile(kt + 1);
         const bf16* as = As + buf * BM * BK + (wm * WTM) * BK;
         const bf16* bs = Bs + buf * BN * BK + (wn * WTN) * BK;
@@ -172,6 +174,23 @@ __global__ void __launch_bounds__(256) seer_gemm_kernel(const seer_gemm_desc p) 
         }
         if (kt + 1 < nk) store_tile(buf ^ 1);
         __syncthreads();
+    }
+
+    // ---- split-K: raw fp32 partial tile to the workspace slice of this K range; the reduce kernel does the epilogue
+    if constexpr (SPLIT) {
+        float* ws = reinterpret_cast<float*>(p.workspace) + (int64_t)blockIdx.z * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * WTM + i * 16 + frow;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WTN + j * 16 + fq * 4;
+                if (n >= p.N) continue;
+                *reinterpret_cast<f32x4*>(ws + (int64_t)m * p.N + n) = acc[i][j];
+            }
+        }
+        return;
     }
 
     // ---- epilogue: lane holds rows n = 4*fq + r (r = 0..3) of the 16x16 D tile, column m = frow
@@ -247,6 +266,52 @@ __global__ void __launch_bounds__(256) seer_gemm_kernel(const seer_gemm_desc p) 
     }
 }
 
+// split-K second pass: C = epilogue( sum over slices, in slice order )
+__global__ void __launch_bounds__(256) seer_splitk_reduce_kernel(const seer_gemm_desc p) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int n4 = p.N / 4;
+    if (idx >= (int64_t)p.M * n4) return;
+    const int m = (int)(idx / n4);
+    const int n = (int)(idx - (int64_t)m * n4) * 4;
+    const float* ws = reinterpret_cast<const float*>(p.workspace) + (int64_t)m * p.N + n;
+    f32x4 a = *reinterpret_cast<const f32x4*>(ws);
+    for (int z = 1; z < p.splits; ++z) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(ws + (int64_t)z * p.M * p.N);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] += b[r];
+    }
+    float v[4] = {a[0], a[1], a[2], a[3]};
+    if (p.bias) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bv[r];
+    }
+    if (p.rowvec) {
+        const f32x4 tv = *reinterpret_cast<const f32x4*>(p.rowvec + (int64_t)(m / p.rows_per_batch) * p.rowvec_ld + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += tv[r];
+    }
+    if (p.epilogue & SEER_EPI_SILU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+    }
+    if (p.residual) {
+        const u32x2 rv = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16*>(p.residual) + (int64_t)m * p.ldr + n);
+        v[0] += __builtin_bit_cast(float, rv[0] << 16);
+        v[1] += __builtin_bit_cast(float, rv[0] & 0xffff0000u);
+        v[2] += __builtin_bit_cast(float, rv[1] << 16);
+        v[3] += __builtin_bit_cast(float, rv[1] & 0xffff0000u);
+    }
+    if (p.epilogue & SEER_EPI_OUT_F32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
+    } else {
+        u32x2 o;
+        o[0] = pack2(v[0], v[1]);
+        o[1] = pack2(v[2], v[3]);
+        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + n) = o;
+    }
+}
+
 template <int BM, int BN>
 int launch_tile(const seer_gemm_desc& d, hipStream_t st) {
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
@@ -256,22 +321,34 @@ int launch_tile(const seer_gemm_desc& d, hipStream_t st) {
     const bool geglu = (d.epilogue & SEER_EPI_GEGLU) != 0;
     if (conv && geglu) return SEER_EINVAL;
     if (conv) {
-        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, true, false>), grid, dim3(256), lds, st, d);
+        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, true, false, false>), grid, dim3(256), lds, st, d);
     } else if (geglu) {
-        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, true>), grid, dim3(256), lds, st, d);
+        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, true, false>), grid, dim3(256), lds, st, d);
     } else {
-        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, false>), grid, dim3(256), lds, st, d);
+        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, false, false>), grid, dim3(256), lds, st, d);
     }
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }
 
-}  // namespace
+int launch_split(const seer_gemm_desc& d, hipStream_t st) {
+    constexpr int BM = 64, BN = 64;
+    const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
+    dim3 grid(tiles_m * tiles_n, 1, d.splits);
+    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16);
+    if (d.mode == SEER_GEMM_CONV3X3)
+        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, true, false, true>), grid, dim3(256), lds, st, d);
+    else
+        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, false, true>), grid, dim3(256), lds, st, d);
+    SEER_LAUNCH_CHECK();
+    const int64_t n = (int64_t)d.M * (d.N / 4);
+    hipLaunchKernelGGL(seer_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d);
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
 
-extern "C" int seer_gemm_bf16(const seer_gemm_desc* desc, void* stream) {
-    if (!desc) return SEER_EINVAL;
-    seer_gemm_desc d = *desc;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+// validate + normalise a descriptor; returns SEER_OK and the number of K slices the call will use in *splits
+int prepare(seer_gemm_desc& d, int* splits) {
     if (d.M <= 0 || d.N <= 0 || d.K <= 0) return SEER_EINVAL;
     if (d.K % BK) return SEER_EINVAL;
     if (!d.A || !d.W || !d.C) return SEER_EINVAL;
@@ -292,7 +369,54 @@ extern "C" int seer_gemm_bf16(const seer_gemm_desc* desc, void* stream) {
     if (!(d.epilogue & SEER_EPI_TRANS_OUT) && (d.ldc % 4)) return SEER_EINVAL;
     if (d.residual && (d.ldr % 4)) return SEER_EINVAL;
     if (d.rowvec && d.rows_per_batch <= 0) return SEER_EINVAL;
-    if (d.batch <= 1) { d.batch = 1; }
+    if (d.batch <= 1) d.batch = 1;
+
+    // split-K decision: few output tiles and a long K loop (deep-level convs / linears, M = 384 .. 1536)
+    int s = 1;
+    const bool can_split = d.batch == 1 && !geglu && !(d.epilogue & SEER_EPI_TRANS_OUT) &&
+                           (d.tile == SEER_TILE_AUTO || d.tile == SEER_TILE_64x64);
+    if (can_split) {
+        const int nk = d.K / BK;
+        if (d.splits > 1) {
+            s = d.splits < nk ? d.splits : nk;
+        } else if (d.splits == 0) {
+            const long blocks = (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
+            if (blocks <= 512 && nk >= 16) {
+                long want = (1024 + blocks - 1) / blocks;          // ~4 blocks per CU
+                long maxs = nk / 8;                                  // >= 8 K tiles per slice
+                s = (int)(want < maxs ? want : maxs);
+                if (s > 16) s = 16;
+                if (s < 1) s = 1;
+            }
+        }
+    }
+    *splits = s;
+    return SEER_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t seer_gemm_workspace_bytes(const seer_gemm_desc* desc) {
+    if (!desc) return SEER_EINVAL;
+    seer_gemm_desc d = *desc;
+    int s = 1;
+    const int rc = prepare(d, &s);
+    if (rc != SEER_OK) return rc;
+    return s > 1 ? (int64_t)s * d.M * d.N * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int seer_gemm_bf16(const seer_gemm_desc* desc, void* stream) {
+    if (!desc) return SEER_EINVAL;
+    seer_gemm_desc d = *desc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int s = 1;
+    const int rc = prepare(d, &s);
+    if (rc != SEER_OK) return rc;
+    if (s > 1 && d.workspace && d.workspace_bytes >= (int64_t)s * d.M * d.N * (int64_t)sizeof(float)) {
+        d.splits = s;
+        return launch_split(d, st);
+    }
+    d.splits = 1;
 
     int tile = d.tile;
     if (tile == SEER_TILE_AUTO) {

@@ -77,23 +77,28 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const bf16* __restrict__ 
 }
 
 // stats[b][g][2] = sum over blocks (fixed order: 4 contiguous slices, then the 4 slice sums in order)
-__global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ partials, int nblk, int groups,
-                                                          float* __restrict__ stats) {
-    __shared__ float part[4][128];
+__global__ void __launch_bounds__(1024) gn_finalize_kernel(const float* __restrict__ partials, int nblk, int groups,
+                                                           float* __restrict__ stats) {
+    __shared__ float part[8][128];
     const int b = blockIdx.x;
     const int n = groups * 2;                 // <= 128
-    const int s = threadIdx.x & 127, slice = threadIdx.x >> 7;    // 2 slices x 128 stats with 256 threads
+    const int s = threadIdx.x & 127, slice = threadIdx.x >> 7;    // 8 slices x 128 stats with 1024 threads
     float acc = 0.f;
     if (s < n) {
-        const int per = (nblk + 1) / 2;
+        const int per = (nblk + 7) / 8;
         const int k0 = slice * per, k1 = min(nblk, k0 + per);
         const float* p = partials + ((int64_t)b * nblk) * n + s;
 #pragma unroll 8
         for (int k = k0; k < k1; ++k) acc += p[(int64_t)k * n];
-        part[slice][s] = acc;
     }
+    part[slice][s] = acc;
     __syncthreads();
-    if (threadIdx.x < n) stats[(int64_t)b * n + threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x];
+    if (threadIdx.x < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += part[i][threadIdx.x];     // fixed order
+        stats[(int64_t)b * n + threadIdx.x] = t;
+    }
 }
 
 __global__ void __launch_bounds__(256) gn_apply_kernel(const bf16* __restrict__ x1, const bf16* __restrict__ x2,
@@ -305,7 +310,7 @@ extern "C" int seer_groupnorm_stats(const void* x1, int32_t C1, const void* x2, 
     hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), lds, st, reinterpret_cast<const bf16*>(x1),
                        reinterpret_cast<const bf16*>(x2), g, rows_per_batch, groups, workspace);
     SEER_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(256), 0, st, workspace, g.nblk, groups, stats);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(1024), 0, st, workspace, g.nblk, groups, stats);
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }

@@ -43,7 +43,20 @@ __device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // exact-erf GELU (F.gelu default, attention.py:785-793)
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32 round-off of 1+erf): 2 transcendentals + 8 VALU instead
+// of the ~30-instruction branchy libm erff -- the GEGLU epilogue evaluates it on M*N/2 elements per GEMM.
+__device__ __forceinline__ float gelu_erf_f(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+    const float erf_abs = fmaf(-p * t, e, 1.0f);                 // erf(|x|/sqrt2)
+    const float erf_v = __builtin_copysignf(erf_abs, x);
+    return 0.5f * x * (1.0f + erf_v);
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

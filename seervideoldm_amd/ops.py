@@ -38,7 +38,7 @@ def _req(t: torch.Tensor, dtype, name: str):
 # ------------------------------------------------------------------------------------------------------------
 def gemm(a: torch.Tensor, w: torch.Tensor, *, bias=None, residual=None, rowvec=None, rows_per_batch=0,
          a2: Optional[torch.Tensor] = None, geglu=False, silu=False, out_f32=False, out: Optional[torch.Tensor] = None,
-         tile=0) -> torch.Tensor:
+         tile=0, splits=0) -> torch.Tensor:
     """out[M,N] = epi(a[M,K1] | a2[M,K-K1]) @ w[N,K]^T ; a/a2 may be row-strided views (last dim contiguous)."""
     _req(a, bf16, "a"); _req(w, bf16, "w")
     assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.is_contiguous()
@@ -74,8 +74,21 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias=None, residual=None, rowvec=N
                  (_lib.SEER_EPI_OUT_F32 if (out.dtype == torch.float32) else 0)
     d.batch = 1
     d.tile = tile
-    check(_lib.load().seer_gemm_bf16(C.byref(d), _stream()), "seer_gemm_bf16")
+    d.splits = splits
+    _launch_gemm(d, a.device, "seer_gemm_bf16")
     return out
+
+
+def _launch_gemm(d: GemmDesc, device, what: str) -> None:
+    """split-K needs a caller-provided fp32 workspace (the library never allocates): ask, allocate, launch."""
+    lib = _lib.load()
+    nbytes = lib.seer_gemm_workspace_bytes(C.byref(d))
+    if nbytes < 0:
+        check(int(nbytes), what)
+    if nbytes > 0:
+        ws = torch.empty((nbytes // 4,), device=device, dtype=torch.float32)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
+    check(lib.seer_gemm_bf16(C.byref(d), _stream()), what)
 
 
 def gemm_batched(a: torch.Tensor, w: torch.Tensor, *, trans_out=False, out: Optional[torch.Tensor] = None,
@@ -108,7 +121,7 @@ def gemm_batched(a: torch.Tensor, w: torch.Tensor, *, trans_out=False, out: Opti
 
 def conv3x3(x: torch.Tensor, w: torch.Tensor, n_img: int, Hin: int, Win: int, *, stride=1, upsample=False,
             bias=None, residual=None, rowvec=None, rows_per_batch=0, out: Optional[torch.Tensor] = None,
-            tile=0) -> torch.Tensor:
+            tile=0, splits=0) -> torch.Tensor:
     """x: channels-last [n_img*Hin*Win, Cin] bf16; w: [Cout, 9*Cin] ((ky,kx,ci) order). Returns [n_img*Ho*Wo, Cout]."""
     _req(x, bf16, "x"); _req(w, bf16, "w")
     assert x.is_contiguous() and w.is_contiguous()
@@ -137,7 +150,8 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, n_img: int, Hin: int, Win: int, *,
     d.Hin, d.Win, d.Cin, d.Hout, d.Wout, d.stride, d.upsample = Hin, Win, Cin, Ho, Wo, stride, int(upsample)
     d.batch = 1
     d.tile = tile
-    check(_lib.load().seer_gemm_bf16(C.byref(d), _stream()), "seer_gemm_bf16(conv3x3)")
+    d.splits = splits
+    _launch_gemm(d, x.device, "seer_gemm_bf16(conv3x3)")
     return out
 
 

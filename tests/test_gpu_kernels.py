@@ -55,6 +55,56 @@ def test_gemm_plain(device, M, N, K, tile):
     _close(out32, a.float() @ w.float().t(), rtol=2e-3, atol=2e-3, what="gemm f32 out")
 
 
+@pytest.mark.parametrize("M,N,K,splits", [(384, 1280, 1280, 0), (384, 1280, 5120, 4), (200, 68, 1024, 3), (1536, 1280, 5120, 0)])
+def test_gemm_split_k(device, M, N, K, splits):
+    """split-K (slices -> fp32 workspace -> ordered reduce + epilogue): same answer as one K loop, and deterministic."""
+    from seervideoldm_amd import ops
+    a = _rand((M, K), device, 1).to(bf16)
+    w = _rand((N, K), device, 2, K ** -0.5).to(bf16)
+    bias = _rand((N,), device, 3)
+    res = _rand((M, N), device, 4).to(bf16)
+    rv = _rand((2, N), device, 5)
+    ref = a.float() @ w.float().t() + bias + res.float() + rv.repeat_interleave(M // 2, 0)
+    o1 = ops.gemm(a, w, bias=bias, residual=res, rowvec=rv, rows_per_batch=M // 2, splits=splits)
+    o2 = ops.gemm(a, w, bias=bias, residual=res, rowvec=rv, rows_per_batch=M // 2, splits=splits)
+    _close(o1, ref, what=f"split-K gemm {M}x{N}x{K} s{splits}")
+    assert torch.equal(o1, o2)
+    o3 = ops.gemm(a, w, bias=bias, residual=res, rowvec=rv, rows_per_batch=M // 2, splits=1)
+    _close(o3, ref, what="unsplit")
+
+
+def test_conv3x3_split_k(device):
+    from seervideoldm_amd import ops
+    from seervideoldm_amd.weights import pack_conv3x3
+    n_img, H, W, Ci, Co = 6, 4, 4, 640, 320
+    x = _rand((n_img, Ci, H, W), device, 1).to(bf16)
+    w = _rand((Co, Ci, 3, 3), device, 2, (9 * Ci) ** -0.5).to(bf16)
+    bias = _rand((Co,), device, 3)
+    x_cl = x.permute(0, 2, 3, 1).reshape(-1, Ci).contiguous()
+    ref = Fn.conv2d(x.float(), w.float(), bias, padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
+    for s in (0, 5, 1):
+        _close(ops.conv3x3(x_cl, pack_conv3x3(w), n_img, H, W, bias=bias, splits=s), ref, what=f"conv split {s}")
+
+
+def test_gelu_erf_accuracy(device):
+    """the GEGLU epilogue's erf (Abramowitz-Stegun 7.1.26) against F.gelu over the whole useful range"""
+    from seervideoldm_amd import ops
+    from seervideoldm_amd.weights import interleave_geglu
+    C = 64
+    gate = torch.linspace(-9, 9, 4096, device=device)
+    a = torch.zeros((4096, C), device=device)
+    a[:, 0] = 1.0
+    a[:, 1] = gate
+    w = torch.zeros((2 * 32, C), device=device)      # value rows 0..31, gate rows 32..63
+    w[:32, 0] = 1.0                                   # value = 1
+    w[32:, 1] = 1.0                                   # gate = a[:, 1]
+    wi, bi = interleave_geglu(w.to(bf16), torch.zeros(64, device=device))
+    out = ops.gemm(a.to(bf16), wi, bias=bi, geglu=True, out_f32=True)
+    g = a.to(bf16)[:, 1].float()
+    ref = Fn.gelu(g)[:, None].expand(-1, 32)
+    assert (out - ref).abs().max() < 2e-6
+
+
 def test_gemm_identity_asymmetric(device):
     """A = I against an asymmetric W catches a transposed C write (cdna guide, MFMA section)."""
     from seervideoldm_amd import ops

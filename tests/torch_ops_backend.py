@@ -42,7 +42,7 @@ def _epilogue(acc, bias, geglu, rowvec, rows_per_batch, silu, residual, out_f32,
 
 
 def gemm(a, w, *, bias=None, residual=None, rowvec=None, rows_per_batch=0, a2=None, geglu=False, silu=False,
-         out_f32=False, out=None, tile=0):
+         out_f32=False, out=None, tile=0, splits=0):
     A = a.float() if a2 is None else torch.cat([a.float(), a2.float()], 1)
     assert A.shape[1] % 64 == 0 and w.dtype == bf16 and a.dtype == bf16
     return _epilogue(A @ w.float().t(), bias, geglu, rowvec, rows_per_batch, silu, residual, out_f32, out)
@@ -58,7 +58,7 @@ def gemm_batched(a, w, *, trans_out=False, out=None, bias=None, out_f32=False, t
 
 
 def conv3x3(x, w, n_img, Hin, Win, *, stride=1, upsample=False, bias=None, residual=None, rowvec=None,
-            rows_per_batch=0, out=None, tile=0):
+            rows_per_batch=0, out=None, tile=0, splits=0):
     Ci, Co = x.shape[1], w.shape[0]
     assert Ci % 64 == 0 and w.shape[1] == 9 * Ci
     xi = x.float().reshape(n_img, Hin, Win, Ci).permute(0, 3, 1, 2)
