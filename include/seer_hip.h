@@ -85,6 +85,12 @@ typedef struct seer_gemm_desc {
 #define SEER_TILE_128x128 1
 #define SEER_TILE_64x64 2
 #define SEER_TILE_128x64 3
+/* LDS-direct (global_load_lds) multi-stage variants: tile _ stages */
+#define SEER_TILE_G128x128_2 5
+#define SEER_TILE_G128x128_3 6
+#define SEER_TILE_G128x64_3 7
+#define SEER_TILE_G64x64_3 8
+#define SEER_TILE_G64x64_4 9
 
 int seer_gemm_bf16(const seer_gemm_desc* desc /* host */, void* stream);
 /* bytes of workspace the call would use for split-K with this descriptor (0: it will not split) */

@@ -15,6 +15,10 @@ bf16 = torch.bfloat16
 dev = torch.device("cuda:0")
 
 
+TILES = ((1, "128x128"), (5, "g128x128/2"), (6, "g128x128/3"), (3, "128x64"), (7, "g128x64/3"), (2, "64x64"),
+         (8, "g64x64/3"), (9, "g64x64/4"))
+
+
 def timeit(fn, iters=20, warmup=3):
     for _ in range(warmup):
         fn()
@@ -42,9 +46,9 @@ def bench_gemm():
         bias = torch.randn(N, device=dev)
         out = torch.empty((M, N // 2 if geglu else N), device=dev, dtype=bf16)
         line = f"gemm M{M} N{N} K{K} geglu={int(geglu)}:"
-        for tile, name in ((1, "128x128"), (3, "128x64"), (2, "64x64")):
-            t = timeit(lambda: ops.gemm(a, w, bias=bias, geglu=geglu, out=out, tile=tile))
-            line += f"  {name} {2 * M * N * K / t / 1e12:7.1f} TF ({t * 1e6:7.1f} us)"
+        for tile, name in TILES:
+            t = timeit(lambda: ops.gemm(a, w, bias=bias, geglu=geglu, out=out, tile=tile, splits=1))
+            line += f"  {name} {2 * M * N * K / t / 1e12:5.0f}TF {t * 1e6:6.1f}us |"
         print(line, flush=True)
 
 
@@ -62,9 +66,9 @@ def bench_conv():
         Ho = (2 * H if up else H) // s
         flops = 2 * n * Ho * Ho * Co * 9 * Ci
         line = f"conv n{n} {H}x{W} {Ci}->{Co} s{s} up{int(up)}:"
-        for tile, name in ((1, "128x128"), (3, "128x64"), (2, "64x64")):
-            t = timeit(lambda: ops.conv3x3(x, w, n, H, W, stride=s, upsample=up, bias=bias, tile=tile))
-            line += f"  {name} {flops / t / 1e12:7.1f} TF ({t * 1e6:7.1f} us)"
+        for tile, name in TILES:
+            t = timeit(lambda: ops.conv3x3(x, w, n, H, W, stride=s, upsample=up, bias=bias, tile=tile, splits=1))
+            line += f"  {name} {flops / t / 1e12:5.0f}TF {t * 1e6:6.1f}us |"
         print(line, flush=True)
 
 

@@ -18,7 +18,13 @@ namespace {
 
 constexpr int BK = 64;
 
-template <int BM, int BN, bool CONV, bool GEGLU, bool SPLIT>
+// 16 zero bytes: the source of out-of-image taps for the LDS-direct (global_load_lds) conv gather
+__device__ __attribute__((aligned(16))) unsigned int seer_zero_page[4] = {0u, 0u, 0u, 0u};
+
+// NS == 0: register-staged double buffer (global_load -> VGPR -> ds_write), one barrier per K tile.
+// NS >= 2: NS-stage ring filled by global_load_lds (16 B per lane straight into LDS, no VGPR / ds_write), NS-1 tiles in
+//          flight across raw s_barriers behind counted s_waitcnt vmcnt(N).  Same LDS image either way.
+template <int BM, int BN, bool CONV, bool GEGLU, bool SPLIT, int NS>
 __global__ void __launch_bounds__(256) seer_gemm_kernel(const seer_gemm_desc p) {
     constexpr int WTM = BM / 2, WTN = BN / 2;
     constexpr int TM = WTM / 16, TN = WTN / 16;
@@ -26,8 +32,8 @@ __global__ void __launch_bounds__(256) seer_gemm_kernel(const seer_gemm_desc p) 
     static_assert(!GEGLU || (TN % 2 == 0), "GEGLU needs value/gate n-tile pairs inside one wave");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bf16* As = reinterpret_cast<bf16*>(smem);   // [2][BM*64]
-    bf16* Bs = As + 2 * BM * BK;                // [2][BN*64]
+    constexpr int STAGE = (BM + BN) * BK;        // elements per stage: [A tile BM x 64][B tile BN x 64]
+    bf16* const smem_b = reinterpret_cast<bf16*>(smem);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -128,8 +134,8 @@ __global__ void __launch_bounds__(256) seer_gemm_kernel(const seer_gemm_desc p) 
         }
     };
     auto store_tile = [&](int buf) {
-        bf16* as = As + buf * BM * BK;
-        bf16* bs = Bs + buf * BN * BK;
+        bf16* as = smem_b + buf * STAGE;
+        bf16* bs = as + BM * BK;
         const int sw = ((tid & 7) ^ (srow & 7)) * 8;   // (row & 7) == (srow & 7) because rows step by 32
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) *reinterpret_cast<u32x4*>(as + (srow + 32 * i) * BK + sw) = areg[i];
@@ -149,15 +155,9 @@ __global__ void __launch_bounds__(256) seer_gemm_kernel(const seer_gemm_desc p) 
     const int frow = lane & 15;        // operand row inside a 16-row fragment
     const int fq = lane >> 4;          // 16-byte chunk inside a 32-wide k-step
 
-    load_tile(kt0);
-    store_tile(0);
-    __syncthreads();
-
-    for (int kt = kt0; kt < nk; ++kt) {
-        const int buf = (kt - kt0) & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
-        const bf16* as = As + buf * BM * BK + (wm * WTM) * BK;
-        const bf16* bs = Bs + buf * BN * BK + (wn * WTN) * BK;
+    auto compute_tile = [&](int buf) {
+        const bf16* as = smem_b + buf * STAGE + (wm * WTM) * BK;
+        const bf16* bs = smem_b + buf * STAGE + BM * BK + (wn * WTN) * BK;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int sw = (((ks * 4 + fq) ^ (frow & 7)) * 8);
@@ -172,8 +172,78 @@ __global__ void __launch_bounds__(256) seer_gemm_kernel(const seer_gemm_desc p) 
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
+    };
+
+    if constexpr (NS == 0) {
+        load_tile(kt0);
+        store_tile(0);
         __syncthreads();
+        for (int kt = kt0; kt < nk; ++kt) {
+            const int buf = (kt - kt0) & 1;
+            if (kt + 1 < nk) load_tile(kt + 1);
+            compute_tile(buf);
+            if (kt + 1 < nk) store_tile(buf ^ 1);
+            __syncthreads();
+        }
+    } else {
+        // ---- LDS-direct ring.  One wave instruction writes 1 KiB = 8 rows x 128 B, lane l -> (row l>>3, slot l&7); the
+        // XOR swizzle goes on the SOURCE chunk (slot ^ row&7), the LDS image stays lane-linear (cdna guide, rule 21).
+        constexpr int LPT = A_CH + B_CH;           // global_load_lds per wave per K tile
+        const int schunk = ((tid & 7) ^ (srow & 7)) * 8;
+        auto issue_tile = [&](int kt, int stage) {
+            const int kbase = kt * BK;
+            bf16* as = smem_b + stage * STAGE + (8 * wave) * BK;      // this wave's 8-row group (wave-uniform)
+            bf16* bs = smem_b + stage * STAGE + BM * BK + (8 * wave) * BK;
+            if constexpr (CONV) {
+                const int tap = kbase / p.Cin;
+                const int ci0 = kbase - tap * p.Cin;
+                const int ky = tap / 3, kx = tap - ky * 3;
+                const int Hs = p.upsample ? p.Hin * 2 : p.Hin;
+                const int Ws = p.upsample ? p.Win * 2 : p.Win;
+#pragma unroll
+                for (int i = 0; i < A_CH; ++i) {
+                    const int iy = a_oy[i] + ky, ix = a_ox[i] + kx;
+                    const bool ok = (iy >= 0) & (iy < Hs) & (ix >= 0) & (ix < Ws);
+                    const int sy = p.upsample ? (iy >> 1) : iy;
+                    const int sx = p.upsample ? (ix >> 1) : ix;
+                    const bf16* src = ok ? (A + a_off[i] + ((int64_t)sy * p.Win + sx) * p.Cin + ci0 + schunk)
+                                         : reinterpret_cast<const bf16*>(seer_zero_page);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(as + 32 * i * BK), 16, 0, 0);
+                }
+            } else {
+                const bool second = kbase >= p.K1;
+#pragma unroll
+                for (int i = 0; i < A_CH; ++i) {
+                    const bf16* src = second ? (A2 + a_off2[i] + (kbase - p.K1) + schunk) : (A + a_off[i] + kbase + schunk);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(as + 32 * i * BK), 16, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < B_CH; ++i) {
+                const bf16* src = W + b_off[i] + kbase + schunk;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(bs + 32 * i * BK), 16, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int s_ = 0; s_ < NS - 1; ++s_)
+            if (kt0 + s_ < nk) issue_tile(kt0 + s_, s_);
+        int stage = 0;
+        for (int kt = kt0; kt < nk; ++kt) {
+            // tiles issued after tile kt and still allowed in flight while we wait for tile kt
+            const int pending = min(NS - 2, nk - 1 - kt);
+            if (NS >= 4 && pending >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+            else if (NS >= 3 && pending == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // every wave's part of tile kt has landed AND every wave is done reading stage (kt-1): safe to refill it
+            asm volatile("s_barrier" ::: "memory");
+            const int nxt = kt + NS - 1;
+            if (nxt < nk) issue_tile(nxt, (stage + NS - 1) % NS);
+            compute_tile(stage);
+            stage = (stage + 1 == NS) ? 0 : stage + 1;
+        }
     }
 
     // ---- split-K: raw fp32 partial tile to the workspace slice of this K range; the reduce kernel does the epilogue
@@ -312,20 +382,33 @@ __global__ void __launch_bounds__(256) seer_splitk_reduce_kernel(const seer_gemm
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int NS>
 int launch_tile(const seer_gemm_desc& d, hipStream_t st) {
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, 1, d.batch > 1 ? d.batch : 1);
-    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16);
+    const size_t lds = (size_t)(NS == 0 ? 2 : NS) * (BM + BN) * BK * sizeof(bf16);
+    if (lds > 64 * 1024) {
+        // above the default dynamic-LDS limit: opt in once per instantiation (160 KiB per CU on gfx950)
+        static bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, true, false, false, NS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, false, true, false, NS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, false, false, false, NS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            done = true;
+        }
+    }
     const bool conv = d.mode == SEER_GEMM_CONV3X3;
     const bool geglu = (d.epilogue & SEER_EPI_GEGLU) != 0;
     if (conv && geglu) return SEER_EINVAL;
     if (conv) {
-        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, true, false, false>), grid, dim3(256), lds, st, d);
+        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, true, false, false, NS>), grid, dim3(256), lds, st, d);
     } else if (geglu) {
-        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, true, false>), grid, dim3(256), lds, st, d);
+        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, true, false, NS>), grid, dim3(256), lds, st, d);
     } else {
-        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, false, false>), grid, dim3(256), lds, st, d);
+        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, false, false, NS>), grid, dim3(256), lds, st, d);
     }
     SEER_LAUNCH_CHECK();
     return SEER_OK;
@@ -337,9 +420,9 @@ int launch_split(const seer_gemm_desc& d, hipStream_t st) {
     dim3 grid(tiles_m * tiles_n, 1, d.splits);
     const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16);
     if (d.mode == SEER_GEMM_CONV3X3)
-        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, true, false, true>), grid, dim3(256), lds, st, d);
+        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, true, false, true, 0>), grid, dim3(256), lds, st, d);
     else
-        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, false, true>), grid, dim3(256), lds, st, d);
+        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, false, true, 0>), grid, dim3(256), lds, st, d);
     SEER_LAUNCH_CHECK();
     const int64_t n = (int64_t)d.M * (d.N / 4);
     hipLaunchKernelGGL(seer_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d);
@@ -374,20 +457,17 @@ int prepare(seer_gemm_desc& d, int* splits) {
     // split-K decision: few output tiles and a long K loop (deep-level convs / linears, M = 384 .. 1536)
     int s = 1;
     const bool can_split = d.batch == 1 && !geglu && !(d.epilogue & SEER_EPI_TRANS_OUT) &&
-                           (d.tile == SEER_TILE_AUTO || d.tile == SEER_TILE_64x64);
+                           (d.tile == SEER_TILE_AUTO || d.tile == SEER_TILE_64x64) && d.splits != 1;
     if (can_split) {
         const int nk = d.K / BK;
         if (d.splits > 1) {
             s = d.splits < nk ? d.splits : nk;
         } else if (d.splits == 0) {
+            // measured on MI355X (profiles/r01_splitk_sweep.log): the reduce pass + second launch cost ~4-5 us, so
+            // splitting pays only when a slice still has >= 10 K tiles and the unsplit grid leaves most CUs idle
             const long blocks = (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
-            if (blocks <= 512 && nk >= 16) {
-                long want = (1024 + blocks - 1) / blocks;          // ~4 blocks per CU
-                long maxs = nk / 8;                                  // >= 8 K tiles per slice
-                s = (int)(want < maxs ? want : maxs);
-                if (s > 16) s = 16;
-                if (s < 1) s = 1;
-            }
+            if (blocks <= 160 && nk >= 40) s = nk / 10 < 8 ? nk / 10 : 8;
+            else if (blocks <= 512 && nk >= 160) s = 4;
         }
     }
     *splits = s;
@@ -427,9 +507,14 @@ extern "C" int seer_gemm_bf16(const seer_gemm_desc* desc, void* stream) {
         else tile = SEER_TILE_64x64;
     }
     switch (tile) {
-        case SEER_TILE_128x128: return launch_tile<128, 128>(d, st);
-        case SEER_TILE_128x64: return launch_tile<128, 64>(d, st);
-        case SEER_TILE_64x64: return launch_tile<64, 64>(d, st);
+        case SEER_TILE_128x128: return launch_tile<128, 128, 0>(d, st);
+        case SEER_TILE_128x64: return launch_tile<128, 64, 0>(d, st);
+        case SEER_TILE_64x64: return launch_tile<64, 64, 0>(d, st);
+        case SEER_TILE_G128x128_2: return launch_tile<128, 128, 2>(d, st);
+        case SEER_TILE_G128x128_3: return launch_tile<128, 128, 3>(d, st);
+        case SEER_TILE_G128x64_3: return launch_tile<128, 64, 3>(d, st);
+        case SEER_TILE_G64x64_3: return launch_tile<64, 64, 3>(d, st);
+        case SEER_TILE_G64x64_4: return launch_tile<64, 64, 4>(d, st);
         default: return SEER_EINVAL;
     }
 }

@@ -41,6 +41,9 @@ def _close(got, ref, rtol=2e-2, atol=2e-2, what=""):
     (256, 128, 64, 1), (256, 128, 64, 2), (256, 128, 64, 3),
     (384, 320, 320, 0), (1536, 1280, 1280, 0), (1848, 640, 768, 0), (6144, 640, 2560, 0),
     (100, 64, 128, 2), (130, 68, 192, 3), (24576, 320, 320, 1),
+    # LDS-direct (global_load_lds) multi-stage variants: tile codes 5..9
+    (256, 128, 64, 5), (512, 256, 1280, 5), (512, 256, 1280, 6), (130, 68, 192, 7), (1536, 1280, 1280, 7),
+    (100, 64, 128, 8), (384, 320, 2560, 8), (384, 320, 2560, 9), (1848, 640, 768, 9), (6144, 640, 128, 9),
 ])
 def test_gemm_plain(device, M, N, K, tile):
     from seervideoldm_amd import ops
@@ -172,14 +175,15 @@ def test_gemm_batched_and_transposed(device):
     (2, 8, 8, 64, 64, 1, True), (24, 32, 32, 320, 320, 1, False), (4, 4, 4, 1280, 1280, 1, False),
     (2, 6, 10, 64, 68, 1, False),
 ])
-def test_conv3x3(device, n_img, H, W, Ci, Co, stride, up):
+@pytest.mark.parametrize("tile", [0, 7, 9])
+def test_conv3x3(device, n_img, H, W, Ci, Co, stride, up, tile):
     from seervideoldm_amd import ops
     from seervideoldm_amd.weights import pack_conv3x3
     x = _rand((n_img, Ci, H, W), device, 1).to(bf16)
     w = _rand((Co, Ci, 3, 3), device, 2, (9 * Ci) ** -0.5).to(bf16)
     bias = _rand((Co,), device, 3)
     x_cl = x.permute(0, 2, 3, 1).reshape(-1, Ci).contiguous()
-    out = ops.conv3x3(x_cl, pack_conv3x3(w), n_img, H, W, stride=stride, upsample=up, bias=bias)
+    out = ops.conv3x3(x_cl, pack_conv3x3(w), n_img, H, W, stride=stride, upsample=up, bias=bias, tile=tile, splits=1)
     xin = x.float()
     if up:
         xin = Fn.interpolate(xin, scale_factor=2.0, mode="nearest")
