@@ -15,8 +15,7 @@ bf16 = torch.bfloat16
 dev = torch.device("cuda:0")
 
 
-TILES = ((1, "128x128"), (5, "g128x128/2"), (6, "g128x128/3"), (3, "128x64"), (7, "g128x64/3"), (2, "64x64"),
-         (8, "g64x64/3"), (9, "g64x64/4"))
+TILES = ((0, "auto"), (5, "g128x128/2"), (7, "g128x64/3"), (2, "64x64"), (8, "g64x64/3"))
 
 
 def timeit(fn, iters=20, warmup=3):
@@ -47,7 +46,7 @@ def bench_gemm():
         out = torch.empty((M, N // 2 if geglu else N), device=dev, dtype=bf16)
         line = f"gemm M{M} N{N} K{K} geglu={int(geglu)}:"
         for tile, name in TILES:
-            t = timeit(lambda: ops.gemm(a, w, bias=bias, geglu=geglu, out=out, tile=tile, splits=1))
+            t = timeit(lambda: ops.gemm(a, w, bias=bias, geglu=geglu, out=out, tile=tile, splits=(0 if tile == 0 else 1)))
             line += f"  {name} {2 * M * N * K / t / 1e12:5.0f}TF {t * 1e6:6.1f}us |"
         print(line, flush=True)
 
@@ -67,7 +66,7 @@ def bench_conv():
         flops = 2 * n * Ho * Ho * Co * 9 * Ci
         line = f"conv n{n} {H}x{W} {Ci}->{Co} s{s} up{int(up)}:"
         for tile, name in TILES:
-            t = timeit(lambda: ops.conv3x3(x, w, n, H, W, stride=s, upsample=up, bias=bias, tile=tile, splits=1))
+            t = timeit(lambda: ops.conv3x3(x, w, n, H, W, stride=s, upsample=up, bias=bias, tile=tile, splits=(0 if tile == 0 else 1)))
             line += f"  {name} {flops / t / 1e12:5.0f}TF {t * 1e6:6.1f}us |"
         print(line, flush=True)
 

@@ -155,23 +155,28 @@ __global__ void __launch_bounds__(256) seer_gemm_kernel(const seer_gemm_desc p) 
     const int frow = lane & 15;        // operand row inside a 16-row fragment
     const int fq = lane >> 4;          // 16-byte chunk inside a 32-wide k-step
 
+    // all fragment reads of the K tile (both 32-wide k-steps) are issued before the first MFMA: one exposed LDS latency
+    // per tile instead of one per k-step (with 1-2 waves per SIMD nothing else hides it); the compiler's counted
+    // lgkmcnt waits let the first MFMAs start as soon as the k-step-0 fragments are back.
     auto compute_tile = [&](int buf) {
         const bf16* as = smem_b + buf * STAGE + (wm * WTM) * BK;
         const bf16* bs = smem_b + buf * STAGE + BM * BK + (wn * WTN) * BK;
+        bf16x8 af[2][TM], wf[2][TN];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int sw = (((ks * 4 + fq) ^ (frow & 7)) * 8);
-            bf16x8 af[TM], wf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(as + (i * 16 + frow) * BK + sw);
+            for (int j = 0; j < TN; ++j) wf[ks][j] = *reinterpret_cast<const bf16x8*>(bs + (j * 16 + frow) * BK + sw);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(bs + (j * 16 + frow) * BK + sw);
+            for (int i = 0; i < TM; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(as + (i * 16 + frow) * BK + sw);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
     };
 
     if constexpr (NS == 0) {
@@ -415,14 +420,18 @@ int launch_tile(const seer_gemm_desc& d, hipStream_t st) {
 }
 
 int launch_split(const seer_gemm_desc& d, hipStream_t st) {
-    constexpr int BM = 64, BN = 64;
+    constexpr int BM = 64, BN = 64, NS = 3;
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, 1, d.splits);
-    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16);
-    if (d.mode == SEER_GEMM_CONV3X3)
-        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, true, false, true, 0>), grid, dim3(256), lds, st, d);
-    else
-        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, false, true, 0>), grid, dim3(256), lds, st, d);
+    const bool reg = d.tile == SEER_TILE_64x64;       // explicit 64x64 request keeps the register-staged loop (A/B testing)
+    const size_t lds = (size_t)(reg ? 2 : NS) * (BM + BN) * BK * sizeof(bf16);
+    if (d.mode == SEER_GEMM_CONV3X3) {
+        if (reg) hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, true, false, true, 0>), grid, dim3(256), lds, st, d);
+        else hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, true, false, true, NS>), grid, dim3(256), lds, st, d);
+    } else {
+        if (reg) hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, false, true, 0>), grid, dim3(256), lds, st, d);
+        else hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, false, true, NS>), grid, dim3(256), lds, st, d);
+    }
     SEER_LAUNCH_CHECK();
     const int64_t n = (int64_t)d.M * (d.N / 4);
     hipLaunchKernelGGL(seer_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d);
@@ -457,7 +466,8 @@ int prepare(seer_gemm_desc& d, int* splits) {
     // split-K decision: few output tiles and a long K loop (deep-level convs / linears, M = 384 .. 1536)
     int s = 1;
     const bool can_split = d.batch == 1 && !geglu && !(d.epilogue & SEER_EPI_TRANS_OUT) &&
-                           (d.tile == SEER_TILE_AUTO || d.tile == SEER_TILE_64x64) && d.splits != 1;
+                           (d.tile == SEER_TILE_AUTO || d.tile == SEER_TILE_64x64 || d.tile == SEER_TILE_G64x64_3) &&
+                           d.splits != 1;
     if (can_split) {
         const int nk = d.K / BK;
         if (d.splits > 1) {
@@ -500,10 +510,17 @@ extern "C" int seer_gemm_bf16(const seer_gemm_desc* desc, void* stream) {
 
     int tile = d.tile;
     if (tile == SEER_TILE_AUTO) {
+        // from the MI355X sweep (profiles/r01_gemm_tile_sweep.log): LDS-direct 2-stage 128x128 wherever it fills the chip,
+        // LDS-direct 3-stage 128x64 / 64x64 for narrow N or few rows once the K loop is long enough to amortise the ring
+        // prologue, register-staged 64x64 for short K.
+        const int nk = d.K / BK;
         const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch;
         const long t12864 = (long)((d.M + 127) / 128) * ((d.N + 63) / 64) * d.batch;
-        if (t128 >= 448 && d.N % 128 == 0) tile = SEER_TILE_128x128;
-        else if (t12864 >= 384) tile = SEER_TILE_128x64;
+        const int n128 = (d.N + 127) / 128 * 128;
+        const bool n_fits_128 = (n128 - d.N) * 8 <= d.N;           // <= 12.5 % padded columns
+        if (t128 >= 256 && n_fits_128 && d.N >= 640) tile = SEER_TILE_G128x128_2;
+        else if (t12864 >= 256 && nk >= 10) tile = SEER_TILE_G128x64_3;
+        else if (nk >= 12) tile = SEER_TILE_G64x64_3;
         else tile = SEER_TILE_64x64;
     }
     switch (tile) {
