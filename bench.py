@@ -214,6 +214,31 @@ def main():
                         step_breakdown_ms={k: round(v["ms"] / reps, 3) for k, v in summ.items()},
                         attention_tflops=round(summ.get("attention", {}).get("tflops", 0.0), 2))
 
+    # ---- end-to-end clip latency: 50 DDIM steps + frozen VAE decode of the 10 predicted frames
+    clip = None
+    if rank == 0 and world == 1:
+        from seervideoldm_amd import AutoencoderKL, ddim_sample
+        from seervideoldm_amd.vae import ldm_to_diffusers_vae
+        vae = AutoencoderKL().to(device)
+        vae.load_state_dict(ldm_to_diffusers_vae(synth.synth_state_dict(synth.vae_param_shapes(), device=device), 4))
+        model.use_graph = not args.no_graph
+        shape = (w["b"], 4, w["frames"] - w["cond_frames"], w["latent"], w["latent"])
+        for _ in range(2):          # first call builds the VAE's packed weights / warms allocations
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = ddim_sample(sampler, model, vae, shape, c, x_T, x0_emb, ddim_steps=w["ddim_steps"], scale=w["scale"], uc=uc)
+            torch.cuda.synchronize()
+            t_clip = time.perf_counter() - t0
+        z = torch.randn((shape[0] * shape[2], 4, w["latent"], w["latent"]), device=device)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        vae.decode(z)
+        torch.cuda.synchronize()
+        t_dec = time.perf_counter() - t0
+        assert out.shape == (w["b"], 3, shape[2], 8 * w["latent"], 8 * w["latent"]) and torch.isfinite(out).all()
+        clip = dict(clip_latency_ms=round(t_clip * 1e3, 2), vae_decode_ms=round(t_dec * 1e3, 2),
+                    what="50-step ddim_sample incl. decode of 10 frames to 256x256 (full SD-VAE decoder, synthetic weights)")
+
     cpu = None
     if sd_cpu is not None:
         cpu = cpu_baseline(sd_cpu, cfg, args.cpu_budget_s)
@@ -228,7 +253,7 @@ def main():
             "config": {"workload": "Sthv2 config: CFG batch 2 x 12 frames (2 cond + 10 predicted) x 32x32 latent, "
                                    "full-width SeerUNet 1.08G params, 50-step DDIM, scale 7.5",
                        "parallelism": par, "hip_graph": bool(not args.no_graph and world == 1)},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "end_to_end": clip,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

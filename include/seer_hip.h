@@ -52,6 +52,7 @@ const char* seer_build_arch(void);          /* "gfx950" */
 #define SEER_EPI_OUT_F32 2u    /* C is fp32 instead of bf16 */
 #define SEER_EPI_SILU 4u       /* C = silu(acc + bias) (time_embedding.linear_1) */
 #define SEER_EPI_TRANS_OUT 8u  /* store C transposed: Ct[n*ldc + m] (used for V^T in the VAE attention) */
+#define SEER_EPI_ROTARY 16u    /* rotate the q|k columns (n < rot_cols) of a fused q|k|v projection (attention.py:649-651) */
 
 typedef struct seer_gemm_desc {
     const void* A;          /* bf16 */
@@ -79,6 +80,11 @@ typedef struct seer_gemm_desc {
     int32_t splits;
     void* workspace;
     int64_t workspace_bytes;
+    /* SEER_EPI_ROTARY: cos/sin table of seer_rotary_table ([pos][rot_dim/2][2] fp32); position of row m is
+     * m % rot_tokens_per_batch + rot_pos_offset; columns n < rot_cols are heads of rot_head_dim channels of which the first
+     * rot_dim are rotated (interleaved pairs) */
+    const float* rot_table;
+    int32_t rot_tokens_per_batch, rot_pos_offset, rot_head_dim, rot_dim, rot_cols;
 } seer_gemm_desc;
 
 #define SEER_TILE_AUTO 0
@@ -91,6 +97,8 @@ typedef struct seer_gemm_desc {
 #define SEER_TILE_G128x64_3 7
 #define SEER_TILE_G64x64_3 8
 #define SEER_TILE_G64x64_4 9
+#define SEER_TILE_G64x64_5 10
+#define SEER_TILE_G128x64_4 11
 
 int seer_gemm_bf16(const seer_gemm_desc* desc /* host */, void* stream);
 /* bytes of workspace the call would use for split-K with this descriptor (0: it will not split) */

@@ -149,6 +149,25 @@ __global__ void __launch_bounds__(256) seer_gemm_kernel(const seer_gemm_desc p) 
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // ---- residual tile prefetch: the epilogue's bf16 residual (8 B per accumulator quad) is requested before the K loop so
+    // its HBM/L2 latency hides under the main loop instead of adding a dependent round trip to every block's tail
+    const bf16* R = reinterpret_cast<const bf16*>(p.residual);
+    u32x2 rpre[TM][TN];
+    if constexpr (!GEGLU && !SPLIT) {
+        if (R) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = m0 + wm * WTM + i * 16 + (lane & 15);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn * WTN + j * 16 + (lane >> 4) * 4;
+                    rpre[i][j] = (m < p.M && n < p.N) ? *reinterpret_cast<const u32x2*>(R + (int64_t)m * p.ldr + n)
+                                                        : u32x2{0u, 0u};
+                }
+            }
+        }
+    }
+
     const int nk_all = p.K / BK;
     const int kt0 = SPLIT ? (int)((int64_t)nk_all * blockIdx.z / p.splits) : 0;
     const int nk = SPLIT ? (int)((int64_t)nk_all * (blockIdx.z + 1) / p.splits) : nk_all;
@@ -239,7 +258,8 @@ __global__ void __launch_bounds__(256) seer_gemm_kernel(const seer_gemm_desc p) 
         for (int kt = kt0; kt < nk; ++kt) {
             // tiles issued after tile kt and still allowed in flight while we wait for tile kt
             const int pending = min(NS - 2, nk - 1 - kt);
-            if (NS >= 4 && pending >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+            if (NS >= 5 && pending >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");
+            else if (NS >= 4 && pending == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
             else if (NS >= 3 && pending == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // every wave's part of tile kt has landed AND every wave is done reading stage (kt-1): safe to refill it
@@ -274,7 +294,7 @@ __global__ void __launch_bounds__(256) seer_gemm_kernel(const seer_gemm_desc p) 
     const bool trans = (p.epilogue & SEER_EPI_TRANS_OUT) != 0;
     bf16* Cb = reinterpret_cast<bf16*>(p.C) + (int64_t)z * p.strideC;
     float* Cf = reinterpret_cast<float*>(p.C) + (int64_t)z * p.strideC;
-    const bf16* R = reinterpret_cast<const bf16*>(p.residual);
+    const bool do_rot = (p.epilogue & SEER_EPI_ROTARY) != 0;
 
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -316,8 +336,24 @@ __global__ void __launch_bounds__(256) seer_gemm_kernel(const seer_gemm_desc p) 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
             }
+            if (do_rot && n < p.rot_cols) {
+                // rotary on q|k columns (attention.py:649-651): channel inside its head = n % head_dim; the lane's 4
+                // consecutive columns are two interleaved pairs (x0,x1) -> (x0 c - x1 s, x1 c + x0 s)
+                const int ch = n % p.rot_head_dim;
+                if (ch < p.rot_dim) {
+                    const int pos = m % p.rot_tokens_per_batch + p.rot_pos_offset;
+                    const f32x4 cs = *reinterpret_cast<const f32x4*>(p.rot_table + ((int64_t)pos * (p.rot_dim / 2) + ch / 2) * 2);
+                    const float a0 = v[0], b0 = v[1], a1 = v[2], b1 = v[3];
+                    v[0] = a0 * cs[0] - b0 * cs[1];
+                    v[1] = b0 * cs[0] + a0 * cs[1];
+                    v[2] = a1 * cs[2] - b1 * cs[3];
+                    v[3] = b1 * cs[2] + a1 * cs[3];
+                }
+            }
             if (R) {
-                const u32x2 rv = *reinterpret_cast<const u32x2*>(R + (int64_t)m * p.ldr + nc);
+                u32x2 rv;
+                if constexpr (!GEGLU) rv = rpre[i][j];
+                else rv = *reinterpret_cast<const u32x2*>(R + (int64_t)m * p.ldr + nc);
                 v[0] += __builtin_bit_cast(float, rv[0] << 16);
                 v[1] += __builtin_bit_cast(float, rv[0] & 0xffff0000u);
                 v[2] += __builtin_bit_cast(float, rv[1] << 16);
@@ -461,11 +497,16 @@ int prepare(seer_gemm_desc& d, int* splits) {
     if (!(d.epilogue & SEER_EPI_TRANS_OUT) && (d.ldc % 4)) return SEER_EINVAL;
     if (d.residual && (d.ldr % 4)) return SEER_EINVAL;
     if (d.rowvec && d.rows_per_batch <= 0) return SEER_EINVAL;
+    if (d.epilogue & SEER_EPI_ROTARY) {
+        if (!d.rot_table || d.rot_head_dim <= 0 || d.rot_head_dim % 4 || d.rot_dim <= 0 || d.rot_dim % 4 ||
+            d.rot_dim > d.rot_head_dim || d.rot_tokens_per_batch <= 0 || d.rot_cols % d.rot_head_dim || geglu)
+            return SEER_EINVAL;
+    }
     if (d.batch <= 1) d.batch = 1;
 
     // split-K decision: few output tiles and a long K loop (deep-level convs / linears, M = 384 .. 1536)
     int s = 1;
-    const bool can_split = d.batch == 1 && !geglu && !(d.epilogue & SEER_EPI_TRANS_OUT) &&
+    const bool can_split = d.batch == 1 && !geglu && !(d.epilogue & (SEER_EPI_TRANS_OUT | SEER_EPI_ROTARY)) &&
                            (d.tile == SEER_TILE_AUTO || d.tile == SEER_TILE_64x64 || d.tile == SEER_TILE_G64x64_3) &&
                            d.splits != 1;
     if (can_split) {
@@ -532,6 +573,8 @@ extern "C" int seer_gemm_bf16(const seer_gemm_desc* desc, void* stream) {
         case SEER_TILE_G128x64_3: return launch_tile<128, 64, 3>(d, st);
         case SEER_TILE_G64x64_3: return launch_tile<64, 64, 3>(d, st);
         case SEER_TILE_G64x64_4: return launch_tile<64, 64, 4>(d, st);
+        case SEER_TILE_G64x64_5: return launch_tile<64, 64, 5>(d, st);
+        case SEER_TILE_G128x64_4: return launch_tile<128, 64, 4>(d, st);
         default: return SEER_EINVAL;
     }
 }

@@ -115,7 +115,6 @@ class DDIMSampler(object):
         timesteps = self.ddim_timesteps
         intermediates = {"x_inter": [img], "pred_x0": [img]}
         total_steps = timesteps.shape[0]
-        self._cfg_inputs = None
         for i, step in enumerate(np.flip(timesteps)):
             index = total_steps - i - 1
             ts = self._t_table[index].expand(b)
@@ -131,7 +130,6 @@ class DDIMSampler(object):
             if index % log_every_t == 0 or index == total_steps - 1:
                 intermediates["x_inter"].append(img)
                 intermediates["pred_x0"].append(pred_x0)
-        self._cfg_inputs = None
         return img, intermediates
 
     @torch.no_grad()
@@ -156,8 +154,9 @@ class DDIMSampler(object):
             cfg = False
         elif uc.shape[2] == c.shape[2]:
             cached = getattr(self, "_cfg_inputs", None)
-            if cached is None or cached[0] is not c or cached[1] is not uc:
-                cached = (c, uc, torch.cat([uc, c]).contiguous())
+            if (cached is None or cached[0] is not c or cached[1] is not uc or cached[3] != (c._version, uc._version)):
+                # one [uc, c] tensor per (c, uc) pair: its identity keys the UNet's cross-attention K/V cache and graph
+                cached = (c, uc, torch.cat([uc, c]).contiguous(), (c._version, uc._version))
                 self._cfg_inputs = cached
             eps = unet(torch.cat([x_cat] * 2), torch.cat([t] * 2), cached[2], cond_frame=cond_frames)
             cfg = True

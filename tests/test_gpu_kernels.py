@@ -290,6 +290,36 @@ def test_window_attention(device, d, Fr, H, W, ws):
     _close(out, o, rtol=2e-2, atol=1e-2, what="window attention")
 
 
+@pytest.mark.parametrize("d,Fr,H,W,ws,f0,f1", [(40, 6, 16, 16, 4, 2, 4), (80, 5, 8, 8, 4, 3, 5), (160, 4, 4, 4, 0, 1, 3),
+                                               (40, 4, 32, 32, 8, 0, 2)])
+def test_frame_shard_attention(device, d, Fr, H, W, ws, f0, f1):
+    """frame-sharded temporal attention: queries of frames [f0, f1) against the K|V of all frames with
+    causal_offset = position of frame f0 must equal the rows [f0, f1) of the unsharded causal attention."""
+    from seervideoldm_amd import ops
+    B, Hh = 2, 8
+    C = Hh * d
+    T = Fr * H * W
+    qkv = _rand((B * T, 3 * C), device, 21).to(bf16)
+    full = torch.zeros((B * T, C), device=device, dtype=bf16)
+    if ws:
+        ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], full, batch=B, heads=Hh, head_dim=d,
+                      Sq=Fr * ws * ws, Sk=Fr * ws * ws, causal=True, window=(ws, Fr, H, W))
+    else:
+        ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], full, batch=B, heads=Hh, head_dim=d,
+                      Sq=T, Sk=T, causal=True)
+    Fl = f1 - f0
+    ql = qkv.reshape(B, Fr, H * W, 3 * C)[:, f0:f1, :, :C].reshape(B * Fl * H * W, C).contiguous()
+    out = torch.zeros((B * Fl * H * W, C), device=device, dtype=bf16)
+    if ws:
+        ops.attention(ql, qkv[:, C:2 * C], qkv[:, 2 * C:], out, batch=B, heads=Hh, head_dim=d, Sq=Fl * ws * ws,
+                      Sk=Fr * ws * ws, causal=True, window=(ws, Fr, H, W), Fq=Fl, causal_offset=f0 * ws * ws)
+    else:
+        ops.attention(ql, qkv[:, C:2 * C], qkv[:, 2 * C:], out, batch=B, heads=Hh, head_dim=d, Sq=Fl * H * W, Sk=T,
+                      causal=True, causal_offset=f0 * H * W)
+    ref = full.reshape(B, Fr, H * W, C)[:, f0:f1].reshape(B * Fl * H * W, C)
+    assert torch.equal(out, ref), "a frame shard must reproduce the unsharded rows bit for bit"
+
+
 def test_rotary(device):
     from seervideoldm_amd import ops
     B, T, Hh, d = 2, 640, 8, 40
