@@ -13,7 +13,7 @@ _PKG = Path(__file__).resolve().parent
 _LIB_PATH = _PKG / "lib" / "libseer_hip.so"
 _lib = None
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 SEER_GEMM_PLAIN = 0
 SEER_GEMM_CONV3X3 = 1
@@ -21,6 +21,7 @@ SEER_EPI_GEGLU = 1
 SEER_EPI_OUT_F32 = 2
 SEER_EPI_SILU = 4
 SEER_EPI_TRANS_OUT = 8
+SEER_EPI_ROTARY = 16
 SEER_TILE_AUTO, SEER_TILE_128x128, SEER_TILE_64x64, SEER_TILE_128x64 = 0, 1, 2, 3
 
 
@@ -41,6 +42,8 @@ class GemmDesc(C.Structure):
         ("batch", C.c_int32),
         ("strideA", C.c_int64), ("strideW", C.c_int64), ("strideC", C.c_int64),
         ("tile", C.c_int32), ("splits", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("rot_table", C.c_void_p), ("rot_tokens_per_batch", C.c_int32), ("rot_pos_offset", C.c_int32),
+        ("rot_head_dim", C.c_int32), ("rot_dim", C.c_int32), ("rot_cols", C.c_int32),
     ]
 
 

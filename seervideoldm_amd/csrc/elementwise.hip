@@ -401,7 +401,7 @@ extern "C" int seer_clamp01(float* x, int64_t n, void* stream) {
     return SEER_OK;
 }
 
-extern "C" int seer_abi_version(void) { return 4; }
+extern "C" int seer_abi_version(void) { return 5; }
 extern "C" const char* seer_build_arch(void) { return "gfx950"; }
 extern "C" const char* seer_strerror(int code) {
     switch (code) {

@@ -38,8 +38,9 @@ def _req(t: torch.Tensor, dtype, name: str):
 # ------------------------------------------------------------------------------------------------------------
 def gemm(a: torch.Tensor, w: torch.Tensor, *, bias=None, residual=None, rowvec=None, rows_per_batch=0,
          a2: Optional[torch.Tensor] = None, geglu=False, silu=False, out_f32=False, out: Optional[torch.Tensor] = None,
-         tile=0, splits=0) -> torch.Tensor:
-    """out[M,N] = epi(a[M,K1] | a2[M,K-K1]) @ w[N,K]^T ; a/a2 may be row-strided views (last dim contiguous)."""
+         tile=0, splits=0, rotary=None) -> torch.Tensor:
+    """out[M,N] = epi(a[M,K1] | a2[M,K-K1]) @ w[N,K]^T ; a/a2 may be row-strided views (last dim contiguous).
+    rotary = (cos_sin table, tokens_per_batch, pos_offset, head_dim, rot_dim, cols): rotate columns < cols in the epilogue."""
     _req(a, bf16, "a"); _req(w, bf16, "w")
     assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.is_contiguous()
     M, K1 = a.shape
@@ -72,6 +73,13 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias=None, residual=None, rowvec=N
     d.mode = _lib.SEER_GEMM_PLAIN
     d.epilogue = (_lib.SEER_EPI_GEGLU if geglu else 0) | (_lib.SEER_EPI_SILU if silu else 0) | \
                  (_lib.SEER_EPI_OUT_F32 if (out.dtype == torch.float32) else 0)
+    if rotary is not None:
+        table, tpb, pos_off, hd, rd, cols = rotary
+        _req(table, torch.float32, "rotary table")
+        assert table.shape[0] >= tpb + pos_off and table.shape[1] * 2 == rd
+        d.epilogue |= _lib.SEER_EPI_ROTARY
+        d.rot_table, d.rot_tokens_per_batch, d.rot_pos_offset = _p(table), tpb, pos_off
+        d.rot_head_dim, d.rot_dim, d.rot_cols = hd, rd, cols
     d.batch = 1
     d.tile = tile
     d.splits = splits

@@ -347,12 +347,12 @@ class _Engine:
         hn = self._gn(x, None, B, Fr * HW, p + ".norm", 1e-6, False)
         h = ops.gemm(hn, w[p + ".proj_in.weight"], bias=w[p + ".proj_in.bias"])
         n1 = ops.layernorm(h, w[tb + ".norm1.weight"], w[tb + ".norm1.bias"])
-        qkv = ops.gemm(n1, w[tb + ".attn1.qkv"])
         F_all = Fr if self.shard is None else self.shard.total_frames
         f_off = 0 if self.shard is None else self.shard.frame_offset
         rot_dim = min(32, d)
         cs = self._rotary_table(tb, F_all * HW)
-        ops.rotary_inplace(qkv, 0, C, heads, d, rot_dim, Fr * HW, cs, pos_offset=f_off * HW)
+        # q|k|v projection with the rotary embedding applied to the q and k columns in the GEMM epilogue
+        qkv = ops.gemm(n1, w[tb + ".attn1.qkv"], rotary=(cs, Fr * HW, f_off * HW, d, rot_dim, 2 * C))
         a = torch.empty_like(h)
         if self.shard is not None:
             self.shard.temporal_attention(ops, qkv, a, B, heads, d, H, W)

@@ -320,6 +320,28 @@ def test_frame_shard_attention(device, d, Fr, H, W, ws, f0, f1):
     assert torch.equal(out, ref), "a frame shard must reproduce the unsharded rows bit for bit"
 
 
+@pytest.mark.parametrize("d,T,off", [(40, 640, 0), (80, 192, 64), (160, 48, 16)])
+def test_gemm_rotary_epilogue(device, d, T, off):
+    """q|k|v projection with rotary fused into the epilogue == projection followed by the rotary kernel"""
+    from seervideoldm_amd import ops
+    B, Hh = 2, 8
+    C = Hh * d
+    x = _rand((B * T, C), device, 1).to(bf16)
+    w = _rand((3 * C, C), device, 2, C ** -0.5).to(bf16)
+    freqs = (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))).to(device)
+    cs = ops.rotary_table(freqs, T + off)
+    fused = ops.gemm(x, w, rotary=(cs, T, off, d, 32, 2 * C))
+    plain32 = ops.gemm(x, w, out_f32=True)
+    # reference: rotate the fp32 projection, round once (what the fused epilogue does)
+    pos = (torch.arange(B * T, device=device) % T) + off
+    c, s = cs[pos, :, 0], cs[pos, :, 1]
+    t = plain32[:, :2 * C].reshape(B * T, 2 * Hh, d)
+    x0, x1 = t[..., :32:2], t[..., 1:32:2]
+    rot = torch.stack([x0 * c[:, None] - x1 * s[:, None], x1 * c[:, None] + x0 * s[:, None]], -1).flatten(-2)
+    ref = torch.cat([torch.cat([rot, t[..., 32:]], -1).reshape(B * T, 2 * C), plain32[:, 2 * C:]], 1)
+    _close(fused, ref, rtol=1e-2, atol=1e-2, what="fused rotary")
+
+
 def test_rotary(device):
     from seervideoldm_amd import ops
     B, T, Hh, d = 2, 640, 8, 40

@@ -42,10 +42,21 @@ def _epilogue(acc, bias, geglu, rowvec, rows_per_batch, silu, residual, out_f32,
 
 
 def gemm(a, w, *, bias=None, residual=None, rowvec=None, rows_per_batch=0, a2=None, geglu=False, silu=False,
-         out_f32=False, out=None, tile=0, splits=0):
+         out_f32=False, out=None, tile=0, splits=0, rotary=None):
     A = a.float() if a2 is None else torch.cat([a.float(), a2.float()], 1)
     assert A.shape[1] % 64 == 0 and w.dtype == bf16 and a.dtype == bf16
-    return _epilogue(A @ w.float().t(), bias, geglu, rowvec, rows_per_batch, silu, residual, out_f32, out)
+    acc = A @ w.float().t()
+    if rotary is not None:
+        table, tpb, pos_off, hd, rd, cols = rotary
+        assert bias is None and residual is None and not geglu
+        rows = acc.shape[0]
+        pos = (torch.arange(rows) % tpb) + pos_off
+        c, s = table[pos, :, 0], table[pos, :, 1]
+        t = acc[:, :cols].reshape(rows, cols // hd, hd)
+        x0, x1 = t[..., :rd:2], t[..., 1:rd:2]
+        rot = torch.stack([x0 * c[:, None] - x1 * s[:, None], x1 * c[:, None] + x0 * s[:, None]], -1).flatten(-2)
+        acc = torch.cat([torch.cat([rot, t[..., rd:]], -1).reshape(rows, cols), acc[:, cols:]], 1)
+    return _epilogue(acc, bias, geglu, rowvec, rows_per_batch, silu, residual, out_f32, out)
 
 
 def gemm_batched(a, w, *, trans_out=False, out=None, bias=None, out_f32=False, tile=0):
