@@ -32,7 +32,8 @@ struct AttnCfg {
     static constexpr int VRS = DV < 96 ? 96 : DV;      // V row stride (elements): 192 B or 320 B
     static constexpr int CH = D / 8;                   // 16-byte chunks per row in global memory
     static constexpr int NCH = (KT * CH + 255) / 256;  // chunks per thread per tile (K or V)
-    static constexpr size_t LDS_BYTES = (size_t)KT * (KRS + VRS) * 2;
+    static constexpr int BUF = KT * (KRS + VRS);          // elements per K|V buffer (two buffers: ping-pong)
+    static constexpr size_t LDS_BYTES = (size_t)2 * BUF * 2;
 };
 
 struct TokMap {
@@ -52,8 +53,7 @@ template <int D>
 __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, const int ws_log2) {
     using C = AttnCfg<D>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bf16* Ks = reinterpret_cast<bf16*>(smem);           // [KT][KRS]
-    bf16* Vs = Ks + KT * C::KRS;                        // [KT][VRS]
+    bf16* const lds = reinterpret_cast<bf16*>(smem);    // 2 x { K [KT][KRS], V [KT][VRS] }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, lh = lane >> 5;
@@ -87,8 +87,9 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
 
     // ---- zero the K pad columns once (D=40: elements 40..47 take part in the contraction)
     if constexpr (C::DP != D) {
-        for (int r = tid; r < KT; r += 256) {
-            *reinterpret_cast<u32x4*>(Ks + r * C::KRS + (C::DP - 8)) = u32x4{0u, 0u, 0u, 0u};
+        for (int r = tid; r < 2 * KT; r += 256) {
+            bf16* kb_ = lds + (r / KT) * C::BUF + (r % KT) * C::KRS + (C::DP - 8);
+            *reinterpret_cast<u32x4*>(kb_) = u32x4{0u, 0u, 0u, 0u};
         }
     }
 
@@ -143,7 +144,9 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
             }
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](int buf) {
+        bf16* Ks = lds + buf * C::BUF;
+        bf16* Vs = Ks + KT * C::KRS;
 #pragma unroll
         for (int i = 0; i < C::NCH; ++i) {
             const int idx = tid + 256 * i;
@@ -155,18 +158,20 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
         }
     };
 
-    if (ntiles > 0) prefetch(0);
+    // ping-pong: tile t is computed from buffer t&1 while tile t+1 travels global -> registers; it is written to the other
+    // buffer after the compute (its last readers passed the previous barrier).  One barrier per tile.
+    prefetch(0);
+    commit(0);
+    __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
-        __syncthreads();          // every wave finished reading the previous tile
-        commit();
-        __syncthreads();
         if (t + 1 < ntiles) prefetch(t + 1);
-        if (!wave_active) continue;
-
+        const bf16* Ks = lds + (t & 1) * C::BUF;
+        const bf16* Vs = Ks + KT * C::KRS;
         const int kt0 = t * KT;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
+            if (!wave_active) continue;
             const int kb = kt0 + sub * 32;                 // first key of this 32-key sub tile
             if (kb >= k_end) continue;
             if (p.causal && kb > q0 + 31 + q_off) continue; // wave-uniform: fully above the diagonal
@@ -184,25 +189,23 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
 
             // ---- scale (+ mask on boundary tiles)
             const bool need_mask = (kb + 31 >= p.Sk) || (p.causal && (kb + 31 > q0 + q_off));
+            // raw scores stay unscaled: max in the raw domain (cscale > 0), then p = exp2(fma(s, cscale, -m)) -- one FMA
+            // and one v_exp per score
             float mx = kNegInf;
             if (need_mask) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     const bool ok = (key < p.Sk) && (!p.causal || key <= qi + q_off);
-                    const float x = ok ? sacc[r] * cscale : kNegInf;
+                    const float x = ok ? sacc[r] : kNegInf;
                     sacc[r] = x;
                     mx = fmaxf(mx, x);
                 }
             } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float x = sacc[r] * cscale;
-                    sacc[r] = x;
-                    mx = fmaxf(mx, x);
-                }
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * cscale;
             const float m_new = fmaxf(m_run, mx);
             const float m_use = (m_new == kNegInf) ? 0.f : m_new;
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);   // m_run == -inf -> 0
@@ -210,15 +213,18 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
             float psum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(sacc[r] - m_use);
+                const float e = __builtin_amdgcn_exp2f(fmaf(sacc[r], cscale, -m_use));
                 sacc[r] = e;
                 psum += e;
             }
             l_run = l_run * alpha + psum;
+            // the running max of most queries stops moving after the first tiles: skip the O rescale when no lane needs it
+            if (!__all(alpha == 1.0f)) {
 #pragma unroll
-            for (int tt = 0; tt < C::NDT; ++tt)
+                for (int tt = 0; tt < C::NDT; ++tt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[tt][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) oacc[tt][r] *= alpha;
+            }
 
             // ---- P^T -> bf16 B fragments (k-step s2 uses accumulator registers 8*s2 .. 8*s2+7)
             bf16x8 pf[2];
@@ -249,6 +255,8 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
                 }
             }
         }
+        if (t + 1 < ntiles) commit((t + 1) & 1);
+        __syncthreads();
     }
 
     // ---- finalize: O[q][d] = O^T[d][q] / l
@@ -278,6 +286,14 @@ int launch_attn(const seer_attn_desc& d, int ws_log2, hipStream_t st) {
     int nbatch = d.batch;
     if (ws_log2 >= 0) nbatch *= (d.H >> ws_log2) * (d.W >> ws_log2);
     dim3 grid((d.Sq + 127) / 128, nbatch * d.heads, 1);
+    if (AttnCfg<D>::LDS_BYTES > 64 * 1024) {
+        static bool done = false;      // opt in to > 64 KiB dynamic LDS once per head dim
+        if (!done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_attn_kernel<D>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)AttnCfg<D>::LDS_BYTES);
+            done = true;
+        }
+    }
     hipLaunchKernelGGL((seer_attn_kernel<D>), grid, dim3(256), AttnCfg<D>::LDS_BYTES, st, d, ws_log2);
     SEER_LAUNCH_CHECK();
     return SEER_OK;
