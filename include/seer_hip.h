@@ -99,10 +99,6 @@ typedef struct seer_gemm_desc {
 #define SEER_TILE_G64x64_4 9
 #define SEER_TILE_G64x64_5 10
 #define SEER_TILE_G128x64_4 11
-/* same, with the LDS-direct pieces interleaved between the MFMAs */
-#define SEER_TILE_I128x128_2 12
-#define SEER_TILE_I128x64_3 13
-#define SEER_TILE_I64x64_3 14
 
 int seer_gemm_bf16(const seer_gemm_desc* desc /* host */, void* stream);
 /* bytes of workspace the call would use for split-K with this descriptor (0: it will not split) */

@@ -16,6 +16,7 @@
 // LDS images: K rows padded to an odd number of 16-byte chunks (conflict-free ds_read_b128 by key row);
 //             V row stride == 64 or 192 (mod 256) bytes (conflict-free transposed reads of 4 key rows).
 #include "seer_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -49,8 +50,12 @@ struct TokMap {
     }
 };
 
-template <int D>
-__global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, const int ws_log2) {
+// DBUF: ping-pong K|V LDS buffers (one barrier per tile) vs one buffer (two barriers, half the LDS).
+// defer_thr: the running max of a query is only raised when a tile's max exceeds it by more than defer_thr (log2 units), so
+//            p <= 2^defer_thr instead of <= 1 and the O rescale (skipped when no lane moved its max) becomes rare; bf16 P keeps
+//            its relative precision at any magnitude and l/O accumulate in fp32, so the result is unchanged to rounding.
+template <int D, bool DBUF>
+__global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, const int ws_log2, const float defer_thr) {
     using C = AttnCfg<D>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16* const lds = reinterpret_cast<bf16*>(smem);    // 2 x { K [KT][KRS], V [KT][VRS] }
@@ -87,7 +92,7 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
 
     // ---- zero the K pad columns once (D=40: elements 40..47 take part in the contraction)
     if constexpr (C::DP != D) {
-        for (int r = tid; r < 2 * KT; r += 256) {
+        for (int r = tid; r < (DBUF ? 2 : 1) * KT; r += 256) {
             bf16* kb_ = lds + (r / KT) * C::BUF + (r % KT) * C::KRS + (C::DP - 8);
             *reinterpret_cast<u32x4*>(kb_) = u32x4{0u, 0u, 0u, 0u};
         }
@@ -161,12 +166,19 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
     // ping-pong: tile t is computed from buffer t&1 while tile t+1 travels global -> registers; it is written to the other
     // buffer after the compute (its last readers passed the previous barrier).  One barrier per tile.
     prefetch(0);
-    commit(0);
-    __syncthreads();
+    if constexpr (DBUF) {
+        commit(0);
+        __syncthreads();
+    }
 
     for (int t = 0; t < ntiles; ++t) {
+        if constexpr (!DBUF) {
+            __syncthreads();          // every wave finished reading the previous tile
+            commit(0);
+            __syncthreads();
+        }
         if (t + 1 < ntiles) prefetch(t + 1);
-        const bf16* Ks = lds + (t & 1) * C::BUF;
+        const bf16* Ks = lds + (DBUF ? (t & 1) : 0) * C::BUF;
         const bf16* Vs = Ks + KT * C::KRS;
         const int kt0 = t * KT;
 #pragma unroll
@@ -206,7 +218,7 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * cscale;
-            const float m_new = fmaxf(m_run, mx);
+            const float m_new = (mx > m_run + defer_thr) ? mx : m_run;
             const float m_use = (m_new == kNegInf) ? 0.f : m_new;
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);   // m_run == -inf -> 0
             m_run = m_new;
@@ -255,8 +267,10 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
                 }
             }
         }
-        if (t + 1 < ntiles) commit((t + 1) & 1);
-        __syncthreads();
+        if constexpr (DBUF) {
+            if (t + 1 < ntiles) commit((t + 1) & 1);
+            __syncthreads();
+        }
     }
 
     // ---- finalize: O[q][d] = O^T[d][q] / l
@@ -281,22 +295,31 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
     }
 }
 
-template <int D>
-int launch_attn(const seer_attn_desc& d, int ws_log2, hipStream_t st) {
+template <int D, bool DBUF>
+int launch_attn2(const seer_attn_desc& d, int ws_log2, float thr, hipStream_t st) {
     int nbatch = d.batch;
     if (ws_log2 >= 0) nbatch *= (d.H >> ws_log2) * (d.W >> ws_log2);
     dim3 grid((d.Sq + 127) / 128, nbatch * d.heads, 1);
-    if (AttnCfg<D>::LDS_BYTES > 64 * 1024) {
-        static bool done = false;      // opt in to > 64 KiB dynamic LDS once per head dim
+    constexpr size_t lds = AttnCfg<D>::LDS_BYTES / (DBUF ? 1 : 2);
+    if (lds > 64 * 1024) {
+        static bool done = false;      // opt in to > 64 KiB dynamic LDS once per instantiation
         if (!done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_attn_kernel<D>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)AttnCfg<D>::LDS_BYTES);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_attn_kernel<D, DBUF>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             done = true;
         }
     }
-    hipLaunchKernelGGL((seer_attn_kernel<D>), grid, dim3(256), AttnCfg<D>::LDS_BYTES, st, d, ws_log2);
+    hipLaunchKernelGGL((seer_attn_kernel<D, DBUF>), grid, dim3(256), lds, st, d, ws_log2, thr);
     SEER_LAUNCH_CHECK();
     return SEER_OK;
+}
+
+// tuning knobs (A/B on one device): SEER_ATTN_DBUF=0|1, SEER_ATTN_DEFER=<log2 threshold>
+template <int D>
+int launch_attn(const seer_attn_desc& d, int ws_log2, hipStream_t st) {
+    static const int dbuf = [] { const char* e = getenv("SEER_ATTN_DBUF"); return e ? atoi(e) : (D >= 160 ? 0 : 1); }();
+    static const float thr = [] { const char* e = getenv("SEER_ATTN_DEFER"); return e ? (float)atof(e) : 4.0f; }();
+    return dbuf ? launch_attn2<D, true>(d, ws_log2, thr, st) : launch_attn2<D, false>(d, ws_log2, thr, st);
 }
 
 }  // namespace

@@ -44,9 +44,7 @@ def _close(got, ref, rtol=2e-2, atol=2e-2, what=""):
     # LDS-direct (global_load_lds) multi-stage variants: tile codes 5..9
     (256, 128, 64, 5), (512, 256, 1280, 5), (512, 256, 1280, 6), (130, 68, 192, 7), (1536, 1280, 1280, 7),
     (100, 64, 128, 8), (384, 320, 2560, 8), (384, 320, 2560, 9), (1848, 640, 768, 9), (6144, 640, 128, 9),
-    # deeper rings (10, 11) and the interleaved issue order (12..14); K = 64 / 128 exercise the zero-page tail pieces
-    (384, 320, 2560, 10), (1536, 1280, 1280, 11), (256, 128, 64, 12), (512, 256, 1280, 12), (130, 68, 192, 13),
-    (1536, 1280, 1280, 13), (100, 64, 64, 14), (1848, 640, 768, 14), (6144, 640, 128, 14),
+    (384, 320, 2560, 10), (1536, 1280, 1280, 11),      # deeper rings
 ])
 def test_gemm_plain(device, M, N, K, tile):
     from seervideoldm_amd import ops
@@ -178,7 +176,7 @@ def test_gemm_batched_and_transposed(device):
     (2, 8, 8, 64, 64, 1, True), (24, 32, 32, 320, 320, 1, False), (4, 4, 4, 1280, 1280, 1, False),
     (2, 6, 10, 64, 68, 1, False),
 ])
-@pytest.mark.parametrize("tile", [0, 7, 9, 12, 13, 14])
+@pytest.mark.parametrize("tile", [0, 7, 9])
 def test_conv3x3(device, n_img, H, W, Ci, Co, stride, up, tile):
     from seervideoldm_amd import ops
     from seervideoldm_amd.weights import pack_conv3x3
