@@ -317,7 +317,9 @@ int launch_attn2(const seer_attn_desc& d, int ws_log2, float thr, hipStream_t st
 // tuning knobs (A/B on one device): SEER_ATTN_DBUF=0|1, SEER_ATTN_DEFER=<log2 threshold>
 template <int D>
 int launch_attn(const seer_attn_desc& d, int ws_log2, hipStream_t st) {
-    static const int dbuf = [] { const char* e = getenv("SEER_ATTN_DBUF"); return e ? atoi(e) : (D >= 160 ? 0 : 1); }();
+    // measured on one MI355X (profiles/r01_attention_ab.log): deferred max +7-8 %; ping-pong LDS within noise (the kernel is
+    // VALU-bound at d=40, not barrier-bound) -> single buffer (half the LDS), threshold 4
+    static const int dbuf = [] { const char* e = getenv("SEER_ATTN_DBUF"); return e ? atoi(e) : 0; }();
     static const float thr = [] { const char* e = getenv("SEER_ATTN_DEFER"); return e ? (float)atof(e) : 4.0f; }();
     return dbuf ? launch_attn2<D, true>(d, ws_log2, thr, st) : launch_attn2<D, false>(d, ws_log2, thr, st);
 }

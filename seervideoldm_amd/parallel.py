@@ -44,6 +44,7 @@ class FrameShard:
         self._pgs = {}
         self.G = self.P = None
         self.total_frames = self.frame_offset = self.local_frames = 0
+        self.debug_boundaries = False   # tests: hit every sync point (with a no-op exchange) even when P == 1
 
     # ---- geometry --------------------------------------------------------------------------------------------
     def plan(self, B: int, F: int):
@@ -76,36 +77,59 @@ class FrameShard:
         return f"batch_groups{self.G}xframe_shards{self.P}" if self.G else "unplanned"
 
     # ---- hooks used by unet._Engine ----------------------------------------------------------------------------
-    def reduce_gn_stats(self, stats: torch.Tensor, count_local: float) -> float:
+    def reduce_gn_stats(self, stats: torch.Tensor, count_local: float, sync=None) -> float:
+        """all-reduce the (sum, sumsq) statistics of one GroupNorm over the frame group; `sync` is the engine's
+        sync_point (the exchange is an eager collective between two hipGraph segments)."""
+        run = sync if sync is not None else (lambda fn: fn())
         if self.P > 1:
-            dist.all_reduce(stats, group=self.frame_group())
+            grp = self.frame_group()
+            run(lambda: dist.all_reduce(stats, group=grp))
+        elif self.debug_boundaries:
+            run(lambda: None)
         return count_local / self.local_frames * self.total_frames
 
     def local_cond_frames(self, cond_frame: int) -> int:
         return max(0, min(self.local_frames, cond_frame - self.frame_offset))
 
-    def _gather_frames(self, x: torch.Tensor, B: int, rows_per_frame: int) -> torch.Tensor:
-        """x [B*F_local*rows_per_frame, C] of this rank -> [B*F_total*rows_per_frame, C] in global frame order"""
+    def _gather_frames(self, x: torch.Tensor, B: int, rows_per_frame: int, sync=None) -> torch.Tensor:
+        """x [B*F_local*rows_per_frame, C] of this rank -> [B*F_total*rows_per_frame, C] in global frame order.
+        The result lives in a buffer allocated here (static under graph capture); the exchange itself runs through `sync`."""
+        run = sync if sync is not None else (lambda fn: fn())
         if self.P == 1:
+            if self.debug_boundaries:
+                run(lambda: None)
             return x
         C = x.shape[1]
         fmax = max(self.frame_counts)
-        send = x.reshape(B, self.local_frames * rows_per_frame, C)
-        if self.local_frames != fmax:
-            pad = torch.zeros((B, (fmax - self.local_frames) * rows_per_frame, C), device=x.device, dtype=x.dtype)
-            send = torch.cat([send, pad], 1)
-        send = send.contiguous()
+        rows_l = self.local_frames * rows_per_frame
+        even = all(c == fmax for c in self.frame_counts)
+        grp = self.frame_group()
+        out = torch.empty((B * self.total_frames * rows_per_frame, C), device=x.device, dtype=x.dtype)
+        if even and B == 1:
+            # [P][F_l*rows, C] in rank order IS the global frame order: gather straight into the output
+            run(lambda: dist.all_gather_into_tensor(out, x, group=grp))
+            return out
+        send = torch.zeros((B, fmax * rows_per_frame, C), device=x.device, dtype=x.dtype)
+        send[:, :rows_l] = x.reshape(B, rows_l, C)
         recv = [torch.empty_like(send) for _ in range(self.P)]
-        dist.all_gather(recv, send, group=self.frame_group())
-        parts = [recv[i][:, : self.frame_counts[i] * rows_per_frame] for i in range(self.P)]
-        return torch.cat(parts, 1).reshape(B * self.total_frames * rows_per_frame, C)
+        outv = out.reshape(B, self.total_frames * rows_per_frame, C)
+        starts, counts = self.frame_starts, self.frame_counts
 
-    def temporal_attention(self, ops, qkv: torch.Tensor, out: torch.Tensor, B: int, heads: int, d: int, H: int, W: int):
+        def exchange():
+            dist.all_gather(recv, send, group=grp)
+            for i in range(self.P):
+                n = counts[i] * rows_per_frame
+                outv[:, starts[i] * rows_per_frame: starts[i] * rows_per_frame + n] = recv[i][:, :n]
+        run(exchange)
+        return out
+
+    def temporal_attention(self, ops, qkv: torch.Tensor, out: torch.Tensor, B: int, heads: int, d: int, H: int, W: int,
+                           sync=None):
         """causal (window) attention of the local frames' queries over the gathered K|V of frames [0, F_total)."""
         C = heads * d
         HW = H * W
         Fl, Ft, f0 = self.local_frames, self.total_frames, self.frame_offset
-        kv = self._gather_frames(qkv[:, C:].contiguous(), B, HW)             # [B*Ft*HW, 2C]
+        kv = self._gather_frames(qkv[:, C:].contiguous(), B, HW, sync=sync)   # [B*Ft*HW, 2C]
         if H > MIN_WIN_SIZE:
             ws = MAX_WIN_SIZE if (H // MAX_WIN_SIZE) >= MAX_RATIO else MIN_WIN_SIZE
             ops.attention(qkv[:, :C], kv[:, :C], kv[:, C:], out, batch=B, heads=heads, head_dim=d, Sq=Fl * ws * ws,

@@ -176,7 +176,7 @@ class SeerUNet(nn.Module):
         if self._ctx_slice is None or self._ctx_slice[0] != key:
             self._ctx_slice = (key, context[b0:b1, f0:f1].contiguous())
         local = self._engine.run(sample[b0:b1, :, f0:f1].float().contiguous(), t[b0:b1].contiguous(),
-                                 self._ctx_slice[1], int(cond_frame), use_graph=False)
+                                 self._ctx_slice[1], int(cond_frame), use_graph=self.use_graph)
         return sh.gather_output(local, B, Fr).to(sample.dtype)
 
 
@@ -202,6 +202,7 @@ class _Engine:
         self._kv_cache: Dict[str, torch.Tensor] = {}
         self._kv_key = None
         self._graphs: Dict[Tuple, object] = {}
+        self._rec = None                # _SegmentRecorder while a segmented capture is running
 
     # ---- weight packing ---------------------------------------------------------------------------------------
     def _pack(self, sd):
@@ -264,7 +265,7 @@ class _Engine:
         C = x1.shape[1] + (0 if x2 is None else x2.shape[1])
         count = rows_pb * (C // self.G)
         if self.shard is not None:
-            count = self.shard.reduce_gn_stats(stats, count)
+            count = self.shard.reduce_gn_stats(stats, count, sync=self.sync_point)
         return ops.groupnorm_apply(x1, x2, B, self.G, stats, count, eps, self.w[name + ".weight"],
                                    self.w[name + ".bias"], silu)
 
@@ -355,7 +356,7 @@ class _Engine:
         qkv = ops.gemm(n1, w[tb + ".attn1.qkv"], rotary=(cs, Fr * HW, f_off * HW, d, rot_dim, 2 * C))
         a = torch.empty_like(h)
         if self.shard is not None:
-            self.shard.temporal_attention(ops, qkv, a, B, heads, d, H, W)
+            self.shard.temporal_attention(ops, qkv, a, B, heads, d, H, W, sync=self.sync_point)
         else:
             if H > MIN_WIN_SIZE:
                 ws = MAX_WIN_SIZE if (H // MAX_WIN_SIZE) >= MAX_RATIO else MIN_WIN_SIZE
@@ -447,28 +448,92 @@ class _Engine:
         if H % 8 or W % 8:
             raise ValueError("latent height/width must be multiples of 8 (three stride-2 levels + 4/8 windows)")
         ctx, L = self._context(context)
-        if not use_graph:
+        if not use_graph or getattr(self, "_graph_broken", False):
             return self._forward(sample, t, ctx, L, cond_frame)
         return self._run_graph(sample, t, ctx, L, cond_frame)
 
+    def sync_point(self, fn):
+        """run `fn` -- an EAGER cross-rank exchange (RCCL all-reduce / all-gather on static buffers) -- at this point of the
+        schedule.  Under segmented capture it ends the current hipGraph segment, records `fn` as a replay step and opens
+        the next segment, so the collectives never have to be captured themselves."""
+        rec = self._rec
+        if rec is None:
+            fn()
+            return
+        rec.end_segment()
+        fn()
+        rec.steps.append(fn)
+        rec.begin_segment()
+
     def _run_graph(self, sample, t, ctx, L, cond_frame):
-        """hipGraph replay of the shape-static step (~1.3k launches -> one graph launch)."""
+        """hipGraph replay of the shape-static step: ~1.3k launches -> one graph launch, or -- frame-sharded -- one graph
+        launch per stretch between two collectives (GroupNorm statistics / K|V exchanges stay eager torch.distributed
+        calls on the same stream)."""
         key = (tuple(sample.shape), L, cond_frame, self._kv_key)
         g = self._graphs.get(key)
         if g is None:
-            # warm up eagerly (fills the K/V and rotary caches, lets allocations settle), then capture
+            # warm up eagerly (fills the K/V and rotary caches, creates process groups, lets allocations settle), then capture
             s_in, t_in = sample.clone(), t.clone()
             self._forward(s_in, t_in, ctx, L, cond_frame)
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            rec = _SegmentRecorder()
+            self._rec = rec
+            try:
+                rec.begin_segment()
                 out = self._forward(s_in, t_in, ctx, L, cond_frame)
-            g = (graph, s_in, t_in, out)
+                rec.end_segment()
+            except Exception as e:                       # capture refused (driver / RCCL state): stay correct, run eagerly
+                rec.abort()
+                self._rec = None
+                self._graph_broken = True
+                import warnings
+                warnings.warn(f"hipGraph capture of the denoising step failed ({type(e).__name__}: {e}); running eagerly")
+                return self._forward(sample, t, ctx, L, cond_frame)
+            finally:
+                self._rec = None
+            g = (rec, s_in, t_in, out)
             if len(self._graphs) > 4:
                 self._graphs.clear()
             self._graphs[key] = g
-        graph, s_in, t_in, out = g
+        rec, s_in, t_in, out = g
         s_in.copy_(sample)
         t_in.copy_(t)
-        graph.replay()
+        for step in rec.steps:
+            step()
         return out
+
+
+class _SegmentRecorder:
+    """a step = a list of hipGraph segments (sharing one memory pool) interleaved with eager callables"""
+
+    def __init__(self):
+        self.steps = []
+        self.pool = torch.cuda.graph_pool_handle()
+        self._cur = None
+
+    def begin_segment(self):
+        g = torch.cuda.CUDAGraph()
+        # thread_local: an RCCL watchdog thread polling its events must not invalidate this thread's capture
+        ctx = torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local")
+        ctx.__enter__()
+        self._cur = (g, ctx)
+
+    def end_segment(self):
+        g, ctx = self._cur
+        self._cur = None
+        ctx.__exit__(None, None, None)
+        self.steps.append(g.replay)
+
+    def abort(self):
+        if self._cur is not None:
+            g, ctx = self._cur
+            self._cur = None
+            try:
+                ctx.__exit__(None, None, None)
+            except Exception:
+                pass
+        self.steps = []
+
+    @property
+    def n_segments(self):
+        return sum(1 for s in self.steps if getattr(s, "__self__", None).__class__ is torch.cuda.CUDAGraph)

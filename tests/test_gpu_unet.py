@@ -84,6 +84,31 @@ def test_unet_forward_matches_oracle(device, cfg_name, B, Fr, H, cond_frame):
     assert torch.equal(g1, got) and torch.equal(g2, got), "hipGraph replay must reproduce the eager launches bit for bit"
 
 
+def test_segmented_graph_replay(device):
+    """the frame-sharded step replays as hipGraph SEGMENTS with eager exchanges between them; exercised on one GPU by a
+    1-rank shard that hits every sync point with a no-op exchange: same bits as the eager step, one segment per stretch."""
+    from seervideoldm_amd import parallel
+    cfg, sd, m = _model("mini", device)
+    x = _randn((2, 4, 3, 16, 16), 11).to(device)
+    ctx = _randn((2, 3, 77, cfg["cross_attention_dim"]), 12).to(device)
+    t = torch.tensor([301, 301], device=device)
+    ref = m(x, t, ctx).clone()
+    shard = parallel.attach(m, 1, 0)
+    shard.debug_boundaries = True
+    try:
+        m.use_graph = True
+        g1 = m(x, t, ctx).clone()
+        g2 = m(x, t, ctx).clone()
+        rec = next(iter(m._engine._graphs.values()))[0]
+        n_gn, n_temporal = m._engine.n_groupnorms(), 3 + 1 + 6       # lpb=1: 3 down + mid + 3x2 up temporal blocks
+        assert rec.n_segments == n_gn + n_temporal + 1, (rec.n_segments, n_gn, n_temporal)
+    finally:
+        m.use_graph = False
+        m._shard = None
+        m._engine = None
+    assert torch.equal(g1, ref) and torch.equal(g2, ref)
+
+
 def test_groupnorm_couples_frames(device):
     """SURVEY finding 3: perturbing only the last frame changes frame 0 (GroupNorm statistics span frames)."""
     cfg, sd, m = _model("mini", device)
