@@ -99,6 +99,9 @@ typedef struct seer_gemm_desc {
 #define SEER_TILE_G64x64_4 9
 #define SEER_TILE_G64x64_5 10
 #define SEER_TILE_G128x64_4 11
+/* 160-wide tiles: N = 320 / 640 (C of the two upper levels) in 2 / 4 column tiles instead of 5 / 10 */
+#define SEER_TILE_G128x160_2 12
+#define SEER_TILE_G64x160_3 13
 
 int seer_gemm_bf16(const seer_gemm_desc* desc /* host */, void* stream);
 /* bytes of workspace the call would use for split-K with this descriptor (0: it will not split) */

@@ -15,7 +15,8 @@ bf16 = torch.bfloat16
 dev = torch.device("cuda:0")
 
 
-TILES = ((0, "auto"), (5, "g128x128/2"), (7, "g128x64/3"), (2, "64x64"), (8, "g64x64/3"))
+TILES = ((0, "auto"), (5, "g128x128/2"), (7, "g128x64/3"), (12, "g128x160/2"), (13, "g64x160/3"), (2, "64x64"),
+         (8, "g64x64/3"))
 
 
 def timeit(fn, iters=20, warmup=3):

@@ -431,14 +431,16 @@ int launch_tile(const seer_gemm_desc& d, hipStream_t st) {
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, 1, d.batch > 1 ? d.batch : 1);
     const size_t lds = (size_t)(NS == 0 ? 2 : NS) * (BM + BN) * BK * sizeof(bf16);
+    constexpr bool GEGLU_OK = ((BN / 32) % 2) == 0;      // value / gate n-tile pairs must sit in one wave
     if (lds > 64 * 1024) {
         // above the default dynamic-LDS limit: opt in once per instantiation (160 KiB per CU on gfx950)
         static bool done = false;
         if (!done) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, true, false, false, NS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, false, true, false, NS>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if constexpr (GEGLU_OK)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, false, true, false, NS>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, false, false, false, NS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             done = true;
@@ -450,7 +452,10 @@ int launch_tile(const seer_gemm_desc& d, hipStream_t st) {
     if (conv) {
         hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, true, false, false, NS>), grid, dim3(256), lds, st, d);
     } else if (geglu) {
-        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, true, false, NS>), grid, dim3(256), lds, st, d);
+        if constexpr (GEGLU_OK)
+            hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, true, false, NS>), grid, dim3(256), lds, st, d);
+        else
+            return SEER_EINVAL;
     } else {
         hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, false, false, NS>), grid, dim3(256), lds, st, d);
     }
@@ -578,6 +583,8 @@ extern "C" int seer_gemm_bf16(const seer_gemm_desc* desc, void* stream) {
         case SEER_TILE_G64x64_4: return launch_tile<64, 64, 4>(d, st);
         case SEER_TILE_G64x64_5: return launch_tile<64, 64, 5>(d, st);
         case SEER_TILE_G128x64_4: return launch_tile<128, 64, 4>(d, st);
+        case SEER_TILE_G128x160_2: return launch_tile<128, 160, 2>(d, st);
+        case SEER_TILE_G64x160_3: return launch_tile<64, 160, 3>(d, st);
         default: return SEER_EINVAL;
     }
 }

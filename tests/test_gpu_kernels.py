@@ -45,6 +45,7 @@ def _close(got, ref, rtol=2e-2, atol=2e-2, what=""):
     (256, 128, 64, 5), (512, 256, 1280, 5), (512, 256, 1280, 6), (130, 68, 192, 7), (1536, 1280, 1280, 7),
     (100, 64, 128, 8), (384, 320, 2560, 8), (384, 320, 2560, 9), (1848, 640, 768, 9), (6144, 640, 128, 9),
     (384, 320, 2560, 10), (1536, 1280, 1280, 11),      # deeper rings
+    (384, 320, 320, 12), (6144, 640, 640, 12), (130, 68, 192, 12), (384, 320, 2560, 13), (1000, 640, 128, 13),   # 160-wide
 ])
 def test_gemm_plain(device, M, N, K, tile):
     from seervideoldm_amd import ops
@@ -176,7 +177,7 @@ def test_gemm_batched_and_transposed(device):
     (2, 8, 8, 64, 64, 1, True), (24, 32, 32, 320, 320, 1, False), (4, 4, 4, 1280, 1280, 1, False),
     (2, 6, 10, 64, 68, 1, False),
 ])
-@pytest.mark.parametrize("tile", [0, 7, 9])
+@pytest.mark.parametrize("tile", [0, 7, 9, 12, 13])
 def test_conv3x3(device, n_img, H, W, Ci, Co, stride, up, tile):
     from seervideoldm_amd import ops
     from seervideoldm_amd.weights import pack_conv3x3
