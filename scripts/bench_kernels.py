@@ -47,7 +47,11 @@ def bench_gemm():
         out = torch.empty((M, N // 2 if geglu else N), device=dev, dtype=bf16)
         line = f"gemm M{M} N{N} K{K} geglu={int(geglu)}:"
         for tile, name in TILES:
-            t = timeit(lambda: ops.gemm(a, w, bias=bias, geglu=geglu, out=out, tile=tile, splits=(0 if tile == 0 else 1)))
+            try:
+                t = timeit(lambda: ops.gemm(a, w, bias=bias, geglu=geglu, out=out, tile=tile, splits=(0 if tile == 0 else 1)))
+            except Exception:
+                line += f"  {name}   n/a |"
+                continue
             line += f"  {name} {2 * M * N * K / t / 1e12:5.0f}TF {t * 1e6:6.1f}us |"
         print(line, flush=True)
 
