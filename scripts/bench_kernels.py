@@ -102,6 +102,38 @@ def bench_split():
         print(line, flush=True)
 
 
+def bench_split2():
+    """split-K x tile sweep on the M = 1536 shapes (8x8 level): 64x64 vs 128x128 tiles under K slicing"""
+    convs = [(24, 8, 8, 1280, 1280, 1), (24, 8, 8, 2560, 1280, 1), (24, 8, 8, 1920, 1280, 1), (24, 8, 8, 640, 1280, 1)]
+    for n, H, W, Ci, Co, st in convs:
+        x = torch.randn(n * H * W, Ci, device=dev).to(bf16)
+        w = (torch.randn(Co, 9 * Ci, device=dev) * (9 * Ci) ** -0.5).to(bf16)
+        bias = torch.randn(Co, device=dev)
+        line = f"conv n{n} {H}x{W} {Ci}->{Co}:"
+        t = timeit(lambda: ops.conv3x3(x, w, n, H, W, stride=st, bias=bias))
+        line += f"  auto {t * 1e6:6.1f}us |"
+        for tile, name in ((8, "g64"), (5, "g128")):
+            for s in (1, 2, 4, 6, 8):
+                t = timeit(lambda: ops.conv3x3(x, w, n, H, W, stride=st, bias=bias, splits=s, tile=tile))
+                line += f" {name}/s{s} {t * 1e6:6.1f}"
+            line += " |"
+        print(line, flush=True)
+    gemms = [(1536, 1280, 5120), (1536, 1280, 2560), (1536, 1280, 1280)]
+    for M, N, K in gemms:
+        a = torch.randn(M, K, device=dev).to(bf16)
+        w = (torch.randn(N, K, device=dev) * K ** -0.5).to(bf16)
+        bias = torch.randn(N, device=dev)
+        line = f"gemm M{M} N{N} K{K}:"
+        t = timeit(lambda: ops.gemm(a, w, bias=bias))
+        line += f"  auto {t * 1e6:6.1f}us |"
+        for tile, name in ((8, "g64"), (5, "g128")):
+            for s in (1, 2, 4, 8):
+                t = timeit(lambda: ops.gemm(a, w, bias=bias, splits=s, tile=tile))
+                line += f" {name}/s{s} {t * 1e6:6.1f}"
+            line += " |"
+        print(line, flush=True)
+
+
 def bench_attn():
     cases = [  # name, batch, S_q, S_k, d, causal, window
         ("spatial L0", 24, 1024, 1024, 40, False, None), ("spatial L1", 24, 256, 256, 80, False, None),
@@ -150,6 +182,8 @@ if __name__ == "__main__":
         bench_conv()
     if what in ("split", "all"):
         bench_split()
+    if what in ("split2",):
+        bench_split2()
     if what in ("attn", "all"):
         bench_attn()
     if what in ("norm", "all"):

@@ -463,24 +463,30 @@ int launch_tile(const seer_gemm_desc& d, hipStream_t st) {
     return SEER_OK;
 }
 
-int launch_split(const seer_gemm_desc& d, hipStream_t st) {
-    constexpr int BM = 64, BN = 64, NS = 3;
+template <int BM, int BN, int NS>
+int launch_split_tile(const seer_gemm_desc& d, hipStream_t st) {
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, 1, d.splits);
-    const bool reg = d.tile == SEER_TILE_64x64;       // explicit 64x64 request keeps the register-staged loop (A/B testing)
-    const size_t lds = (size_t)(reg ? 2 : NS) * (BM + BN) * BK * sizeof(bf16);
-    if (d.mode == SEER_GEMM_CONV3X3) {
-        if (reg) hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, true, false, true, 0>), grid, dim3(256), lds, st, d);
-        else hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, true, false, true, NS>), grid, dim3(256), lds, st, d);
-    } else {
-        if (reg) hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, false, true, 0>), grid, dim3(256), lds, st, d);
-        else hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, false, true, NS>), grid, dim3(256), lds, st, d);
-    }
+    const size_t lds = (size_t)(NS == 0 ? 2 : NS) * (BM + BN) * BK * sizeof(bf16);
+    if (d.mode == SEER_GEMM_CONV3X3)
+        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, true, false, true, NS>), grid, dim3(256), lds, st, d);
+    else
+        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, false, true, NS>), grid, dim3(256), lds, st, d);
     SEER_LAUNCH_CHECK();
     const int64_t n = (int64_t)d.M * (d.N / 4);
     hipLaunchKernelGGL(seer_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d);
     SEER_LAUNCH_CHECK();
     return SEER_OK;
+}
+
+int launch_split(const seer_gemm_desc& d, hipStream_t st) {
+    if (d.tile == SEER_TILE_64x64) return launch_split_tile<64, 64, 0>(d, st);        // register-staged (A/B testing)
+    if (d.tile == SEER_TILE_G64x64_3) return launch_split_tile<64, 64, 3>(d, st);
+    if (d.tile == SEER_TILE_G128x128_2) return launch_split_tile<128, 128, 2>(d, st);
+    // auto: the 8x8-level convs (M = 1536, N = 1280) have enough rows for 128x128 tiles once K is sliced 4 ways
+    // (0.5x the L2->LDS traffic per FLOP of 64x64); the 4x4 level (M = 384) keeps 64x64
+    if (d.M >= 1024 && d.N >= 1024 && d.N % 128 == 0) return launch_split_tile<128, 128, 2>(d, st);
+    return launch_split_tile<64, 64, 3>(d, st);
 }
 
 // validate + normalise a descriptor; returns SEER_OK and the number of K slices the call will use in *splits
@@ -515,7 +521,8 @@ int prepare(seer_gemm_desc& d, int* splits) {
     // split-K decision: few output tiles and a long K loop (deep-level convs / linears, M = 384 .. 1536)
     int s = 1;
     const bool can_split = d.batch == 1 && !geglu && !(d.epilogue & (SEER_EPI_TRANS_OUT | SEER_EPI_ROTARY)) &&
-                           (d.tile == SEER_TILE_AUTO || d.tile == SEER_TILE_64x64 || d.tile == SEER_TILE_G64x64_3) &&
+                           (d.tile == SEER_TILE_AUTO || d.tile == SEER_TILE_64x64 || d.tile == SEER_TILE_G64x64_3 ||
+                            d.tile == SEER_TILE_G128x128_2) &&
                            d.splits != 1;
     if (can_split) {
         const int nk = d.K / BK;
