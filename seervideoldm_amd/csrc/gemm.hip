@@ -533,7 +533,7 @@ int prepare(seer_gemm_desc& d, int* splits) {
             // splitting pays only when a slice still has >= 10 K tiles and the unsplit grid leaves most CUs idle
             const long blocks = (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
             if (blocks <= 160 && nk >= 40) s = nk / 10 < 8 ? nk / 10 : 8;
-            else if (blocks <= 512 && nk >= 160) s = 4;
+            else if (blocks <= 512 && nk >= 80) s = 4;      // M = 1536: 128x128 tiles x 4 K slices (profiles/r01_splitk_tile_sweep.log)
         }
     }
     *splits = s;
