@@ -485,7 +485,7 @@ int launch_split(const seer_gemm_desc& d, hipStream_t st) {
     if (d.tile == SEER_TILE_G128x128_2) return launch_split_tile<128, 128, 2>(d, st);
     // auto: the 8x8-level convs (M = 1536, N = 1280) have enough rows for 128x128 tiles once K is sliced 4 ways
     // (0.5x the L2->LDS traffic per FLOP of 64x64); the 4x4 level (M = 384) keeps 64x64
-    if (d.M >= 1024 && d.N >= 1024 && d.N % 128 == 0) return launch_split_tile<128, 128, 2>(d, st);
+    if ((d.M >= 1024 || d.splits >= 12) && d.N >= 1024 && d.N % 128 == 0) return launch_split_tile<128, 128, 2>(d, st);
     return launch_split_tile<64, 64, 3>(d, st);
 }
 
@@ -532,7 +532,8 @@ int prepare(seer_gemm_desc& d, int* splits) {
             // measured on MI355X (profiles/r01_splitk_sweep.log): the reduce pass + second launch cost ~4-5 us, so
             // splitting pays only when a slice still has >= 10 K tiles and the unsplit grid leaves most CUs idle
             const long blocks = (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
-            if (blocks <= 160 && nk >= 40) s = nk / 10 < 8 ? nk / 10 : 8;
+            if (blocks <= 160 && nk >= 160) s = 16;            // 4x4 level convs: 128x128 tiles x 16 slices (r01_splitk_m384_sweep.log)
+            else if (blocks <= 160 && nk >= 40) s = nk / 20 < 8 ? nk / 20 : 8;
             else if (blocks <= 512 && nk >= 80) s = 4;      // M = 1536: 128x128 tiles x 4 K slices (profiles/r01_splitk_tile_sweep.log)
         }
     }
