@@ -102,6 +102,9 @@ typedef struct seer_gemm_desc {
 /* 160-wide tiles: N = 320 / 640 (C of the two upper levels) in 2 / 4 column tiles instead of 5 / 10 */
 #define SEER_TILE_G128x160_2 12
 #define SEER_TILE_G64x160_3 13
+/* 8 waves (4 x 2), 256-row tiles */
+#define SEER_TILE_G256x128_2 14
+#define SEER_TILE_G256x64_3 15
 
 int seer_gemm_bf16(const seer_gemm_desc* desc /* host */, void* stream);
 /* bytes of workspace the call would use for split-K with this descriptor (0: it will not split) */

@@ -15,7 +15,7 @@ bf16 = torch.bfloat16
 dev = torch.device("cuda:0")
 
 
-TILES = ((0, "auto"), (5, "g128x128/2"), (7, "g128x64/3"), (12, "g128x160/2"), (13, "g64x160/3"), (2, "64x64"),
+TILES = ((0, "auto"), (5, "g128x128/2"), (14, "g256x128/2"), (7, "g128x64/3"), (15, "g256x64/3"), (12, "g128x160/2"),
          (8, "g64x64/3"))
 
 

@@ -24,11 +24,15 @@ __device__ __attribute__((aligned(16))) unsigned int seer_zero_page[4] = {0u, 0u
 // NS == 0: register-staged double buffer (global_load -> VGPR -> ds_write), one barrier per K tile.
 // NS >= 2: NS-stage ring filled by global_load_lds (16 B per lane straight into LDS, no VGPR / ds_write), NS-1 tiles in
 //          flight across raw s_barriers behind counted s_waitcnt vmcnt(N).  Same LDS image either way.
-template <int BM, int BN, bool CONV, bool GEGLU, bool SPLIT, int NS>
-__global__ void __launch_bounds__(256) seer_gemm_kernel(const seer_gemm_desc p) {
-    constexpr int WTM = BM / 2, WTN = BN / 2;
+// WM: waves along M (the wave grid is WM x 2): 2 -> 256 threads, 4 -> 512 threads (256-row tiles, same 64x64 wave tile).
+template <int BM, int BN, bool CONV, bool GEGLU, bool SPLIT, int NS, int WM = 2>
+__global__ void __launch_bounds__(128 * WM) seer_gemm_kernel(const seer_gemm_desc p) {
+    constexpr int NT = 128 * WM;                   // threads per block
+    constexpr int RPP = NT / 8;                    // tile rows staged per pass (8 lanes x 16 B cover one 128-B row)
+    constexpr int WTM = BM / WM, WTN = BN / 2;
     constexpr int TM = WTM / 16, TN = WTN / 16;
-    constexpr int A_CH = BM / 32, B_CH = BN / 32;  // 16-byte chunks per thread per K tile
+    constexpr int A_CH = BM / RPP, B_CH = BN / RPP;  // 16-byte chunks per thread per K tile
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the rows staged per pass");
     static_assert(!GEGLU || (TN % 2 == 0), "GEGLU needs value/gate n-tile pairs inside one wave");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -66,13 +70,13 @@ __global__ void __launch_bounds__(256) seer_gemm_kernel(const seer_gemm_desc p) 
 
     // ---- per-thread staging descriptors
     const int c8 = (tid & 7) * 8;     // element offset of this thread's chunk inside the K tile
-    const int srow = tid >> 3;        // 0..31
+    const int srow = tid >> 3;        // 0..RPP-1
     int64_t a_off[A_CH];              // plain: row offset into A ; conv: image base offset
     int64_t a_off2[A_CH];
     int a_oy[A_CH], a_ox[A_CH];
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
-        int gm = m0 + srow + 32 * i;
+        int gm = m0 + srow + RPP * i;
         gm = gm < p.M ? gm : p.M - 1;
         if constexpr (CONV) {
             const int hw = p.Hout * p.Wout;
@@ -92,7 +96,7 @@ __global__ void __launch_bounds__(256) seer_gemm_kernel(const seer_gemm_desc p) 
     int64_t b_off[B_CH];
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
-        int gn = n0 + srow + 32 * i;
+        int gn = n0 + srow + RPP * i;
         gn = gn < p.N ? gn : p.N - 1;
         b_off[i] = (int64_t)gn * p.K;
     }
@@ -136,11 +140,11 @@ __global__ void __launch_bounds__(256) seer_gemm_kernel(const seer_gemm_desc p) 
     auto store_tile = [&](int buf) {
         bf16* as = smem_b + buf * STAGE;
         bf16* bs = as + BM * BK;
-        const int sw = ((tid & 7) ^ (srow & 7)) * 8;   // (row & 7) == (srow & 7) because rows step by 32
+        const int sw = ((tid & 7) ^ (srow & 7)) * 8;   // (row & 7) == (srow & 7) because rows step by RPP (a multiple of 8)
 #pragma unroll
-        for (int i = 0; i < A_CH; ++i) *reinterpret_cast<u32x4*>(as + (srow + 32 * i) * BK + sw) = areg[i];
+        for (int i = 0; i < A_CH; ++i) *reinterpret_cast<u32x4*>(as + (srow + RPP * i) * BK + sw) = areg[i];
 #pragma unroll
-        for (int i = 0; i < B_CH; ++i) *reinterpret_cast<u32x4*>(bs + (srow + 32 * i) * BK + sw) = breg[i];
+        for (int i = 0; i < B_CH; ++i) *reinterpret_cast<u32x4*>(bs + (srow + RPP * i) * BK + sw) = breg[i];
     };
 
     f32x4 acc[TM][TN];
@@ -233,7 +237,7 @@ __global__ void __launch_bounds__(256) seer_gemm_kernel(const seer_gemm_desc p) 
                     const bf16* src = ok ? (A + a_off[i] + ((int64_t)sy * p.Win + sx) * p.Cin + ci0 + schunk)
                                          : reinterpret_cast<const bf16*>(seer_zero_page);
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                     (__attribute__((address_space(3))) void*)(as + 32 * i * BK), 16, 0, 0);
+                                                     (__attribute__((address_space(3))) void*)(as + RPP * i * BK), 16, 0, 0);
                 }
             } else {
                 const bool second = kbase >= p.K1;
@@ -241,14 +245,14 @@ __global__ void __launch_bounds__(256) seer_gemm_kernel(const seer_gemm_desc p) 
                 for (int i = 0; i < A_CH; ++i) {
                     const bf16* src = second ? (A2 + a_off2[i] + (kbase - p.K1) + schunk) : (A + a_off[i] + kbase + schunk);
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                     (__attribute__((address_space(3))) void*)(as + 32 * i * BK), 16, 0, 0);
+                                                     (__attribute__((address_space(3))) void*)(as + RPP * i * BK), 16, 0, 0);
                 }
             }
 #pragma unroll
             for (int i = 0; i < B_CH; ++i) {
                 const bf16* src = W + b_off[i] + kbase + schunk;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(bs + 32 * i * BK), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(bs + RPP * i * BK), 16, 0, 0);
             }
         };
 #pragma unroll
@@ -426,7 +430,7 @@ __global__ void __launch_bounds__(256) seer_splitk_reduce_kernel(const seer_gemm
     }
 }
 
-template <int BM, int BN, int NS>
+template <int BM, int BN, int NS, int WM = 2>
 int launch_tile(const seer_gemm_desc& d, hipStream_t st) {
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, 1, d.batch > 1 ? d.batch : 1);
@@ -436,12 +440,12 @@ int launch_tile(const seer_gemm_desc& d, hipStream_t st) {
         // above the default dynamic-LDS limit: opt in once per instantiation (160 KiB per CU on gfx950)
         static bool done = false;
         if (!done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, true, false, false, NS>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, true, false, false, NS, WM>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if constexpr (GEGLU_OK)
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, false, true, false, NS>),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, false, true, false, NS, WM>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, false, false, false, NS>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, false, false, false, NS, WM>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             done = true;
         }
@@ -450,14 +454,14 @@ int launch_tile(const seer_gemm_desc& d, hipStream_t st) {
     const bool geglu = (d.epilogue & SEER_EPI_GEGLU) != 0;
     if (conv && geglu) return SEER_EINVAL;
     if (conv) {
-        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, true, false, false, NS>), grid, dim3(256), lds, st, d);
+        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, true, false, false, NS, WM>), grid, dim3(128 * WM), lds, st, d);
     } else if (geglu) {
         if constexpr (GEGLU_OK)
-            hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, true, false, NS>), grid, dim3(256), lds, st, d);
+            hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, true, false, NS, WM>), grid, dim3(128 * WM), lds, st, d);
         else
             return SEER_EINVAL;
     } else {
-        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, false, false, NS>), grid, dim3(256), lds, st, d);
+        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, false, false, NS, WM>), grid, dim3(128 * WM), lds, st, d);
     }
     SEER_LAUNCH_CHECK();
     return SEER_OK;
@@ -596,6 +600,8 @@ extern "C" int seer_gemm_bf16(const seer_gemm_desc* desc, void* stream) {
         case SEER_TILE_G128x64_4: return launch_tile<128, 64, 4>(d, st);
         case SEER_TILE_G128x160_2: return launch_tile<128, 160, 2>(d, st);
         case SEER_TILE_G64x160_3: return launch_tile<64, 160, 3>(d, st);
+        case SEER_TILE_G256x128_2: return launch_tile<256, 128, 2, 4>(d, st);
+        case SEER_TILE_G256x64_3: return launch_tile<256, 64, 3, 4>(d, st);
         default: return SEER_EINVAL;
     }
 }
