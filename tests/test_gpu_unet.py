@@ -171,6 +171,24 @@ def test_vae_decode_matches_oracle(device):
     _check(got, ref, "vae decode")
 
 
+def test_config4_64x64_latent_step(device):
+    """BASELINE config 4 (512^2 pixels: 64x64 latent, spatial attention over 4096 tokens, windows ws=8 at two levels):
+    finite, deterministic, identical batch elements agree bit for bit."""
+    cfg = dict(synth.SD15_UNET_CFG)
+    m = SeerUNet(**cfg).to(device)
+    m.load_state_dict(synth.synth_state_dict(synth.unet_param_shapes(cfg), device=device), strict=True)
+    x1 = _randn((1, 4, 12, 64, 64), 1).to(device)
+    c1 = _randn((1, 12, 77, 768), 2).to(device)
+    x, c = torch.cat([x1, x1]), torch.cat([c1, c1])
+    t = torch.tensor([501, 501], device=device)
+    y = m(x, t, c)
+    assert y.shape == (2, 4, 12, 64, 64) and torch.isfinite(y).all()
+    assert torch.equal(y[0], y[1])
+    assert torch.equal(m(x, t, c), y)
+    del m
+    torch.cuda.empty_cache()
+
+
 def test_full_size_step_properties(device):
     """BASELINE config 2 shape (CFG batch 2 x 12 frames x 32^2, full-width UNet): size-independent properties.
     (a) finite output of the right shape; (b) the two CFG halves given IDENTICAL inputs produce identical outputs (the
