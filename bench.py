@@ -207,9 +207,19 @@ def main():
         gm = summ["gemm"]
         per_launch_flops = gm["flops"] / gm["launches"]
         avg_launch_ms = gm["ms"] / gm["launches"]
+        # HBM-side bytes per launch from the separate rocprofv3 --pmc passes of the same step (scripts/pmc_step.py ->
+        # scripts/pmc_summary.py; PMC cannot be collected from inside this process)
+        traffic = None
+        try:
+            pmc = json.load(open(ROOT / "profiles" / "r01_pmc_traffic.json"))
+            traffic = round(pmc["kernels"]["seer_gemm_kernel"]["hbm_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            pass
         roofline = dict(bound="mfma", kernel="seer_gemm_kernel (bf16 MFMA GEMM / implicit-GEMM conv3x3, all tiles)",
                         achieved=round(gm["tflops"], 2), peak=MFMA_BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=round(gm["tflops"] / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), traffic=None,
+                        frac=round(gm["tflops"] / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), traffic=traffic,
+                        traffic_unit="bytes beyond L2 per launch (2*FETCH_SIZE + WRITE_SIZE, PMC)",
+                        algorithmic_bytes_per_launch=round(gm["bytes"] / gm["launches"]),
                         launches_per_step=gm["launches"] // reps, avg_launch_us=round(avg_launch_ms * 1e3, 2),
                         algorithmic_gflop_per_launch=round(per_launch_flops / 1e9, 3),
                         step_breakdown_ms={k: round(v["ms"] / reps, 3) for k, v in summ.items()},
