@@ -18,6 +18,15 @@ namespace {
 
 constexpr int BK = 64;
 
+#ifndef SEER_GEMM_EARLY_REFILL
+#define SEER_GEMM_EARLY_REFILL 1
+#endif
+// measurement-only builds (scripts/probe_gemm.sh; results are WRONG): bit 0 = no global->LDS refills inside the K loop,
+// bit 1 = no LDS fragment reads, bit 2 = no MFMAs.  The shipped library is built with 0.
+#ifndef SEER_GEMM_PROBE
+#define SEER_GEMM_PROBE 0
+#endif
+
 // 16 zero bytes: the source of out-of-image taps for the LDS-direct (global_load_lds) conv gather
 __device__ __attribute__((aligned(16))) unsigned int seer_zero_page[4] = {0u, 0u, 0u, 0u};
 
@@ -255,6 +264,69 @@ __global__ void __launch_bounds__(128 * WM) seer_gemm_kernel(const seer_gemm_des
                                                  (__attribute__((address_space(3))) void*)(bs + RPP * i * BK), 16, 0, 0);
             }
         };
+#if SEER_GEMM_EARLY_REFILL
+        // Early refill: a stage is only occupied from "landed" to "fragments in registers".  Per K tile: wait for the tile,
+        // barrier, read ALL its fragments (both k-steps) into VGPRs, barrier, refill the SAME stage with tile kt+NS, then run
+        // the MFMAs from registers -> NS tiles (not NS-1) are in flight while the MFMAs of a tile run, at the same LDS bytes.
+        bf16x8 af[2][TM], wf[2][TN];
+        auto read_frags = [&](int buf) {
+            const bf16* as = smem_b + buf * STAGE + (wm * WTM) * BK;
+            const bf16* bs = smem_b + buf * STAGE + BM * BK + (wn * WTN) * BK;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int sw = (((ks * 4 + fq) ^ (frow & 7)) * 8);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) wf[ks][j] = *reinterpret_cast<const bf16x8*>(bs + (j * 16 + frow) * BK + sw);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(as + (i * 16 + frow) * BK + sw);
+            }
+        };
+        auto mma_tile = [&]() {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+        };
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_)
+            if (kt0 + s_ < nk) issue_tile(kt0 + s_, s_);
+#if SEER_GEMM_PROBE & 2
+        read_frags(0);
+#endif
+        int stage = 0;
+        for (int kt = kt0; kt < nk; ++kt) {
+            const int pending = min(NS - 1, nk - 1 - kt);   // tiles issued after tile kt
+            if (NS >= 4 && pending >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");
+            else if (NS >= 3 && pending == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+            else if (pending == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");            // every wave's part of tile kt has landed
+#if !(SEER_GEMM_PROBE & 2)
+            read_frags(stage);
+#endif
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");            // every wave holds its fragments: the stage is free
+#if !(SEER_GEMM_PROBE & 1)
+            if (kt + NS < nk) issue_tile(kt + NS, stage);
+#endif
+#if !(SEER_GEMM_PROBE & 4)
+            mma_tile();
+#else
+            // probe build (scripts/probe_gemm.sh): keep the fragment reads alive without issuing MFMAs
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(wf[ks][j]));
+#pragma unroll
+                for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(af[ks][i]));
+            }
+#endif
+            stage = (stage + 1 == NS) ? 0 : stage + 1;
+        }
+#else
 #pragma unroll
         for (int s_ = 0; s_ < NS - 1; ++s_)
             if (kt0 + s_ < nk) issue_tile(kt0 + s_, s_);
@@ -273,6 +345,7 @@ __global__ void __launch_bounds__(128 * WM) seer_gemm_kernel(const seer_gemm_des
             compute_tile(stage);
             stage = (stage + 1 == NS) ? 0 : stage + 1;
         }
+#endif
         // (measured and rejected on MI355X, profiles/r01_gemm_microbench_v5.log: issuing the LDS-DMA pieces between the MFMAs
         //  with sched_group_barrier instead of in one burst is 5-20 % SLOWER at 2 blocks/CU: the other block already covers
         //  the burst, and spreading the pieces delays the next tile's arrival at the barrier.)
@@ -302,6 +375,16 @@ __global__ void __launch_bounds__(128 * WM) seer_gemm_kernel(const seer_gemm_des
     bf16* Cb = reinterpret_cast<bf16*>(p.C) + (int64_t)z * p.strideC;
     float* Cf = reinterpret_cast<float*>(p.C) + (int64_t)z * p.strideC;
     const bool do_rot = (p.epilogue & SEER_EPI_ROTARY) != 0;
+
+    // bf16 row-major outputs leave through LDS: the MFMA layout gives a lane 8 B in each of 16 different rows (32-B row
+    // segments per wave instruction, measured ~1.5 TB/s); staged through the (now idle) K-loop LDS the block stores 16 B per
+    // lane along whole output rows instead.
+    constexpr int BNO = GEGLU ? BN / 2 : BN;            // output columns of the block tile
+    constexpr int CPITCH = BNO * 2 + 16;               // staged row pitch in bytes (16-B aligned rows)
+    static_assert(BM * CPITCH <= 2 * STAGE * (int)sizeof(bf16), "staged C tile must fit in the K-loop LDS");
+    const bool staged = !out_f32 && !trans && (p.ldc % 8 == 0) && (p.N % (GEGLU ? 16 : 8) == 0) &&
+                        ((reinterpret_cast<uintptr_t>(Cb) & 15) == 0);
+    if (staged) __syncthreads();                        // every wave is done with the K-loop stages
 
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -378,8 +461,29 @@ __global__ void __launch_bounds__(128 * WM) seer_gemm_kernel(const seer_gemm_des
                 u32x2 o;
                 o[0] = pack2(v[0], v[1]);
                 o[1] = pack2(v[2], v[3]);
-                *reinterpret_cast<u32x2*>(Cb + (int64_t)m * p.ldc + nc) = o;
+                if (staged) {
+                    const int row_l = wm * WTM + i * 16 + frow;
+                    const int col_l = nc - (GEGLU ? (n0 >> 1) : n0);
+                    *reinterpret_cast<u32x2*>(smem + row_l * CPITCH + col_l * 2) = o;
+                } else {
+                    *reinterpret_cast<u32x2*>(Cb + (int64_t)m * p.ldc + nc) = o;
+                }
             }
+        }
+    }
+    if (staged) {
+        __syncthreads();
+        constexpr int CPR = BNO / 8;                    // 16-byte chunks per staged row
+        const int n0o = GEGLU ? (n0 >> 1) : n0;
+        const int n_out = GEGLU ? (p.N >> 1) : p.N;
+        static_assert((BM * CPR) % NT == 0, "staged store passes must be whole");
+#pragma unroll
+        for (int it = 0; it < BM * CPR / NT; ++it) {
+            const int c = tid + it * NT;
+            const int row = c / CPR, ch = c - row * CPR;
+            const int m = m0 + row, n = n0o + ch * 8;
+            if (m < p.M && n < n_out)
+                *reinterpret_cast<u32x4*>(Cb + (int64_t)m * p.ldc + n) = *reinterpret_cast<const u32x4*>(smem + row * CPITCH + ch * 16);
         }
     }
 }
