@@ -20,6 +20,9 @@ LIBDIR = PKG / "lib"
 LIB = LIBDIR / "libseer_hip.so"
 SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "elementwise.hip"]
 ARCH = "gfx950"
+# per-source extra flags.  attention: keep the MFMA accumulators in VGPRs (gfx950's unified file allows it) -- the online
+# softmax touches S and O every key tile, and the default AGPR form costs ~220 v_accvgpr moves per tile per wave.
+EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc() -> str:
@@ -31,7 +34,7 @@ def _hipcc() -> str:
 
 def _digest() -> str:
     h = hashlib.sha256()
-    for p in sorted(list(CSRC.glob("*")) + [ROOT / "include" / "seer_hip.h"]):
+    for p in sorted(list(CSRC.glob("*")) + [ROOT / "include" / "seer_hip.h", Path(__file__).resolve()]):
         if p.is_file():
             h.update(p.name.encode())
             h.update(p.read_bytes())
@@ -52,7 +55,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
 
     def compile_one(src: str) -> Path:
         obj = objdir / (src + ".o")
-        cmd = [hipcc, *flags, "-c", str(CSRC / src), "-o", str(obj)]
+        cmd = [hipcc, *flags, *EXTRA_FLAGS.get(src, []), "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         r = subprocess.run(cmd, capture_output=True, text=True)

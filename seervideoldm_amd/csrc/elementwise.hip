@@ -66,118 +66,171 @@ __global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, int B, 
     else { o[j] = s; o[half + j] = c; }
 }
 
-// ---- small-M linear: one wave per output feature, all B (<= 8) rows at once -----------------------------------
-template <int MAXB>
+// ---- small-M linear (time-embedding MLP, B <= 8 rows): act(x) staged once per block in LDS, each wave owns ROWS
+// consecutive output features so ROWS independent 16-B weight loads per lane are in flight per K pass (the 51 MB
+// time_emb_proj stack is a pure HBM stream) -----------------------------------------------------------------------
+template <int MAXB, int ROWS>
 __global__ void __launch_bounds__(256) linear_smallm_kernel(const float* __restrict__ x, int B, int K,
                                                             const bf16* __restrict__ W, const float* __restrict__ bias,
                                                             int N, int silu_in, int silu_out, float* __restrict__ y) {
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= N) return;
+    extern __shared__ __attribute__((aligned(16))) float xs[];     // [B][K]
+    for (int i = threadIdx.x; i < B * K; i += 256) {
+        float v = x[i];
+        if (silu_in) v = silu_f(v);
+        xs[i] = v;
+    }
+    __syncthreads();
     const int lane = threadIdx.x & 63;
-    float acc[MAXB];
+    const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
+    if (n0 >= N) return;
+    float acc[ROWS][MAXB];
 #pragma unroll
-    for (int b = 0; b < MAXB; ++b) acc[b] = 0.f;
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) acc[r][b] = 0.f;
     for (int k0 = lane * 8; k0 < K; k0 += 64 * 8) {
-        const u32x4 wv = *reinterpret_cast<const u32x4*>(W + (int64_t)n * K + k0);
-        float w[8];
-        unpack8(wv, w);
+        u32x4 wv[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int n = n0 + r < N ? n0 + r : N - 1;
+            wv[r] = *reinterpret_cast<const u32x4*>(W + (int64_t)n * K + k0);
+        }
+        float xv[MAXB][8];
 #pragma unroll
         for (int b = 0; b < MAXB; ++b) {
-            if (b < B) {
-                const float* xr = x + (int64_t)b * K + k0;
+            const int bb = b < B ? b : 0;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(xs + bb * K + k0);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(xs + bb * K + k0 + 4);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float xv = xr[e];
-                    if (silu_in) xv = silu_f(xv);
-                    acc[b] += xv * w[e];
-                }
-            }
+            for (int e = 0; e < 4; ++e) { xv[b][e] = lo[e]; xv[b][4 + e] = hi[e]; }
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            float w[8];
+            unpack8(wv[r], w);
+#pragma unroll
+            for (int b = 0; b < MAXB; ++b)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[r][b] += xv[b][e] * w[e];
         }
     }
 #pragma unroll
-    for (int b = 0; b < MAXB; ++b) {
-        if (b < B) {
-            float v = wave_sum(acc[b]);
-            if (lane == 0) {
-                if (bias) v += bias[n];
+    for (int r = 0; r < ROWS; ++r) {
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) {
+            const float v0 = wave_sum(acc[r][b]);
+            if (lane == 0 && b < B && n0 + r < N) {
+                float v = v0;
+                if (bias) v += bias[n0 + r];
                 if (silu_out) v = silu_f(v);
-                y[(int64_t)b * N + n] = v;
+                y[(int64_t)b * N + n0 + r] = v;
             }
         }
     }
 }
 
 // ---- conv_in: [B, Cin, F, H, W] fp32 -> channels-last bf16 [B*F*H*W, Cout]; weights fp32 [3][3][Cin][Cout] ----
+// per block: the 9*Cin*Cout weights and the 3x3xCin input patches of its `ppb` pixels are staged in LDS once (every
+// output-channel group needs the same 9*Cin inputs); a thread owns 8 output channels of one pixel lane
 __global__ void __launch_bounds__(256) conv_in_kernel(const float* __restrict__ x, int B, int Cin, int F, int H, int Wd,
                                                       const float* __restrict__ Wt, const float* __restrict__ bias,
-                                                      int Cout, bf16* __restrict__ y) {
-    const int cgroups = Cout / 8;
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                                      int Cout, bf16* __restrict__ y, int ppb) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];     // [9*Cin][Cout] then patches [ppb][9*Cin]
+    const int nw = 9 * Cin * Cout;
+    const int kk = 9 * Cin;
+    float* patch = wsm + nw;
+    for (int i = threadIdx.x * 4; i < nw; i += 1024) *reinterpret_cast<f32x4*>(wsm + i) = *reinterpret_cast<const f32x4*>(Wt + i);
     const int64_t npix = (int64_t)B * F * H * Wd;
-    if (gid >= npix * cgroups) return;
-    const int cg = (int)(gid % cgroups);
-    const int64_t pix = gid / cgroups;
-    const int ox = (int)(pix % Wd);
-    const int oy = (int)((pix / Wd) % H);
-    const int f = (int)((pix / ((int64_t)Wd * H)) % F);
-    const int b = (int)(pix / ((int64_t)Wd * H * F));
-    float acc[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = bias ? bias[cg * 8 + e] : 0.f;
-    for (int ky = 0; ky < 3; ++ky) {
-        const int iy = oy + ky - 1;
-        if (iy < 0 || iy >= H) continue;
-        for (int kx = 0; kx < 3; ++kx) {
-            const int ix = ox + kx - 1;
-            if (ix < 0 || ix >= Wd) continue;
-            for (int ci = 0; ci < Cin; ++ci) {
-                const float xv = x[((((int64_t)b * Cin + ci) * F + f) * H + iy) * Wd + ix];
-                const float* w = Wt + ((int64_t)((ky * 3 + kx) * Cin + ci)) * Cout + cg * 8;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += xv * w[e];
-            }
-        }
+    const int64_t p0 = (int64_t)blockIdx.x * ppb;
+    const int np = (int)(p0 + ppb < npix ? ppb : npix - p0);
+    const int64_t cstride = (int64_t)F * H * Wd;   // channel stride of the NCFHW input
+    for (int i = threadIdx.x; i < np * kk; i += 256) {
+        const int pp = i / kk, k = i - pp * kk;
+        const int tap = k / Cin, ci = k - tap * Cin;
+        const int64_t pix = p0 + pp;
+        const int ox = (int)(pix % Wd);
+        const int oy = (int)((pix / Wd) % H);
+        const int f = (int)((pix / ((int64_t)Wd * H)) % F);
+        const int b = (int)(pix / ((int64_t)Wd * H * F));
+        const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+        float v = 0.f;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < Wd)
+            v = x[(((int64_t)b * Cin + ci) * F + f) * H * Wd + (int64_t)iy * Wd + ix];
+        patch[i] = v;
     }
-    *reinterpret_cast<u32x4*>(y + pix * Cout + cg * 8) = pack8(acc);
+    __syncthreads();
+    const int cgroups = Cout / 8;
+    const int npl = 256 / cgroups;                // pixel lanes per block
+    const int pl = threadIdx.x / cgroups;
+    const int cg = threadIdx.x - pl * cgroups;
+    if (pl >= npl) return;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = bias ? bias[cg * 8 + e] : 0.f;
+    for (int pp = pl; pp < np; pp += npl) {
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = bv[e];
+        const float* xp = patch + pp * kk;
+        const float* wp = wsm + cg * 8;
+#pragma unroll 4
+        for (int k = 0; k < kk; ++k) {
+            const float xv = xp[k];
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp + k * Cout);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(wp + k * Cout + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[e] += xv * w0[e]; acc[4 + e] += xv * w1[e]; }
+        }
+        *reinterpret_cast<u32x4*>(y + (p0 + pp) * Cout + cg * 8) = pack8(acc);
+    }
 }
 
 // ---- conv_out: channels-last bf16 [B*F*H*W, C0] -> [B, Cout, F, H, W] fp32; weights fp32 [Cout][3][3][C0] -------
+// weights in LDS once per block; one wave per pixel (lanes over the 9 * C0/8 input chunks), `ppb` pixels per block
 template <int COUT>
 __global__ void __launch_bounds__(256) conv_out_kernel(const bf16* __restrict__ x, int B, int C0, int F, int H, int Wd,
                                                        const float* __restrict__ Wt, const float* __restrict__ bias,
-                                                       float* __restrict__ y) {
-    const int64_t pix = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                       float* __restrict__ y, int ppb) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];     // [COUT][9][C0]
+    const int nw = COUT * 9 * C0;
+    for (int i = threadIdx.x * 4; i < nw; i += 1024) *reinterpret_cast<f32x4*>(wsm + i) = *reinterpret_cast<const f32x4*>(Wt + i);
+    __syncthreads();
     const int64_t npix = (int64_t)B * F * H * Wd;
-    if (pix >= npix) return;
+    const int64_t p0 = (int64_t)blockIdx.x * ppb;
+    const int64_t p1 = p0 + ppb < npix ? p0 + ppb : npix;
     const int lane = threadIdx.x & 63;
-    const int ox = (int)(pix % Wd);
-    const int oy = (int)((pix / Wd) % H);
-    const int64_t img = pix / ((int64_t)Wd * H);       // b*F + f
     const int nch = C0 / 8;
-    float acc[COUT];
+    for (int64_t pix = p0 + (threadIdx.x >> 6); pix < p1; pix += 4) {
+        const int ox = (int)(pix % Wd);
+        const int oy = (int)((pix / Wd) % H);
+        const int64_t img = pix / ((int64_t)Wd * H);       // b*F + f
+        float acc[COUT];
 #pragma unroll
-    for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
-    for (int item = lane; item < 9 * nch; item += 64) {
-        const int tap = item / nch, ch = item - tap * nch;
-        const int ky = tap / 3, kx = tap - 3 * ky;
-        const int iy = oy + ky - 1, ix = ox + kx - 1;
-        if (iy < 0 || iy >= H || ix < 0 || ix >= Wd) continue;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(x + ((img * H + iy) * Wd + ix) * C0 + ch * 8);
-        float f[8];
-        unpack8(v, f);
+        for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
+        for (int item = lane; item < 9 * nch; item += 64) {
+            const int tap = item / nch, ch = item - tap * nch;
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const int iy = oy + ky - 1, ix = ox + kx - 1;
+            if (iy < 0 || iy >= H || ix < 0 || ix >= Wd) continue;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(x + ((img * H + iy) * Wd + ix) * C0 + ch * 8);
+            float f[8];
+            unpack8(v, f);
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) {
+                const float* w = wsm + (o * 9 + tap) * C0 + ch * 8;
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(w);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(w + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[o] += f[e] * w0[e] + f[4 + e] * w1[e];
+            }
+        }
+        const int f_ = (int)(img % F);
+        const int b = (int)(img / F);
 #pragma unroll
         for (int o = 0; o < COUT; ++o) {
-            const float* w = Wt + ((int64_t)o * 9 + tap) * C0 + ch * 8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[o] += f[e] * w[e];
+            const float v = wave_sum(acc[o]);
+            if (lane == 0) y[((((int64_t)b * COUT + o) * F + f_) * H + oy) * Wd + ox] = v + (bias ? bias[o] : 0.f);
         }
-    }
-    const int f_ = (int)(img % F);
-    const int b = (int)(img / F);
-#pragma unroll
-    for (int o = 0; o < COUT; ++o) {
-        const float v = wave_sum(acc[o]);
-        if (lane == 0) y[((((int64_t)b * COUT + o) * F + f_) * H + oy) * Wd + ox] = v + (bias ? bias[o] : 0.f);
     }
 }
 
@@ -314,23 +367,52 @@ extern "C" int seer_timestep_embedding(const int64_t* t, int32_t B, int32_t dim,
     return SEER_OK;
 }
 
+// kernels whose dynamic LDS may exceed the 64 KiB default: opt in once per kernel (160 KiB per CU on gfx950)
+template <typename K>
+int ensure_lds(K kernel, size_t bytes, bool* done) {
+    if (bytes > 160 * 1024) return SEER_EINVAL;
+    if (bytes > 64 * 1024 && !*done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return SEER_ELAUNCH;
+        *done = true;
+    }
+    return SEER_OK;
+}
+
 extern "C" int seer_linear_smallm(const float* x, int32_t B, int32_t K, const void* W, const float* bias, int32_t N,
                                   int32_t silu_in, int32_t silu_out, float* y, void* stream) {
     if (!x || !W || !y || B <= 0 || B > 8 || K <= 0 || K % 8 || N <= 0) return SEER_EINVAL;
-    dim3 grid((N + 3) / 4);
+    const size_t lds = (size_t)B * K * sizeof(float);
     const bf16* Wb = reinterpret_cast<const bf16*>(W);
-    if (B <= 2) hipLaunchKernelGGL(linear_smallm_kernel<2>, grid, dim3(256), 0, S(stream), x, B, K, Wb, bias, N, silu_in, silu_out, y);
-    else hipLaunchKernelGGL(linear_smallm_kernel<8>, grid, dim3(256), 0, S(stream), x, B, K, Wb, bias, N, silu_in, silu_out, y);
+    if (B <= 2) {
+        static bool done = false;
+        const int rc = ensure_lds(linear_smallm_kernel<2, 4>, lds, &done);
+        if (rc != SEER_OK) return rc;
+        hipLaunchKernelGGL((linear_smallm_kernel<2, 4>), dim3((N + 15) / 16), dim3(256), lds, S(stream), x, B, K, Wb, bias, N,
+                           silu_in, silu_out, y);
+    } else {
+        static bool done = false;
+        const int rc = ensure_lds(linear_smallm_kernel<8, 2>, lds, &done);
+        if (rc != SEER_OK) return rc;
+        hipLaunchKernelGGL((linear_smallm_kernel<8, 2>), dim3((N + 7) / 8), dim3(256), lds, S(stream), x, B, K, Wb, bias, N,
+                           silu_in, silu_out, y);
+    }
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }
 
 extern "C" int seer_conv_in(const float* x, int32_t B, int32_t Cin, int32_t F, int32_t H, int32_t W_, const float* Wt,
                             const float* bias, int32_t Cout, void* y, void* stream) {
-    if (!x || !Wt || !y || B <= 0 || Cin <= 0 || F <= 0 || H <= 0 || W_ <= 0 || Cout <= 0 || Cout % 8) return SEER_EINVAL;
-    const int64_t n = (int64_t)B * F * H * W_ * (Cout / 8);
-    hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), x, B, Cin, F, H, W_,
-                       Wt, bias, Cout, reinterpret_cast<bf16*>(y));
+    if (!x || !Wt || !y || B <= 0 || Cin <= 0 || F <= 0 || H <= 0 || W_ <= 0 || Cout <= 0 || Cout % 8 || Cout > 2048)
+        return SEER_EINVAL;
+    const int ppb = 32;
+    const size_t lds = ((size_t)9 * Cin * Cout + (size_t)ppb * 9 * Cin) * sizeof(float);
+    static bool done = false;
+    const int rc = ensure_lds(conv_in_kernel, lds, &done);
+    if (rc != SEER_OK) return rc;
+    const int64_t npix = (int64_t)B * F * H * W_;
+    hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(256), lds, S(stream), x, B, Cin, F, H, W_,
+                       Wt, bias, Cout, reinterpret_cast<bf16*>(y), ppb);
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }
@@ -339,11 +421,23 @@ extern "C" int seer_conv_out(const void* x, int32_t B, int32_t C0, int32_t F, in
                              const float* bias, int32_t Cout, float* y, void* stream) {
     if (!x || !Wt || !y || B <= 0 || C0 <= 0 || C0 % 8 || F <= 0 || H <= 0 || W_ <= 0) return SEER_EINVAL;
     const int64_t npix = (int64_t)B * F * H * W_;
-    dim3 grid((unsigned)((npix + 3) / 4));
+    const int ppb = 32;
+    dim3 grid((unsigned)((npix + ppb - 1) / ppb));
+    const size_t lds = (size_t)Cout * 9 * C0 * sizeof(float);
     const bf16* xb = reinterpret_cast<const bf16*>(x);
-    if (Cout == 4) hipLaunchKernelGGL(conv_out_kernel<4>, grid, dim3(256), 0, S(stream), xb, B, C0, F, H, W_, Wt, bias, y);
-    else if (Cout == 3) hipLaunchKernelGGL(conv_out_kernel<3>, grid, dim3(256), 0, S(stream), xb, B, C0, F, H, W_, Wt, bias, y);
-    else return SEER_ENOSYS;
+    if (Cout == 4) {
+        static bool done = false;
+        const int rc = ensure_lds(conv_out_kernel<4>, lds, &done);
+        if (rc != SEER_OK) return rc;
+        hipLaunchKernelGGL(conv_out_kernel<4>, grid, dim3(256), lds, S(stream), xb, B, C0, F, H, W_, Wt, bias, y, ppb);
+    } else if (Cout == 3) {
+        static bool done = false;
+        const int rc = ensure_lds(conv_out_kernel<3>, lds, &done);
+        if (rc != SEER_OK) return rc;
+        hipLaunchKernelGGL(conv_out_kernel<3>, grid, dim3(256), lds, S(stream), xb, B, C0, F, H, W_, Wt, bias, y, ppb);
+    } else {
+        return SEER_ENOSYS;
+    }
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }

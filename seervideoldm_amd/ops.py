@@ -315,10 +315,30 @@ def conv_in(x: torch.Tensor, w_khwc: torch.Tensor, bias: torch.Tensor) -> torch.
 
 
 def conv_out(x: torch.Tensor, w_ohwc: torch.Tensor, bias: torch.Tensor, B: int, F: int, H: int, W: int) -> torch.Tensor:
-    """x [B*F*H*W, C0] bf16 -> [B, Cout, F, H, W] fp32 ; w fp32 [Cout,3,3,C0]."""
-    _req(x, bf16, "x"); _req(w_ohwc, torch.float32, "w")
+    """x [B*F*H*W, C0] bf16 -> [B, Cout, F, H, W] fp32 ; w fp32 [Cout,3,3,C0] (direct kernel) or, for Cout % 4 == 0,
+    bf16 [Cout, 9*C0] in conv3x3 packing: implicit-GEMM on the MFMA path, batched over B with a transposed fp32 store
+    (the [Cout, F*H*W] planes of NCFHW are C^T of the per-sample GEMM)."""
+    _req(x, bf16, "x")
     Cout = w_ohwc.shape[0]
     y = torch.empty((B, Cout, F, H, W), device=x.device, dtype=torch.float32)
+    if w_ohwc.dtype == bf16:
+        C0 = x.shape[1]
+        assert w_ohwc.dim() == 2 and w_ohwc.shape[1] == 9 * C0 and Cout % 4 == 0 and x.is_contiguous()
+        M = F * H * W
+        d = GemmDesc()
+        d.A, d.W, d.C = _p(x), _p(w_ohwc), _p(y)
+        d.M, d.N, d.K, d.K1 = M, Cout, 9 * C0, 9 * C0
+        d.ldc = M
+        _req(bias, torch.float32, "bias")
+        d.bias = _p(bias)
+        d.mode = _lib.SEER_GEMM_CONV3X3
+        d.epilogue = _lib.SEER_EPI_TRANS_OUT | _lib.SEER_EPI_OUT_F32
+        d.Hin, d.Win, d.Cin, d.Hout, d.Wout, d.stride, d.upsample = H, W, C0, H, W, 1, 0
+        d.batch, d.strideA, d.strideW, d.strideC = B, M * C0, 0, Cout * M
+        d.splits = 1
+        _launch_gemm(d, x.device, "seer_gemm_bf16(conv_out)")
+        return y
+    _req(w_ohwc, torch.float32, "w")
     check(_lib.load().seer_conv_out(_p(x), B, x.shape[1], F, H, W, _p(w_ohwc), _p(bias), Cout, _p(y), _stream()),
           "seer_conv_out")
     return y

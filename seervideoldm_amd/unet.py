@@ -230,7 +230,10 @@ class _Engine:
             if k in ("conv_in.weight",):
                 w[k] = f32(v.permute(2, 3, 1, 0))                       # [3,3,Cin,Cout]
             elif k in ("conv_out.weight",):
-                w[k] = f32(v.permute(0, 2, 3, 1))                       # [Cout,3,3,C0]
+                if v.shape[0] % 4 == 0:
+                    w[k] = b16(pack_conv3x3(v))                         # [Cout, 9*C0]: MFMA implicit GEMM, transposed store
+                else:
+                    w[k] = f32(v.permute(0, 2, 3, 1))                   # [Cout,3,3,C0]: direct kernel
             elif k.endswith(".weight") and v.dim() == 4:
                 w[k] = b16(pack_conv3x3(v) if v.shape[-1] == 3 else pack_conv1x1(v))
             elif k.endswith(".weight") and v.dim() == 2:

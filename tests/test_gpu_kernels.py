@@ -442,6 +442,18 @@ def test_conv_in_out(device):
     yin = y.float().reshape(B * Fr, H, W, 320).permute(0, 3, 1, 2)
     refo = Fn.conv2d(yin, wo, bo, padding=1).reshape(B, Fr, 4, H, W).permute(0, 2, 1, 3, 4)
     _close(z, refo, rtol=1e-3, atol=1e-3, what="conv_out")
+    # MFMA route (bf16 weights in conv3x3 packing, batched implicit GEMM with a transposed fp32 store)
+    from seervideoldm_amd.weights import pack_conv3x3
+    wob = pack_conv3x3(wo).to(bf16).contiguous()
+    zm = ops.conv_out(y, wob, bo, B, Fr, H, W)
+    refm = Fn.conv2d(yin, wob.float().reshape(4, 3, 3, 320).permute(0, 3, 1, 2), bo, padding=1)
+    refm = refm.reshape(B, Fr, 4, H, W).permute(0, 2, 1, 3, 4)
+    _close(zm, refm, rtol=1e-3, atol=1e-3, what="conv_out (MFMA)")
+    # odd pixel counts / a second shape for the LDS-staged conv_in
+    x3 = _rand((1, 4, 2, 8, 24), device, 7)
+    y3 = ops.conv_in(x3, w.permute(2, 3, 1, 0).contiguous(), None)
+    ref3 = Fn.conv2d(x3.permute(0, 2, 1, 3, 4).reshape(2, 4, 8, 24), w, None, padding=1).permute(0, 2, 3, 1).reshape(-1, 320)
+    _close(y3, ref3, what="conv_in (no bias, 8x24)")
 
 
 def test_layout_and_cast(device):

@@ -205,6 +205,8 @@ def conv_in(x, w_khwc, bias):
 
 def conv_out(x, w_ohwc, bias, B, Fr, H, W):
     C0 = x.shape[1]
+    if w_ohwc.dim() == 2:      # bf16 [Cout, 9*C0] in conv3x3 packing (the MFMA path of the HIP backend)
+        w_ohwc = w_ohwc.float().reshape(w_ohwc.shape[0], 3, 3, C0)
     xi = x.float().reshape(B * Fr, H, W, C0).permute(0, 3, 1, 2)
     y = F.conv2d(xi, w_ohwc.permute(0, 3, 1, 2), bias, padding=1)
     return y.reshape(B, Fr, -1, H, W).permute(0, 2, 1, 3, 4).contiguous()
