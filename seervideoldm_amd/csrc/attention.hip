@@ -37,6 +37,20 @@ struct AttnCfg {
     static constexpr size_t LDS_BYTES = (size_t)2 * BUF * 2;
 };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// v_permlane32_swap: (a, b) -> a = [a.lo | b.lo], b = [a.hi | b.hi]; with a = b = v every lane sees both halves' values
+__device__ __forceinline__ float xhalf_max(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+__device__ __forceinline__ float lower_half_value(float v) {      // value of lane (l & 31) in every lane l
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, r[0]);
+}
+
 struct TokMap {
     int ws_log2;   // -1: identity
     int HW, W_, wy0, wx0;
@@ -60,8 +74,15 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16* const lds = reinterpret_cast<bf16*>(smem);    // 2 x { K [KT][KRS], V [KT][VRS] }
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: tile / mask decisions are wave-uniform branches
     const int lq = lane & 31, lh = lane >> 5;
+    // D = 40 / 80 leave unused rows in the last 32-row d tile of O^T: V's first pad column holds 1.0, so row D of O^T is
+    // sum_k P[k][q] -- the softmax denominator comes out of the PV MFMA (rescaled with O) instead of 16 VALU adds per tile
+    constexpr bool LSUM_MFMA = C::DV > D;
+    constexpr int L_TT = D / 32, L_ROW = D % 32;                     // d tile / row inside it that holds the denominator
+    constexpr int L_REG = (L_ROW & 3) + 4 * (L_ROW >> 3);            // 32x32 layout: row = (reg&3) + 8*(reg>>2) + 4*lh
+    static_assert(!LSUM_MFMA || ((L_ROW & 4) == 0), "denominator row must live in the lh = 0 half");
 
     // ---- batch decode
     const int y = blockIdx.y;
@@ -96,6 +117,11 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
             bf16* kb_ = lds + (r / KT) * C::BUF + (r % KT) * C::KRS + (C::DP - 8);
             *reinterpret_cast<u32x4*>(kb_) = u32x4{0u, 0u, 0u, 0u};
         }
+    }
+    // ---- V pad column D = 1.0 (never overwritten: the tile commits only write columns < D)
+    if constexpr (LSUM_MFMA) {
+        for (int r = tid; r < (DBUF ? 2 : 1) * KT; r += 256)
+            lds[(r / KT) * C::BUF + KT * C::KRS + (r % KT) * C::VRS + D] = (bf16)1.0f;
     }
 
     // ---- Q fragments (B operand: col = query, k = 8h + j inside each 16-wide step)
@@ -193,11 +219,11 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
             const bf16* krow = Ks + (sub * 32 + lq) * C::KRS + 8 * lh;
+            bf16x8 kf[C::KSTEPS];            // all K fragments first: one exposed LDS latency per sub tile, not one per step
 #pragma unroll
-            for (int s = 0; s < C::KSTEPS; ++s) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + 16 * s);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc, 0, 0, 0);
-            }
+            for (int s = 0; s < C::KSTEPS; ++s) kf[s] = *reinterpret_cast<const bf16x8*>(krow + 16 * s);
+#pragma unroll
+            for (int s = 0; s < C::KSTEPS; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], sacc, 0, 0, 0);
 
             // ---- scale (+ mask on boundary tiles)
             const bool need_mask = (kb + 31 >= p.Sk) || (p.causal && (kb + 31 > q0 + q_off));
@@ -217,19 +243,26 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * cscale;
+            mx = xhalf_max(mx) * cscale;      // the other 16 keys of this query live in lane ^ 32
             const float m_new = (mx > m_run + defer_thr) ? mx : m_run;
             const float m_use = (m_new == kNegInf) ? 0.f : m_new;
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);   // m_run == -inf -> 0
             m_run = m_new;
-            float psum = 0.f;
+            {
+                const f32x2 c2 = {cscale, cscale}, nm2 = {-m_use, -m_use};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(fmaf(sacc[r], cscale, -m_use));
-                sacc[r] = e;
-                psum += e;
+                for (int r = 0; r < 16; r += 2) {       // v_pk_fma_f32: two scores per instruction
+                    const f32x2 t = __builtin_elementwise_fma(f32x2{sacc[r], sacc[r + 1]}, c2, nm2);
+                    sacc[r] = __builtin_amdgcn_exp2f(t[0]);
+                    sacc[r + 1] = __builtin_amdgcn_exp2f(t[1]);
+                }
             }
-            l_run = l_run * alpha + psum;
+            if constexpr (!LSUM_MFMA) {
+                float psum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) psum += sacc[r];
+                l_run = l_run * alpha + psum;
+            }
             // the running max of most queries stops moving after the first tiles: skip the O rescale when no lane needs it
             if (!__all(alpha == 1.0f)) {
 #pragma unroll
@@ -275,7 +308,9 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
 
     // ---- finalize: O[q][d] = O^T[d][q] / l
     if (!wave_active) return;
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    float l_tot;
+    if constexpr (LSUM_MFMA) l_tot = lower_half_value(oacc[L_TT][L_REG]);   // row D of O^T sits in the lh = 0 lanes
+    else l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     if (qi < p.Sq) {
         bf16* orow = Og + (int64_t)tok(qi) * p.o_ss;
