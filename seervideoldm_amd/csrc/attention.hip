@@ -37,8 +37,6 @@ struct AttnCfg {
     static constexpr size_t LDS_BYTES = (size_t)2 * BUF * 2;
 };
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
 // v_permlane32_swap: (a, b) -> a = [a.lo | b.lo], b = [a.hi | b.hi]; with a = b = v every lane sees both halves' values
 __device__ __forceinline__ float xhalf_max(float v) {
     const unsigned u = __builtin_bit_cast(unsigned, v);

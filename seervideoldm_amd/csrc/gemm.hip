@@ -181,6 +181,40 @@ __global__ void __launch_bounds__(128 * WM) seer_gemm_kernel(const seer_gemm_des
         }
     }
 
+    // bias prefetch, same reason (a dependent L2 round trip at the head of every block's epilogue otherwise); the 160-wide
+    // tiles have no registers to spare for it
+    constexpr bool BIAS_PRE = !SPLIT && TN <= 4;
+    f32x4 bpre[TN];
+    if constexpr (BIAS_PRE) {
+        if (p.bias) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WTN + j * 16 + (lane >> 4) * 4;
+                bpre[j] = n < p.N ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
+
+    // per-batch row vector (time embedding): one row serves the whole tile whenever the tile does not straddle two batch
+    // elements -> prefetch it as well
+    constexpr bool RV_PRE = !SPLIT && !GEGLU && TN <= 4;
+    f32x4 rvpre[TN];
+    bool rv_pre_ok = false;
+    if constexpr (RV_PRE) {
+        if (p.rowvec) {
+            const int rb0 = m0 / p.rows_per_batch;
+            rv_pre_ok = ((min(m0 + BM, p.M) - 1) / p.rows_per_batch) == rb0;
+            if (rv_pre_ok) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn * WTN + j * 16 + (lane >> 4) * 4;
+                    rvpre[j] = n < p.N ? *reinterpret_cast<const f32x4*>(p.rowvec + (int64_t)rb0 * p.rowvec_ld + n)
+                                       : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+    }
+
     const int nk_all = p.K / BK;
     const int kt0 = SPLIT ? (int)((int64_t)nk_all * blockIdx.z / p.splits) : 0;
     const int nk = SPLIT ? (int)((int64_t)nk_all * (blockIdx.z + 1) / p.splits) : nk_all;
@@ -399,7 +433,9 @@ __global__ void __launch_bounds__(128 * WM) seer_gemm_kernel(const seer_gemm_des
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
             if (p.bias) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+                f32x4 bv;
+                if constexpr (BIAS_PRE) bv = bpre[j];
+                else bv = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] += bv[r];
             }
@@ -409,16 +445,20 @@ __global__ void __launch_bounds__(128 * WM) seer_gemm_kernel(const seer_gemm_des
 #pragma unroll
                 for (int r = 0; r < 4; ++r) g[r] = acc[i][j + 1][r];
                 if (p.bias) {
-                    const f32x4 bg = *reinterpret_cast<const f32x4*>(p.bias + n + 16);
+                    f32x4 bg;
+                    if constexpr (BIAS_PRE) bg = bpre[j + 1];
+                    else bg = *reinterpret_cast<const f32x4*>(p.bias + n + 16);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) g[r] += bg[r];
                 }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_f(g[r]);
+                const f32x2 ge0 = gelu_erf_f2(f32x2{g[0], g[1]}), ge1 = gelu_erf_f2(f32x2{g[2], g[3]});
+                v[0] *= ge0[0]; v[1] *= ge0[1]; v[2] *= ge1[0]; v[3] *= ge1[1];
                 nc = ((n - fq * 4) >> 1) + fq * 4;
             }
             if (p.rowvec) {
-                const f32x4 tv = *reinterpret_cast<const f32x4*>(p.rowvec + (int64_t)rb * p.rowvec_ld + nc);
+                f32x4 tv;
+                if (RV_PRE && rv_pre_ok) tv = rvpre[j];
+                else tv = *reinterpret_cast<const f32x4*>(p.rowvec + (int64_t)rb * p.rowvec_ld + nc);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] += tv[r];
             }

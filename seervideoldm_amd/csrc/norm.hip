@@ -109,23 +109,34 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const bf16* __restrict__ 
     __shared__ float mean_s[64], rstd_s[64];
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
-    if (tid < groups) {
-        const float s = stats[((int64_t)b * groups + tid) * 2];
-        const float q = stats[((int64_t)b * groups + tid) * 2 + 1];
-        const float mean = s * inv_count;
-        float var = q * inv_count - mean * mean;
-        var = var > 0.f ? var : 0.f;
-        mean_s[tid] = mean;
-        rstd_s[tid] = rsqrtf(var + eps);
-    }
-    __syncthreads();
-
     const int64_t r0 = (int64_t)blockIdx.x * g.rpb;
     const int64_t r1 = min(r0 + g.rpb, rows_per_batch);
     const int cpp = g.ncols < 256 ? g.ncols : 256;
     const int rows_par = 256 / cpp;
     const int rl = tid / cpp;
     const int cl = tid - rl * cpp;
+    // the statistics, the first column's affine parameters and (below) the first rows are all requested before anything
+    // waits: one memory round trip at the head of the block instead of three dependent ones
+    float s_in = 0.f, q_in = 0.f;
+    if (tid < groups) {
+        s_in = stats[((int64_t)b * groups + tid) * 2];
+        q_in = stats[((int64_t)b * groups + tid) * 2 + 1];
+    }
+    f32x4 gpre[2] = {}, bpre[2] = {};
+    if (rl < rows_par && cl < g.ncols) {
+        gpre[0] = *reinterpret_cast<const f32x4*>(gamma + cl * 8);
+        gpre[1] = *reinterpret_cast<const f32x4*>(gamma + cl * 8 + 4);
+        bpre[0] = *reinterpret_cast<const f32x4*>(beta + cl * 8);
+        bpre[1] = *reinterpret_cast<const f32x4*>(beta + cl * 8 + 4);
+    }
+    if (tid < groups) {
+        const float mean = s_in * inv_count;
+        float var = q_in * inv_count - mean * mean;
+        var = var > 0.f ? var : 0.f;
+        mean_s[tid] = mean;
+        rstd_s[tid] = rsqrtf(var + eps);
+    }
+    __syncthreads();
     if (rl >= rows_par) return;
     const int C = g.C1 + g.C2;
     for (int cb = 0; cb < g.ncols; cb += cpp) {
@@ -139,9 +150,11 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const bf16* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int grp = (c0 + e) / g.cpg;
-            const float a = rstd_s[grp] * gamma[c0 + e];
+            const float gm_ = cb == 0 ? gpre[e >> 2][e & 3] : gamma[c0 + e];
+            const float bt_ = cb == 0 ? bpre[e >> 2][e & 3] : beta[c0 + e];
+            const float a = rstd_s[grp] * gm_;
             sc[e] = a;
-            sh[e] = beta[c0 + e] - mean_s[grp] * a;
+            sh[e] = bt_ - mean_s[grp] * a;
         }
 #pragma unroll 4
         for (int64_t r = r0 + rl; r < r1; r += rows_par) {
