@@ -247,8 +247,23 @@ def main():
         torch.cuda.synchronize()
         t_dec = time.perf_counter() - t0
         assert out.shape == (w["b"], 3, shape[2], 8 * w["latent"], 8 * w["latent"]) and torch.isfinite(out).all()
+        # the step before the path, once per sample: CLIP [1,77,768] -> context [1,12,77,768] (FSTextTransformer, 8 layers)
+        from seervideoldm_amd import FSTextTransformer
+        fst = FSTextTransformer(num_frames=16, num_layers=8).to(device)
+        fst.load_state_dict(synth.synth_state_dict(synth.fstext_param_shapes(), device=device))
+        fst.set_numframe(w["frames"])
+        clip_txt = torch.randn((w["b"], 77, 768), device=device)
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ctx_out = fst(context=clip_txt)
+            torch.cuda.synchronize()
+            t_fst = time.perf_counter() - t0
+        assert ctx_out.shape == (w["b"], w["frames"], 77, 768) and torch.isfinite(ctx_out).all()
         clip = dict(clip_latency_ms=round(t_clip * 1e3, 2), vae_decode_ms=round(t_dec * 1e3, 2),
-                    what="50-step ddim_sample incl. decode of 10 frames to 256x256 (full SD-VAE decoder, synthetic weights)")
+                    fstext_ms=round(t_fst * 1e3, 2),
+                    what="50-step ddim_sample incl. decode of 10 frames to 256x256 (full SD-VAE decoder, synthetic weights); "
+                         "fstext_ms = FSTextTransformer (8 layers, 182.6M params) producing the [1,12,77,768] context, once per sample")
 
     cpu = None
     if sd_cpu is not None:

@@ -119,7 +119,8 @@ int64_t seer_gemm_workspace_bytes(const seer_gemm_desc* desc /* host */);
  * [tokens, 3C] projection output.  window_ws > 0 selects the temporal window form: the batch index runs
  * over (window, b) and sequence position p = (f, wy, wx) maps to token f*H*W + (win_y*ws+wy)*W + win_x*ws+wx
  * (window_partition/window_reverse of attention.py:42-69 folded into the addressing).
- * head_dim in {40, 80, 160}; bf16 in/out, fp32 softmax statistics and accumulation.
+ * head_dim in {40, 80, 160} (SeerUNet levels) or 96 (FSTextTransformer, 768 / 8; its attention over frames uses
+ * ss = tokens-per-frame rows and bs = one row); bf16 in/out, fp32 softmax statistics and accumulation.
  */
 typedef struct seer_attn_desc {
     const void* Q; const void* K; const void* V; void* O;   /* bf16 */

@@ -143,6 +143,34 @@ def main():
                         x_T=noise, is_3d=True)
     _save("ddim_sample_tiny.npz", start_code=noise, x0_emb=x0_emb, c=c, uc=uc, latent=lat, clip=clip)
 
+    gen_fstext(ref)
+
+
+TINY_FSTEXT = dict(num_frames=6, num_layers=2, channels=192, n_heads=2, cross_attention_dim=192)
+
+
+@torch.no_grad()
+def gen_fstext(ref):
+    """6. FSTextTransformer (unet_3d_condition.py:379-484), the step before the path: head dim 96 like the real model
+    (768 / 8), two layers, evaluated at its native frame count and after set_numframe(4) (nearest resize of pos_embed)."""
+    c = TINY_FSTEXT
+    m = ref.unet.FSTextTransformer(num_frames=c["num_frames"], in_channels=c["channels"], out_channels=c["channels"],
+                                   n_heads=c["n_heads"], num_layers=c["num_layers"],
+                                   cross_attention_dim=c["cross_attention_dim"]).eval()
+    ref_import.enable_xformers_path(m)
+    shapes = synth.fstext_param_shapes(**c)
+    assert set(shapes) == set(m.state_dict().keys())
+    m.load_state_dict(synth.synth_state_dict(shapes), strict=True)
+    ctx = _randn((2, 77, c["channels"]), 60)
+    out = {}
+    for Fr in (6, 4):
+        m.set_numframe(Fr)
+        out[f"y_F{Fr}"] = m(context=ctx)
+    _save("fstext_tiny.npz", context=ctx, **out)
+
 
 if __name__ == "__main__":
-    main()
+    if "fstext" in sys.argv[1:]:
+        gen_fstext(ref_import.load_reference())
+    else:
+        main()

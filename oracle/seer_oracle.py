@@ -356,3 +356,42 @@ def ddim_sample(unet_fn, vae_sd, shape, c, start_code, x0_emb, ddim_steps=10, sc
     x = vae_decode(vae_sd, z, **(vae_kwargs or {}))
     x = x.reshape(n, f, *x.shape[1:]).permute(0, 2, 1, 3, 4)
     return torch.clamp((x + 1.0) / 2.0, min=0.0, max=1.0), samples
+
+
+# ------------------------------------------------------------------------------------------------ FSTextTransformer
+# the step BEFORE the path -- CLIP text embedding [b, 77, 768] -> per-frame sub-instruction
+# embeddings [b, F, 77, 768], the `context` of every denoising step.
+def fstext_forward(sd: SD, context, num_frames: int, heads: int = 8):
+    """FSTextTransformer.forward (seer/models/unet_3d_condition.py:464-484) over `num_layers` LinearTransformer3D
+    (attention.py:153-180), each = [BasicLinearTransformerBlock3D(temporal=False), (temporal=True)] (attention.py:328-427).
+    State dict = the module's own keys (learnable_query, pos_embed, trf_blocks.N.transformer_blocks.{0,1}.*, norm.*)."""
+    b, l, c = context.shape
+    Fr = num_frames
+    pos = sd["pos_embed"][:, :, :l, :]
+    if sd["pos_embed"].shape[1] != Fr:       # nearest-neighbour resize over (frames, length), unet_3d_condition.py:471-474
+        pos = F.interpolate(pos.permute(0, 3, 1, 2), size=(Fr, l)).permute(0, 2, 3, 1)
+    x = sd["learnable_query"].expand(b, Fr, l, -1) + pos
+    n_layers = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("trf_blocks."))
+    for n in range(n_layers):
+        # ---- block 0: per-frame self-attention over the 77 tokens (causal=True is ignored when temporal=False:
+        # the mask is only built under `if self.temporal`, attention.py:523-526), cross-attention of all F*l tokens to
+        # the CLIP sequence (3-D context -> x.reshape(b, f*l, c), attention.py:400-401), GEGLU feed-forward
+        p = f"trf_blocks.{n}.transformer_blocks.0"
+        h = x.reshape(b * Fr, l, c)
+        h = cross_attention(sd, p + ".attn1", _ln(sd, p + ".norm1", h), None, heads) + h
+        h = h.reshape(b, Fr * l, c)
+        h = cross_attention(sd, p + ".attn2", _ln(sd, p + ".norm2", h), context, heads) + h
+        h = feed_forward(sd, p + ".ff", _ln(sd, p + ".norm3", h)) + h
+        x = h.reshape(b, Fr, l, c)
+        # ---- block 1 (temporal): every token position attends causally over the frames, rotary on q,k with the frame
+        # index as position (attention.py:383-396, 512-533)
+        p = f"trf_blocks.{n}.transformer_blocks.1"
+        h = x.permute(0, 2, 1, 3).reshape(b * l, Fr, c)
+        hn = _ln(sd, p + ".norm1", h)
+        q, k, v = (_heads(_lin(sd, f"{p}.attn1.to_{n_}", hn), heads) for n_ in "qkv")
+        fr = sd[p + ".attn1.rotary_emb.freqs"]
+        o = _unheads(mea(rotary(q, fr), rotary(k, fr), v, True), heads)
+        h = _lin(sd, p + ".attn1.to_out.0", o) + h
+        h = feed_forward(sd, p + ".ff", _ln(sd, p + ".norm3", h)) + h
+        x = h.reshape(b, l, Fr, c).permute(0, 2, 1, 3)
+    return _ln(sd, "norm", x)

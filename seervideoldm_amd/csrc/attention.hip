@@ -1,4 +1,4 @@
-// Flash-style attention forward for gfx950 (MI355X): head_dim 40 / 80 / 160, bf16 in/out.
+// Flash-style attention forward for gfx950 (MI355X): head_dim 40 / 80 / 160 (UNet) and 96 (FSTextTransformer), bf16 in/out.
 //
 // One kernel serves the three attention sites of the Seer UNet (include/seer_hip.h, seer_attn_fwd):
 //   spatial self-attention  [B*F*8, HW, d]  x [.., HW, d]      non-causal
@@ -378,6 +378,7 @@ extern "C" int seer_attn_fwd(const seer_attn_desc* desc, void* stream) {
     switch (d.head_dim) {
         case 40: return launch_attn<40>(d, ws_log2, st);
         case 80: return launch_attn<80>(d, ws_log2, st);
+        case 96: return launch_attn<96>(d, ws_log2, st);      // FSTextTransformer (768 channels, 8 heads)
         case 160: return launch_attn<160>(d, ws_log2, st);
         default: return SEER_ENOSYS;
     }

@@ -166,11 +166,14 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, n_img: int, Hin: int, Win: int, *,
 # ------------------------------------------------------------------------------------------------------------
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *, batch: int, heads: int,
               head_dim: int, Sq: int, Sk: int, causal=False, scale: Optional[float] = None,
-              window=None, Fq: Optional[int] = None, causal_offset: int = 0) -> torch.Tensor:
+              window=None, Fq: Optional[int] = None, causal_offset: int = 0,
+              seq_stride_rows: int = 1, batch_stride_rows: Optional[int] = None) -> torch.Tensor:
     """q/k/v/out are 2-D token-major views [batch*S, >=heads*head_dim] (row stride = token stride, e.g. column slices
     of a fused qkv buffer).  window = (ws, F, H, W) selects the temporal window form (K/V: F*H*W tokens per batch
     element in memory, Sk = F*ws*ws per window; Q/O hold Fq frames, Fq = F unless frame-sharded).  causal_offset is the
-    sequence position of query 0 in the key sequence (frame shards)."""
+    sequence position of query 0 in the key sequence (frame shards).  seq_stride_rows / batch_stride_rows: token s of
+    sequence b sits in row b*batch_stride_rows + s*seq_stride_rows (default: sequences stored one after the other) --
+    FSTextTransformer's attention over frames reads rows ordered (frame, token) with seq stride = tokens per frame."""
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (out, "out")):
         _req(t, bf16, n)
         assert t.dim() == 2 and t.stride(1) == 1
@@ -188,6 +191,10 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     assert q.shape[0] == batch * tq and k.shape[0] == batch * tk and v.shape[0] == batch * tk
     d.q_bs, d.o_bs = tq * q.stride(0), tq * out.stride(0)
     d.k_bs, d.v_bs = tk * k.stride(0), tk * v.stride(0)
+    if seq_stride_rows != 1 or batch_stride_rows is not None:
+        assert window is None and batch_stride_rows is not None
+        d.q_ss, d.k_ss, d.v_ss, d.o_ss = (seq_stride_rows * t.stride(0) for t in (q, k, v, out))
+        d.q_bs, d.k_bs, d.v_bs, d.o_bs = (batch_stride_rows * t.stride(0) for t in (q, k, v, out))
     d.batch, d.heads, d.head_dim, d.Sq, d.Sk = batch, heads, head_dim, Sq, Sk
     d.causal = int(causal)
     d.scale = float(scale if scale is not None else head_dim ** -0.5)

@@ -104,6 +104,28 @@ def unet_param_shapes(cfg: dict) -> "OrderedDict[str, Tuple[int, ...]]":
     return sh
 
 
+def fstext_param_shapes(num_frames=16, num_layers=8, channels=768, n_heads=8, cross_attention_dim=768, max_length=1024):
+    """FSTextTransformer state dict (seer/models/unet_3d_condition.py:379-400; blocks attention.py:153-180,328-362):
+    `pytorch_model_1.bin` of a Seer checkpoint (inference_img.py:80,100-101: num_frames=16, num_layers=8)."""
+    sh: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    C = channels
+    sh["learnable_query"] = (1, 1, 1, C)
+    sh["pos_embed"] = (1, num_frames, max_length, C)
+    for n in range(num_layers):
+        for d, temporal in ((0, False), (1, True)):
+            tb = f"trf_blocks.{n}.transformer_blocks.{d}"
+            _attn(sh, tb + ".attn1", C, C, n_heads, rotary=temporal)
+            sh[tb + ".ff.net.0.proj.weight"] = (8 * C, C); sh[tb + ".ff.net.0.proj.bias"] = (8 * C,)
+            sh[tb + ".ff.net.2.weight"] = (C, 4 * C); sh[tb + ".ff.net.2.bias"] = (C,)
+            if not temporal:
+                _attn(sh, tb + ".attn2", C, cross_attention_dim, n_heads, rotary=False)
+                sh[tb + ".norm2.weight"] = (C,); sh[tb + ".norm2.bias"] = (C,)
+            sh[tb + ".norm1.weight"] = (C,); sh[tb + ".norm1.bias"] = (C,)
+            sh[tb + ".norm3.weight"] = (C,); sh[tb + ".norm3.bias"] = (C,)
+    sh["norm.weight"] = (C,); sh["norm.bias"] = (C,)
+    return sh
+
+
 def vae_param_shapes(ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2, z_channels=4, out_ch=3):
     """SD VAE decoder in the vendored-ldm key layout (ldm/modules/diffusionmodules/model.py:462-533) + post_quant_conv."""
     sh: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
@@ -156,8 +178,10 @@ def synth_tensor(name: str, shape, device="cpu", gain: float = 1.0) -> torch.Ten
         return (1.0 / (10000 ** (torch.arange(0, dim, 2)[: dim // 2].float() / dim))).to(device)
     u = _hash_uniform(name, n, device)
     leaf = name.rsplit(".", 1)[-1]
-    is_norm = any(t in name for t in (".norm", "norm1", "norm2", "norm3", "norm_out", "group_norm"))
-    if is_norm and leaf == "weight":
+    is_norm = any(t in name for t in (".norm", "norm1", "norm2", "norm3", "norm_out", "group_norm")) or name.startswith("norm.")
+    if leaf in ("learnable_query", "pos_embed"):      # FSTextTransformer tokens: O(1) values (zero-initialised in the reference)
+        val = u - 0.5
+    elif is_norm and leaf == "weight":
         val = 1.0 + 0.2 * (u - 0.5)
     elif leaf == "bias":
         val = 0.1 * (u - 0.5)

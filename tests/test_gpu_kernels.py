@@ -231,6 +231,7 @@ def _attn_ref(q, k, v, causal):
     (40, 128, 128, False), (40, 1024, 1024, False), (80, 256, 256, False), (160, 64, 64, False), (160, 16, 16, False),
     (40, 1024, 77, False), (80, 256, 77, False), (160, 64, 77, False), (160, 16, 77, False),
     (40, 768, 768, True), (80, 192, 192, True), (160, 192, 192, True), (40, 100, 100, True), (80, 272, 272, True),
+    (96, 77, 77, False), (96, 924, 77, False), (96, 12, 12, True), (96, 200, 200, True),     # FSTextTransformer head dim
 ])
 def test_attention(device, d, Sq, Sk, causal):
     from seervideoldm_amd import ops
@@ -258,6 +259,21 @@ def test_attention_fused_qkv_layout(device):
     q, k, v = [t.reshape(B, S, Hh, d).permute(0, 2, 1, 3) for t in qkv.split(C, dim=1)]
     ref = _attn_ref(q, k, v, False).permute(0, 2, 1, 3).reshape(B * S, C)
     _close(out, ref, rtol=2e-2, atol=1e-2, what="fused-qkv attention")
+
+
+def test_attention_strided_sequences(device):
+    """rows ordered (frame, token): causal attention over the frames of every token position, read through strides
+    (seq stride = tokens per frame, batch stride = one row) -- FSTextTransformer's temporal block"""
+    from seervideoldm_amd import ops
+    Fr, L, Hh, d = 12, 77, 8, 96
+    C = Hh * d
+    qkv = _rand((Fr * L, 3 * C), device, 5).to(bf16)
+    out = torch.zeros((Fr * L, C), device=device, dtype=bf16)
+    ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, batch=L, heads=Hh, head_dim=d, Sq=Fr, Sk=Fr,
+                  causal=True, seq_stride_rows=L, batch_stride_rows=1)
+    q, k, v = [t.reshape(Fr, L, Hh, d).permute(1, 2, 0, 3) for t in qkv.split(C, dim=1)]     # [L, heads, F, d]
+    ref = _attn_ref(q, k, v, True).permute(2, 0, 1, 3).reshape(Fr * L, C)
+    _close(out, ref, rtol=2e-2, atol=1e-2, what="strided-sequence attention")
 
 
 def test_attention_softmax_spike(device):

@@ -93,10 +93,20 @@ def _tok_index(batch, ws, Fr, H, W):
 
 
 def attention(q, k, v, out, *, batch, heads, head_dim, Sq, Sk, causal=False, scale=None, window=None, Fq=None,
-              causal_offset=0):
-    assert head_dim in (40, 80, 160), "the flash kernels are built for head_dim 40/80/160"
+              causal_offset=0, seq_stride_rows=1, batch_stride_rows=None):
+    assert head_dim in (40, 80, 96, 160), "the flash kernels are built for head_dim 40/80/96/160"
     C = heads * head_dim
     scale = head_dim ** -0.5 if scale is None else scale
+    if batch_stride_rows is not None:
+        # row(b, s) = b*batch_stride_rows + s*seq_stride_rows: gather to the contiguous form, run, scatter back
+        assert window is None
+        rq = (torch.arange(batch)[:, None] * batch_stride_rows + torch.arange(Sq)[None] * seq_stride_rows).reshape(-1)
+        rk = (torch.arange(batch)[:, None] * batch_stride_rows + torch.arange(Sk)[None] * seq_stride_rows).reshape(-1)
+        tmp = torch.empty((batch * Sq, C), dtype=bf16)
+        attention(q[rq], k[rk], v[rk], tmp, batch=batch, heads=heads, head_dim=head_dim, Sq=Sq, Sk=Sk, causal=causal,
+                  scale=scale, causal_offset=causal_offset)
+        out[rq, :C] = tmp
+        return out
     if window is None:
         qq = q[:, :C].float().reshape(batch, Sq, heads, head_dim).permute(0, 2, 1, 3)
         kk = k[:, :C].float().reshape(batch, Sk, heads, head_dim).permute(0, 2, 1, 3)
