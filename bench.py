@@ -260,10 +260,21 @@ def main():
             torch.cuda.synchronize()
             t_fst = time.perf_counter() - t0
         assert ctx_out.shape == (w["b"], w["frames"], 77, 768) and torch.isfinite(ctx_out).all()
+        # ... and the VAE encode of the conditioning frames (2 x 256x256 -> x0_emb latents), also once per sample
+        vae.load_state_dict(ldm_to_diffusers_vae(synth.synth_state_dict(synth.vae_encoder_param_shapes(), device=device), 4))
+        frames = torch.tanh(torch.randn((w["b"] * w["cond_frames"], 3, 8 * w["latent"], 8 * w["latent"]), device=device))
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            lat = vae.encode(frames).latent_dist.sample() * 0.18215
+            torch.cuda.synchronize()
+            t_enc = time.perf_counter() - t0
+        assert lat.shape == (w["b"] * w["cond_frames"], 4, w["latent"], w["latent"]) and torch.isfinite(lat).all()
         clip = dict(clip_latency_ms=round(t_clip * 1e3, 2), vae_decode_ms=round(t_dec * 1e3, 2),
-                    fstext_ms=round(t_fst * 1e3, 2),
+                    fstext_ms=round(t_fst * 1e3, 2), vae_encode_ms=round(t_enc * 1e3, 2),
                     what="50-step ddim_sample incl. decode of 10 frames to 256x256 (full SD-VAE decoder, synthetic weights); "
-                         "fstext_ms = FSTextTransformer (8 layers, 182.6M params) producing the [1,12,77,768] context, once per sample")
+                         "once per sample before it: fstext_ms = FSTextTransformer (8 layers, 182.6M params) -> context "
+                         "[1,12,77,768]; vae_encode_ms = SD-VAE encoder on the 2 conditioning frames -> x0_emb")
 
     cpu = None
     if sd_cpu is not None:

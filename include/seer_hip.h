@@ -85,6 +85,10 @@ typedef struct seer_gemm_desc {
      * rot_dim are rotated (interleaved pairs) */
     const float* rot_table;
     int32_t rot_tokens_per_batch, rot_pos_offset, rot_head_dim, rot_dim, rot_cols;
+    /* CONV3X3 padding: 0 = one pixel on every side (every conv of the UNet and the VAE decoder); 1 = only after the last row
+     * and column, X[img, oy*stride+ky, ox*stride+kx, ci] -- the VAE encoder's Downsample, F.pad(x, (0,1,0,1)) + conv(stride 2,
+     * padding 0) (ldm/modules/diffusionmodules/model.py:60-78) */
+    int32_t pad_after_only;
 } seer_gemm_desc;
 
 #define SEER_TILE_AUTO 0
@@ -221,6 +225,13 @@ int seer_cfg_ddim_step(const float* eps, int32_t cfg, int32_t b, int32_t C, int3
 
 /* decoded image post-process of ddim_sample (utils/ddim_sampling_utils.py:41): clamp((x+1)/2, 0, 1) in place */
 int seer_clamp01(float* x, int64_t n, void* stream);
+
+/* VAE encode, the step before the path: DiagonalGaussianDistribution.sample
+ * (ldm/modules/distributions/distributions.py:24-37; diffusers AutoencoderKL.encode(x).latent_dist.sample(),
+ * inference_img.py:168): moments fp32 [N, 2C, HW] = (mean | logvar) along channels ->
+ *   out[n, c, i] = mean + exp(0.5 * clamp(logvar, -30, 20)) * noise[n, c, i]        (noise NULL: the mode) */
+int seer_gaussian_sample(const float* moments, int32_t N, int32_t C, int32_t HW, const float* noise, float* out,
+                         void* stream);
 
 #ifdef __cplusplus
 }

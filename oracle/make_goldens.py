@@ -144,6 +144,7 @@ def main():
     _save("ddim_sample_tiny.npz", start_code=noise, x0_emb=x0_emb, c=c, uc=uc, latent=lat, clip=clip)
 
     gen_fstext(ref)
+    gen_vae_encode(ref)
 
 
 TINY_FSTEXT = dict(num_frames=6, num_layers=2, channels=192, n_heads=2, cross_attention_dim=192)
@@ -169,8 +170,32 @@ def gen_fstext(ref):
     _save("fstext_tiny.npz", context=ctx, **out)
 
 
+@torch.no_grad()
+def gen_vae_encode(ref):
+    """7. VAE encoder (vendored twin, ldm/modules/diffusionmodules/model.py:368-460) + quant_conv + the reference's
+    DiagonalGaussianDistribution.sample (ldm/modules/distributions/distributions.py:24-37) under a fixed seed."""
+    from ldm.modules.distributions.distributions import DiagonalGaussianDistribution
+    enc = ref.vae.Encoder(ch=TINY_VAE["ch"], out_ch=3, ch_mult=TINY_VAE["ch_mult"], num_res_blocks=TINY_VAE["num_res_blocks"],
+                          attn_resolutions=[], in_channels=3, resolution=64, z_channels=4, double_z=True).eval()
+    shapes = synth.vae_encoder_param_shapes(ch=TINY_VAE["ch"], ch_mult=TINY_VAE["ch_mult"],
+                                            num_res_blocks=TINY_VAE["num_res_blocks"], z_channels=4)
+    sd = synth.synth_state_dict(shapes)
+    enc.load_state_dict({k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}, strict=True)
+    qc = torch.nn.Conv2d(8, 8, 1)
+    qc.load_state_dict({"weight": sd["quant_conv.weight"], "bias": sd["quant_conv.bias"]})
+    x = _randn((2, 3, 64, 64), 70)
+    moments = qc(enc(x))
+    torch.manual_seed(71)
+    sample = DiagonalGaussianDistribution(moments).sample()
+    torch.manual_seed(71)
+    noise = torch.randn(sample.shape)
+    _save("vae_enc_tiny.npz", x=x, moments=moments, noise=noise, sample=sample)
+
+
 if __name__ == "__main__":
     if "fstext" in sys.argv[1:]:
         gen_fstext(ref_import.load_reference())
+    elif "vae_encode" in sys.argv[1:]:
+        gen_vae_encode(ref_import.load_reference())
     else:
         main()

@@ -395,3 +395,31 @@ def fstext_forward(sd: SD, context, num_frames: int, heads: int = 8):
         h = feed_forward(sd, p + ".ff", _ln(sd, p + ".norm3", h)) + h
         x = h.reshape(b, l, Fr, c).permute(0, 2, 1, 3)
     return _ln(sd, "norm", x)
+
+
+# ------------------------------------------------------------------------------------------------ VAE encoder
+# conditioning frames -> latents x0_emb (inference_img.py:166-170)
+def vae_encode_moments(sd: SD, x, ch_mult=(1, 2, 4, 4), num_res_blocks=2):
+    """Encoder.forward (ldm/modules/diffusionmodules/model.py:432-460) + quant_conv (ldm/models/autoencoder.py:324-328);
+    ldm key names (`encoder.` prefix, `quant_conv.`).  Returns the moments [N, 2*z, h, w] = (mean | logvar)."""
+    P = "encoder."
+    h = F.conv2d(x, sd[P + "conv_in.weight"], sd[P + "conv_in.bias"], padding=1)
+    nres = len(ch_mult)
+    for lvl in range(nres):
+        for j in range(num_res_blocks):
+            h = _vae_resnet(sd, f"{P}down.{lvl}.block.{j}", h)
+        if lvl != nres - 1:      # Downsample: pad (0,1,0,1) then conv stride 2, padding 0 (model.py:60-78)
+            h = F.conv2d(F.pad(h, (0, 1, 0, 1)), sd[f"{P}down.{lvl}.downsample.conv.weight"],
+                         sd[f"{P}down.{lvl}.downsample.conv.bias"], stride=2)
+    h = _vae_resnet(sd, P + "mid.block_1", h)
+    h = _vae_attn(sd, P + "mid.attn_1", h)
+    h = _vae_resnet(sd, P + "mid.block_2", h)
+    h = F.silu(_vae_norm(sd, P + "norm_out", h))
+    h = F.conv2d(h, sd[P + "conv_out.weight"], sd[P + "conv_out.bias"], padding=1)
+    return F.conv2d(h, sd["quant_conv.weight"], sd["quant_conv.bias"])
+
+
+def gaussian_sample(moments, noise):
+    """DiagonalGaussianDistribution (ldm/modules/distributions/distributions.py:24-37): mean + std * noise"""
+    mean, logvar = moments.chunk(2, dim=1)
+    return mean + torch.exp(0.5 * logvar.clamp(-30.0, 20.0)) * noise

@@ -13,7 +13,7 @@ _PKG = Path(__file__).resolve().parent
 _LIB_PATH = _PKG / "lib" / "libseer_hip.so"
 _lib = None
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 SEER_GEMM_PLAIN = 0
 SEER_GEMM_CONV3X3 = 1
@@ -44,6 +44,7 @@ class GemmDesc(C.Structure):
         ("tile", C.c_int32), ("splits", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("rot_table", C.c_void_p), ("rot_tokens_per_batch", C.c_int32), ("rot_pos_offset", C.c_int32),
         ("rot_head_dim", C.c_int32), ("rot_dim", C.c_int32), ("rot_cols", C.c_int32),
+        ("pad_after_only", C.c_int32),
     ]
 
 
@@ -86,6 +87,7 @@ SIGNATURES = {
     "seer_nhwc_bf16_to_nchw_f32": ([_vp, _i32, _i32, _i32, _vp, _vp], C.c_int),
     "seer_cfg_ddim_step": ([_vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i32, _vp, _vp, _vp, _vp, _vp], C.c_int),
     "seer_clamp01": ([_vp, _i64, _vp], C.c_int),
+    "seer_gaussian_sample": ([_vp, _i32, _i32, _i32, _vp, _vp, _vp], C.c_int),
 }
 
 

@@ -333,6 +333,22 @@ __global__ void clamp01_kernel(float* __restrict__ x, int64_t n) {
     }
 }
 
+// DiagonalGaussianDistribution.sample: moments [N, 2C, HW] = (mean | logvar)
+__global__ void gaussian_sample_kernel(const float* __restrict__ mom, int C, int HW, const float* __restrict__ noise,
+                                       float* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t chw = (int64_t)C * HW;
+    const int64_t img = i / chw, r = i - img * chw;
+    const float mean = mom[img * 2 * chw + r];
+    float v = mean;
+    if (noise) {
+        const float logvar = fminf(fmaxf(mom[img * 2 * chw + chw + r], -30.0f), 20.0f);
+        v = fmaf(__expf(0.5f * logvar), noise[i], mean);
+    }
+    out[i] = v;
+}
+
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace
@@ -495,7 +511,17 @@ extern "C" int seer_clamp01(float* x, int64_t n, void* stream) {
     return SEER_OK;
 }
 
-extern "C" int seer_abi_version(void) { return 5; }
+extern "C" int seer_gaussian_sample(const float* moments, int32_t N, int32_t C, int32_t HW, const float* noise, float* out,
+                                    void* stream) {
+    if (!moments || !out || N <= 0 || C <= 0 || HW <= 0) return SEER_EINVAL;
+    const int64_t n = (int64_t)N * C * HW;
+    hipLaunchKernelGGL(gaussian_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), moments, C, HW,
+                       noise, out, n);
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int seer_abi_version(void) { return 6; }
 extern "C" const char* seer_build_arch(void) { return "gfx950"; }
 extern "C" const char* seer_strerror(int code) {
     switch (code) {

@@ -92,8 +92,9 @@ __global__ void __launch_bounds__(128 * WM) seer_gemm_kernel(const seer_gemm_des
             const int img = gm / hw;
             const int rem = gm - img * hw;
             const int oy = rem / p.Wout;
-            a_oy[i] = oy * p.stride - 1;
-            a_ox[i] = (rem - oy * p.Wout) * p.stride - 1;
+            const int pad0 = p.pad_after_only ? 0 : 1;     // rows / columns of padding before the image
+            a_oy[i] = oy * p.stride - pad0;
+            a_ox[i] = (rem - oy * p.Wout) * p.stride - pad0;
             a_off[i] = (int64_t)img * p.Hin * p.Win * p.Cin;
             a_off2[i] = 0;
         } else {

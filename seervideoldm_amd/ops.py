@@ -129,15 +129,17 @@ def gemm_batched(a: torch.Tensor, w: torch.Tensor, *, trans_out=False, out: Opti
 
 def conv3x3(x: torch.Tensor, w: torch.Tensor, n_img: int, Hin: int, Win: int, *, stride=1, upsample=False,
             bias=None, residual=None, rowvec=None, rows_per_batch=0, out: Optional[torch.Tensor] = None,
-            tile=0, splits=0) -> torch.Tensor:
-    """x: channels-last [n_img*Hin*Win, Cin] bf16; w: [Cout, 9*Cin] ((ky,kx,ci) order). Returns [n_img*Ho*Wo, Cout]."""
+            tile=0, splits=0, pad_after_only=False) -> torch.Tensor:
+    """x: channels-last [n_img*Hin*Win, Cin] bf16; w: [Cout, 9*Cin] ((ky,kx,ci) order). Returns [n_img*Ho*Wo, Cout].
+    pad_after_only: zero padding of one row / column only after the image (the VAE encoder's Downsample)."""
     _req(x, bf16, "x"); _req(w, bf16, "w")
     assert x.is_contiguous() and w.is_contiguous()
     Cin = x.shape[1]
     Cout, K = w.shape
     assert K == 9 * Cin and x.shape[0] == n_img * Hin * Win
     Hs, Ws = (2 * Hin, 2 * Win) if upsample else (Hin, Win)
-    Ho, Wo = (Hs + 2 - 3) // stride + 1, (Ws + 2 - 3) // stride + 1
+    pad = 1 if pad_after_only else 2
+    Ho, Wo = (Hs + pad - 3) // stride + 1, (Ws + pad - 3) // stride + 1
     M = n_img * Ho * Wo
     d = GemmDesc()
     d.A, d.W = _p(x), _p(w)
@@ -156,6 +158,7 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, n_img: int, Hin: int, Win: int, *,
         d.rowvec, d.rowvec_ld, d.rows_per_batch = _p(rowvec), rowvec.stride(0), rows_per_batch
     d.mode = _lib.SEER_GEMM_CONV3X3
     d.Hin, d.Win, d.Cin, d.Hout, d.Wout, d.stride, d.upsample = Hin, Win, Cin, Ho, Wo, stride, int(upsample)
+    d.pad_after_only = int(pad_after_only)
     d.batch = 1
     d.tile = tile
     d.splits = splits
@@ -398,3 +401,17 @@ def clamp01_(x: torch.Tensor) -> torch.Tensor:
     assert x.is_contiguous()
     check(_lib.load().seer_clamp01(_p(x), x.numel(), _stream()), "seer_clamp01")
     return x
+
+
+def gaussian_sample(moments: torch.Tensor, noise: Optional[torch.Tensor]) -> torch.Tensor:
+    """moments fp32 [N, 2C, H, W] (mean | logvar) -> mean + exp(0.5 clamp(logvar, -30, 20)) * noise (noise None: the mean)."""
+    _req(moments, torch.float32, "moments")
+    assert moments.is_contiguous() and moments.dim() == 4 and moments.shape[1] % 2 == 0
+    N, C2, H, W = moments.shape
+    out = torch.empty((N, C2 // 2, H, W), device=moments.device, dtype=torch.float32)
+    if noise is not None:
+        _req(noise, torch.float32, "noise")
+        assert noise.shape == out.shape and noise.is_contiguous()
+    check(_lib.load().seer_gaussian_sample(_p(moments), N, C2 // 2, H * W, _p(noise), _p(out), _stream()),
+          "seer_gaussian_sample")
+    return out

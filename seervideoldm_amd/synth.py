@@ -161,6 +161,41 @@ def vae_param_shapes(ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2, z_channels=
     return sh
 
 
+def vae_encoder_param_shapes(ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2, z_channels=4, in_channels=3):
+    """SD VAE encoder in the vendored-ldm key layout (ldm/modules/diffusionmodules/model.py:368-431) + quant_conv."""
+    sh: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    P = "encoder."
+
+    def res(p, cin, cout):
+        sh[p + ".norm1.weight"] = (cin,); sh[p + ".norm1.bias"] = (cin,)
+        sh[p + ".conv1.weight"] = (cout, cin, 3, 3); sh[p + ".conv1.bias"] = (cout,)
+        sh[p + ".norm2.weight"] = (cout,); sh[p + ".norm2.bias"] = (cout,)
+        sh[p + ".conv2.weight"] = (cout, cout, 3, 3); sh[p + ".conv2.bias"] = (cout,)
+        if cin != cout:
+            sh[p + ".nin_shortcut.weight"] = (cout, cin, 1, 1); sh[p + ".nin_shortcut.bias"] = (cout,)
+
+    sh[P + "conv_in.weight"] = (ch, in_channels, 3, 3); sh[P + "conv_in.bias"] = (ch,)
+    block_in = ch
+    for lvl, m in enumerate(ch_mult):
+        block_out = ch * m
+        for j in range(num_res_blocks):
+            res(f"{P}down.{lvl}.block.{j}", block_in, block_out)
+            block_in = block_out
+        if lvl != len(ch_mult) - 1:
+            sh[f"{P}down.{lvl}.downsample.conv.weight"] = (block_in, block_in, 3, 3)
+            sh[f"{P}down.{lvl}.downsample.conv.bias"] = (block_in,)
+    res(P + "mid.block_1", block_in, block_in)
+    a = P + "mid.attn_1"
+    sh[a + ".norm.weight"] = (block_in,); sh[a + ".norm.bias"] = (block_in,)
+    for nme in ("q", "k", "v", "proj_out"):
+        sh[f"{a}.{nme}.weight"] = (block_in, block_in, 1, 1); sh[f"{a}.{nme}.bias"] = (block_in,)
+    res(P + "mid.block_2", block_in, block_in)
+    sh[P + "norm_out.weight"] = (block_in,); sh[P + "norm_out.bias"] = (block_in,)
+    sh[P + "conv_out.weight"] = (2 * z_channels, block_in, 3, 3); sh[P + "conv_out.bias"] = (2 * z_channels,)
+    sh["quant_conv.weight"] = (2 * z_channels, 2 * z_channels, 1, 1); sh["quant_conv.bias"] = (2 * z_channels,)
+    return sh
+
+
 def _hash_uniform(name: str, n: int, device) -> torch.Tensor:
     """closed-form u[i] in [0,1): frac(sin(i*a + h(name)) * b), float64 arithmetic."""
     h = (zlib.crc32(name.encode()) % 100003) * 0.001

@@ -199,6 +199,22 @@ def test_conv3x3(device, n_img, H, W, Ci, Co, stride, up, tile):
     _close(out, ref_cl, what=f"conv {Ci}->{Co} s{stride} up{up}")
 
 
+@pytest.mark.parametrize("tile", [0, 2, 7, 8])
+def test_conv3x3_pad_after_only(device, tile):
+    """the VAE encoder's Downsample: F.pad(x, (0,1,0,1)) + conv(stride 2, padding 0) (ldm .../model.py:60-78)"""
+    from seervideoldm_amd import ops
+    from seervideoldm_amd.weights import pack_conv3x3
+    n_img, H, W, Ci, Co = 3, 16, 24, 128, 64
+    x = _rand((n_img, Ci, H, W), device, 1).to(bf16)
+    w = _rand((Co, Ci, 3, 3), device, 2, (9 * Ci) ** -0.5).to(bf16)
+    bias = _rand((Co,), device, 3)
+    x_cl = x.permute(0, 2, 3, 1).reshape(-1, Ci).contiguous()
+    out = ops.conv3x3(x_cl, pack_conv3x3(w), n_img, H, W, stride=2, pad_after_only=True, bias=bias, tile=tile, splits=1)
+    ref = Fn.conv2d(Fn.pad(x.float(), (0, 1, 0, 1)), w.float(), bias, stride=2, padding=0)
+    assert out.shape[0] == n_img * (H // 2) * (W // 2)
+    _close(out, ref.permute(0, 2, 3, 1).reshape(-1, Co), what="conv s2 padded after only")
+
+
 def test_conv3x3_epilogue(device):
     from seervideoldm_amd import ops
     from seervideoldm_amd.weights import pack_conv3x3
