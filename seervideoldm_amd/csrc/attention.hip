@@ -20,6 +20,19 @@
 
 namespace {
 
+// measurement-only builds (scripts/probe_attn.sh; results are WRONG): bit 0 = no v_exp (the scaled score is used as is),
+// bit 1 = no PV MFMAs, bit 2 = no QK^T MFMAs, bit 3 = K/V tile staged once (no per-tile loads / commits / barriers).
+#ifndef SEER_ATTN_PROBE
+#define SEER_ATTN_PROBE 0
+#endif
+
+// head dims up to this value issue both QK^T products of an LDS tile before the first softmax (see the K loop).
+// Measured on MI355X (profiles/r01_attention_pipe.log): 5-8 % SLOWER at d = 40 -- the second score tile costs 30 VGPRs and
+// with them the fourth wave per SIMD, and the waves of a SIMD already overlap each other's MFMA and VALU phases -> off.
+#ifndef SEER_ATTN_PIPE_MAXD
+#define SEER_ATTN_PIPE_MAXD 0
+#endif
+
 constexpr int KT = 64;            // keys per LDS tile
 constexpr float kNegInf = -__builtin_inff();
 
@@ -196,22 +209,27 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
     }
 
     for (int t = 0; t < ntiles; ++t) {
+#if SEER_ATTN_PROBE & 8
+        if (t == 0) { commit(0); __syncthreads(); }
+#else
         if constexpr (!DBUF) {
             __syncthreads();          // every wave finished reading the previous tile
             commit(0);
             __syncthreads();
         }
         if (t + 1 < ntiles) prefetch(t + 1);
+#endif
         const bf16* Ks = lds + (DBUF ? (t & 1) : 0) * C::BUF;
         const bf16* Vs = Ks + KT * C::KRS;
         const int kt0 = t * KT;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            if (!wave_active) continue;
+        // The two 32-key sub tiles of the LDS tile, one after the other -- or (SEER_ATTN_PIPE_MAXD, off by default) both QK^T
+        // products first so that the matrix pipe works on sub tile 1 under the softmax of sub tile 0.
+        auto sub_valid = [&](int sub) {
             const int kb = kt0 + sub * 32;                 // first key of this 32-key sub tile
-            if (kb >= k_end) continue;
-            if (p.causal && kb > q0 + 31 + q_off) continue; // wave-uniform: fully above the diagonal
-
+            // wave-uniform: past the last key / fully above the causal diagonal
+            return wave_active && kb < k_end && !(p.causal && kb > q0 + 31 + q_off);
+        };
+        auto qk = [&](int sub) {
             // ---- S^T = K Q^T  (rows = keys, cols = queries)
             f32x16 sacc;
 #pragma unroll
@@ -220,9 +238,20 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
             bf16x8 kf[C::KSTEPS];            // all K fragments first: one exposed LDS latency per sub tile, not one per step
 #pragma unroll
             for (int s = 0; s < C::KSTEPS; ++s) kf[s] = *reinterpret_cast<const bf16x8*>(krow + 16 * s);
+#if SEER_ATTN_PROBE & 4
+#pragma unroll
+            for (int s = 0; s < C::KSTEPS; ++s)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) sacc[r] += (float)kf[s][r] + (float)qf[s][r];
+#else
 #pragma unroll
             for (int s = 0; s < C::KSTEPS; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], sacc, 0, 0, 0);
+#endif
 
+            return sacc;
+        };
+        auto softmax_pv = [&](int sub, f32x16 sacc) {
+            const int kb = kt0 + sub * 32;
             // ---- scale (+ mask on boundary tiles)
             const bool need_mask = (kb + 31 >= p.Sk) || (p.causal && (kb + 31 > q0 + q_off));
             // raw scores stay unscaled: max in the raw domain (cscale > 0), then p = exp2(fma(s, cscale, -m)) -- one FMA
@@ -251,8 +280,13 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {       // v_pk_fma_f32: two scores per instruction
                     const f32x2 t = __builtin_elementwise_fma(f32x2{sacc[r], sacc[r + 1]}, c2, nm2);
+#if SEER_ATTN_PROBE & 1
+                    sacc[r] = t[0];
+                    sacc[r + 1] = t[1];
+#else
                     sacc[r] = __builtin_amdgcn_exp2f(t[0]);
                     sacc[r + 1] = __builtin_amdgcn_exp2f(t[1]);
+#endif
                 }
             }
             if constexpr (!LSUM_MFMA) {
@@ -294,9 +328,24 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
                     bf16x8 vf;
                     vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
                     vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+#if SEER_ATTN_PROBE & 2
+                    oacc[tt][s2] += (float)vf[0] + (float)pf[s2][tt];
+#else
                     oacc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], oacc[tt], 0, 0, 0);
+#endif
                 }
             }
+        };
+        const bool v0 = sub_valid(0), v1 = sub_valid(1);
+        if constexpr (D <= SEER_ATTN_PIPE_MAXD) {
+            f32x16 s0, s1;
+            if (v0) s0 = qk(0);
+            if (v1) s1 = qk(1);
+            if (v0) softmax_pv(0, s0);
+            if (v1) softmax_pv(1, s1);
+        } else {                       // larger head dims: the second score tile costs a wave of occupancy
+            if (v0) softmax_pv(0, qk(0));
+            if (v1) softmax_pv(1, qk(1));
         }
         if constexpr (DBUF) {
             if (t + 1 < ntiles) commit((t + 1) & 1);
