@@ -163,6 +163,32 @@ class AutoencoderKL(nn.Module):
         self._w: Optional[Dict[str, torch.Tensor]] = None
         self._loaded = {"encoder": False, "decoder": False}
 
+    config_name = "config.json"
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, revision=None, **kw):
+        """diffusers semantics (inference_img.py:69: `AutoencoderKL.from_pretrained(model, subfolder="vae")`): read
+        config.json (unknown keys ignored), load `diffusion_pytorch_model.{safetensors,bin}` by name."""
+        import inspect
+        import json
+        import os
+        root = os.path.join(path, subfolder) if subfolder else path
+        with open(os.path.join(root, cls.config_name)) as f:
+            cfg = json.load(f)
+        allowed = set(inspect.signature(cls.__init__).parameters) - {"self", "ignored"}
+        model = cls(**{k: v for k, v in cfg.items() if k in allowed})
+        for fname in ("diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.bin", "pytorch_model.bin"):
+            fp = os.path.join(root, fname)
+            if os.path.exists(fp):
+                if fname.endswith(".safetensors"):
+                    from safetensors.torch import load_file
+                    sd = load_file(fp)
+                else:
+                    sd = torch.load(fp, map_location="cpu")
+                model.load_state_dict(sd, strict=True)
+                return model
+        raise FileNotFoundError(f"no weight file under {root}")
+
     def load_state_dict(self, state_dict, strict=True, **kw):
         """a checkpoint may carry the decoder half, the encoder half or both (the hot path only needs the decoder);
         `strict` applies to each half that is present."""

@@ -48,6 +48,22 @@ def test_key_layout_conversion_and_partial_checkpoints():
     assert vae._loaded == {"encoder": True, "decoder": True}
 
 
+def test_from_pretrained_layout(tmp_path):
+    """`AutoencoderKL.from_pretrained(model, subfolder="vae")` (inference_img.py:69): config.json + weights by name"""
+    import json
+    cfgd = dict(_class_name="AutoencoderKL", in_channels=3, out_channels=3, block_out_channels=[32, 64], layers_per_block=1,
+                latent_channels=4, norm_num_groups=8, sample_size=64, act_fn="silu")
+    src = AutoencoderKL(block_out_channels=(32, 64), layers_per_block=1, norm_num_groups=8)
+    sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in src.state_dict().items()})
+    (tmp_path / "vae").mkdir()
+    (tmp_path / "vae" / "config.json").write_text(json.dumps(cfgd))
+    torch.save(sd, tmp_path / "vae" / "diffusion_pytorch_model.bin")
+    vae = AutoencoderKL.from_pretrained(str(tmp_path), subfolder="vae")
+    assert vae.config.block_out_channels == (32, 64) and vae._loaded == {"encoder": True, "decoder": True}
+    for k, v in vae.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+
+
 # ---------------------------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,H,W", [(2, 64, 64), (1, 64, 128)])     # (H/8)*(W/8) % 64 == 0: K of the mid attention's p @ v GEMM
