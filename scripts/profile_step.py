@@ -1,4 +1,7 @@
-"""Per-shape time table of one full-size denoising step (HIP-event timed launches). Run on the GPU box."""
+"""Per-shape time table of one full-size denoising step (HIP-event timed launches). Run on the GPU box.
+
+    python scripts/profile_step.py [guidance_scale=7.5] [frames=12]
+scale 1.0 drops the unconditional half (B = 1: the per-rank work of a 2-GPU CFG split); fewer frames approximate a frame shard."""
 import sys
 from pathlib import Path
 
@@ -13,11 +16,14 @@ dev = torch.device("cuda:0")
 cfg = dict(synth.SD15_UNET_CFG)
 model = SeerUNet(**cfg).to(dev)
 model.load_state_dict(synth.synth_state_dict(synth.unet_param_shapes(cfg), device=dev), strict=True)
+scale = float(sys.argv[1]) if len(sys.argv) > 1 else 7.5
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else bench.WORKLOAD["frames"]
+bench.WORKLOAD["frames"] = frames
 x_T, x0_emb, c, uc = bench.build_inputs(dev)
 smp = DDIMSampler(dev)
 smp.make_schedule(50, verbose=False)
 ts = smp._t_table[49].expand(1)
-step = lambda: smp.p_sample_ddim(model, x_T, c, ts, index=49, x0_emb=x0_emb, unconditional_guidance_scale=7.5,
+step = lambda: smp.p_sample_ddim(model, x_T, c, ts, index=49, x0_emb=x0_emb, unconditional_guidance_scale=scale,
                                  unconditional_conditioning=uc)
 step()
 timed = TimedOps()

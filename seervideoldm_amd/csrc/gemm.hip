@@ -632,9 +632,7 @@ int launch_split(const seer_gemm_desc& d, hipStream_t st) {
     if (d.tile == SEER_TILE_64x64) return launch_split_tile<64, 64, 0>(d, st);        // register-staged (A/B testing)
     if (d.tile == SEER_TILE_G64x64_3) return launch_split_tile<64, 64, 3>(d, st);
     if (d.tile == SEER_TILE_G128x128_2) return launch_split_tile<128, 128, 2>(d, st);
-    // auto: the 8x8-level convs (M = 1536, N = 1280) have enough rows for 128x128 tiles once K is sliced 4 ways
-    // (0.5x the L2->LDS traffic per FLOP of 64x64); the 4x4 level (M = 384) keeps 64x64
-    if ((d.M >= 1024 || d.splits >= 12) && d.N >= 1024 && d.N % 128 == 0) return launch_split_tile<128, 128, 2>(d, st);
+    // auto: prepare() already wrote its tile choice into d.tile; anything else keeps the 64x64 ring
     return launch_split_tile<64, 64, 3>(d, st);
 }
 
@@ -678,12 +676,25 @@ int prepare(seer_gemm_desc& d, int* splits) {
         if (d.splits > 1) {
             s = d.splits < nk ? d.splits : nk;
         } else if (d.splits == 0) {
-            // measured on MI355X (profiles/r01_splitk_sweep.log): the reduce pass + second launch cost ~4-5 us, so
-            // splitting pays only when a slice still has >= 10 K tiles and the unsplit grid leaves most CUs idle
-            const long blocks = (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
-            if (blocks <= 160 && nk >= 160) s = 16;            // 4x4 level convs: 128x128 tiles x 16 slices (r01_splitk_m384_sweep.log)
-            else if (blocks <= 160 && nk >= 40) s = nk / 20 < 8 ? nk / 20 : 8;
-            else if (blocks <= 512 && nk >= 80) s = 4;      // M = 1536: 128x128 tiles x 4 K slices (profiles/r01_splitk_tile_sweep.log)
+            // measured on MI355X (profiles/r01_splitk_sweep.log, r01_sweep_shapes.log): the reduce pass + second launch
+            // cost ~4-5 us, so splitting pays only when a slice keeps >= ~11 K tiles and the unsplit grid leaves CUs idle.
+            // Wide outputs (N a multiple of 128, >= 640): 128x128 tiles (half the L2->LDS bytes per FLOP of 64x64), K
+            // sliced until the grid holds ~2 blocks per CU -- the 16x16-level convs at B*F = 24 (x2), the 8x8 level (x4),
+            // the 4x4 level (x16) and, with fewer frames or one CFG half per rank, the same levels sliced deeper.
+            const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
+            int s128 = 1;
+            if (d.N % 128 == 0 && d.N >= 640 && d.M >= 256 && t128 < 256 && nk >= 64)
+                while (t128 * s128 < 400 && s128 < 16 && nk / (2 * s128) >= 11) s128 *= 2;
+            if (s128 > 1 && t128 * s128 >= 200 && d.tile == SEER_TILE_AUTO) {
+                s = s128;
+                d.tile = SEER_TILE_G128x128_2;
+            } else {
+                const long blocks = (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
+                if (blocks <= 160 && nk >= 160) s = blocks <= 40 ? 16 : 8;      // 4x4 / 8x8 level convs of a frame shard
+                else if (blocks <= 160 && nk >= 40) s = nk / 20 < 8 ? nk / 20 : 8;
+                else if (blocks <= 512 && nk >= 80) s = 4;
+                if (s > 1 && d.tile == SEER_TILE_AUTO) d.tile = SEER_TILE_G64x64_3;
+            }
         }
     }
     *splits = s;
@@ -713,6 +724,7 @@ extern "C" int seer_gemm_bf16(const seer_gemm_desc* desc, void* stream) {
         return launch_split(d, st);
     }
     d.splits = 1;
+    d.tile = desc->tile;            // prepare() may have picked a split tile; unsplit launches choose their own below
 
     int tile = d.tile;
     if (tile == SEER_TILE_AUTO) {
