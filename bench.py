@@ -32,6 +32,14 @@ import torch  # noqa: E402
 
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16
 WORKLOAD = dict(b=1, cond_frames=2, frames=12, latent=32, ddim_steps=50, scale=7.5)
+# BASELINE.json configs: [1] is the bench line (default); the others are parity-test cases that can be timed on request
+WORKLOADS = {
+    "sthv2": dict(WORKLOAD, name="Sthv2 config: CFG batch 2 x 12 frames (2 cond + 10 predicted) x 32x32 latent"),
+    "bridge": dict(b=4, cond_frames=1, frames=16, latent=32, ddim_steps=50, scale=7.5,
+                   name="Bridge config: CFG batch 8 x 16 frames (1 cond + 15 predicted) x 32x32 latent"),
+    "sthv2_512": dict(b=1, cond_frames=2, frames=12, latent=64, ddim_steps=50, scale=7.5,
+                      name="Sthv2 512^2 config: CFG batch 2 x 12 frames x 64x64 latent (4096-token spatial attention)"),
+}
 
 
 def parse():
@@ -42,6 +50,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="sthv2",
+                    help="default = BASELINE.json's metric configuration; the others are extra measurements")
     return ap.parse_args()
 
 
@@ -119,6 +129,7 @@ def cpu_baseline(sd_cpu, cfg, budget_s):
 
 def main():
     args = parse()
+    WORKLOAD.update({k: v for k, v in WORKLOADS[args.workload].items() if k != "name"})
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -211,6 +222,8 @@ def main():
         # scripts/pmc_summary.py; PMC cannot be collected from inside this process)
         traffic = None
         try:
+            if args.workload != "sthv2":
+                raise OSError("the PMC passes were taken on the default workload")
             pmc = json.load(open(ROOT / "profiles" / "r01_pmc_traffic.json"))
             traffic = round(pmc["kernels"]["seer_gemm_kernel"]["hbm_bytes_per_launch"])
         except (OSError, KeyError, ValueError):
@@ -283,11 +296,12 @@ def main():
     if rank == 0:
         par = "single" if world == 1 else shard.describe()
         line = {
-            "metric": "UNet denoising steps/sec (12-frame 256^2 latent, 50-step DDIM)",
+            "metric": "UNet denoising steps/sec (12-frame 256^2 latent, 50-step DDIM)" if args.workload == "sthv2"
+                      else f"UNet denoising steps/sec ({args.workload} workload, 50-step DDIM)",
             "value": round(1e3 / ms_per_step, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "Sthv2 config: CFG batch 2 x 12 frames (2 cond + 10 predicted) x 32x32 latent, "
+            "config": {"workload": WORKLOADS[args.workload]["name"] + ", "
                                    "full-width SeerUNet 1.08G params, 50-step DDIM, scale 7.5",
                        "parallelism": par, "hip_graph": bool(not args.no_graph)},
             "roofline": roofline, "cpu_baseline": cpu, "end_to_end": clip,
