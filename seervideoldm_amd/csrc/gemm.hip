@@ -64,7 +64,10 @@ __global__ void __launch_bounds__(128 * WM) seer_gemm_kernel(const seer_gemm_des
         const int q = nwg >> 3, r = nwg & 7;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
     }
-    constexpr int GM = 8;
+#ifndef SEER_GEMM_GM
+#define SEER_GEMM_GM 8          // M tiles per block group (sweep: profiles/r01_gemm_group_sweep.log)
+#endif
+    constexpr int GM = SEER_GEMM_GM;
     const int group = wg / (GM * tiles_n);
     const int first_m = group * GM;
     const int gsz = min(tiles_m - first_m, GM);
