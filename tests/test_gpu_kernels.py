@@ -92,6 +92,40 @@ def test_conv3x3_split_k(device):
         _close(ops.conv3x3(x_cl, pack_conv3x3(w), n_img, H, W, bias=bias, splits=s), ref, what=f"conv split {s}")
 
 
+def test_gemm_and_conv_random_shapes_auto_heuristics(device):
+    """seeded random shapes through the AUTO tile / split-K heuristics (ragged M, narrow and wide N, short and long K):
+    whatever configuration `prepare()` picks must give the same answer as the fp32 formula, deterministically"""
+    from seervideoldm_amd import ops
+    from seervideoldm_amd.weights import pack_conv3x3
+    rng = torch.Generator().manual_seed(1234)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=rng))
+    for it in range(36):
+        M = [ri(1, 300), ri(300, 2000), ri(2000, 9000)][it % 3]
+        N = 4 * ri(1, 40) if it % 4 else 128 * ri(5, 12)
+        K = 64 * [ri(1, 6), ri(6, 40), ri(40, 100)][(it // 3) % 3]
+        a = _rand((M, K), device, 10 + it).to(bf16)
+        w = _rand((N, K), device, 50 + it, K ** -0.5).to(bf16)
+        bias = _rand((N,), device, 90 + it) if it % 2 else None
+        res = _rand((M, N), device, 130 + it).to(bf16) if it % 3 == 0 else None
+        out = ops.gemm(a, w, bias=bias, residual=res)
+        ref = a.float() @ w.float().t() + (bias if bias is not None else 0) + (res.float() if res is not None else 0)
+        _close(out, ref, what=f"auto gemm {M}x{N}x{K}")
+        assert torch.equal(out, ops.gemm(a, w, bias=bias, residual=res)), f"gemm {M}x{N}x{K} not deterministic"
+    for it in range(14):
+        n_img, H, W = ri(1, 12), 2 * ri(1, 12), 2 * ri(1, 12)
+        Ci, Co = 64 * ri(1, 10), [4 * ri(2, 40), 128 * ri(5, 10)][it % 2]
+        stride, up = (2, False) if it % 5 == 0 else ((1, True) if it % 5 == 1 else (1, False))
+        x = _rand((n_img, Ci, H, W), device, 200 + it).to(bf16)
+        w = _rand((Co, Ci, 3, 3), device, 240 + it, (9 * Ci) ** -0.5).to(bf16)
+        bias = _rand((Co,), device, 280 + it)
+        x_cl = x.permute(0, 2, 3, 1).reshape(-1, Ci).contiguous()
+        out = ops.conv3x3(x_cl, pack_conv3x3(w), n_img, H, W, stride=stride, upsample=up, bias=bias)
+        xin = Fn.interpolate(x.float(), scale_factor=2.0, mode="nearest") if up else x.float()
+        ref = Fn.conv2d(xin, w.float(), bias, stride=stride, padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
+        _close(out, ref, what=f"auto conv n{n_img} {H}x{W} {Ci}->{Co} s{stride} up{up}")
+        assert torch.equal(out, ops.conv3x3(x_cl, pack_conv3x3(w), n_img, H, W, stride=stride, upsample=up, bias=bias))
+
+
 def test_gelu_erf_accuracy(device):
     """the GEGLU epilogue's exact-erf GELU (relu(x) - |x| * 2^(|x| R(|x|) - 1), seer_common.h) against F.gelu over the
     whole useful range: absolute error < 2e-6, and relative error < 2e-3 (half a bf16 ulp) wherever |gelu| > 1e-4"""
