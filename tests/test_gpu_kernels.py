@@ -311,6 +311,37 @@ def test_attention_fused_qkv_layout(device):
     _close(out, ref, rtol=2e-2, atol=1e-2, what="fused-qkv attention")
 
 
+def test_attention_random_shapes(device):
+    """seeded ragged sequence lengths (tails in the last query block and the last key tile), causal with a query offset"""
+    from seervideoldm_amd import ops
+    rng = torch.Generator().manual_seed(77)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=rng))
+    for it in range(16):
+        d = (40, 80, 96, 160)[it % 4]
+        B, Hh = ri(1, 3), ri(1, 8)
+        Sq, Sk = ri(1, 500), ri(1, 500)
+        causal = it % 3 == 0
+        off = 0
+        if causal:
+            Sk = max(Sk, Sq)
+            off = ri(0, Sk - Sq)
+        C = Hh * d
+        q = _rand((B, Sq, Hh, d), device, 300 + it).to(bf16)
+        k = _rand((B, Sk, Hh, d), device, 340 + it).to(bf16)
+        v = _rand((B, Sk, Hh, d), device, 380 + it).to(bf16)
+        out = torch.zeros((B * Sq, C), device=device, dtype=bf16)
+        ops.attention(q.reshape(B * Sq, C), k.reshape(B * Sk, C), v.reshape(B * Sk, C), out, batch=B, heads=Hh, head_dim=d,
+                      Sq=Sq, Sk=Sk, causal=causal, causal_offset=off)
+        qq, kk, vv = [t.permute(0, 2, 1, 3).float() for t in (q, k, v)]
+        s = torch.einsum("bhqd,bhkd->bhqk", qq, kk) * d ** -0.5
+        if causal:
+            i = torch.arange(Sq, device=device)[:, None] + off
+            j = torch.arange(Sk, device=device)[None, :]
+            s = s.masked_fill(~(j <= i), float("-inf"))
+        ref = torch.einsum("bhqk,bhkd->bhqd", s.softmax(-1), vv).permute(0, 2, 1, 3).reshape(B * Sq, C)
+        _close(out, ref, rtol=2e-2, atol=1e-2, what=f"attn d{d} B{B} H{Hh} {Sq}x{Sk} causal={causal}+{off}")
+
+
 def test_attention_strided_sequences(device):
     """rows ordered (frame, token): causal attention over the frames of every token position, read through strides
     (seq stride = tokens per frame, batch stride = one row) -- FSTextTransformer's temporal block"""
