@@ -140,9 +140,26 @@ typedef struct seer_attn_desc {
     /* causal: key j visible to query i iff j <= i + causal_offset (0 unless the queries are a frame shard whose first
      * query sits at sequence position causal_offset of the key sequence) */
     int32_t causal_offset;
+    /* optional (training): fp32 [batch' * heads][Sq] with batch' = batch (x windows); receives log2(sum_j 2^(scale*log2(e)*s_ij))
+     * per query, the statistic seer_attn_bwd needs to rebuild the probabilities.  NULL at inference. */
+    float* lse;
 } seer_attn_desc;
 
 int seer_attn_fwd(const seer_attn_desc* desc /* host */, void* stream);
+
+/* Backward of the call above (the training step, train.py:380-381 through attention.py:622-630 / 632-703):
+ * given dO, writes dQ, dK, dV (bf16, addressed like Q/K/V with their own strides, so they can be the column slices of one
+ * [tokens, 3C] gradient buffer that feeds a single dX GEMM).  fwd must be the descriptor of the forward call with O and
+ * lse filled in by it; delta is a [batch' * heads][Sq] fp32 scratch (<dO, O> per query).  Frame-sharded queries (Fq != F)
+ * are not supported.  Deterministic: two launches (dQ; dK|dV), no atomics. */
+typedef struct seer_attn_bwd_desc {
+    seer_attn_desc fwd;
+    const void* dO; void* dQ; void* dK; void* dV;     /* bf16 */
+    int64_t do_bs, dq_bs, dk_bs, dv_bs;
+    int32_t do_ss, dq_ss, dk_ss, dv_ss;
+    float* delta;
+} seer_attn_bwd_desc;
+int seer_attn_bwd(const seer_attn_bwd_desc* desc /* host */, void* stream);
 
 /* Rotary embedding on q and k in place (rotary-embedding-torch 0.1.5 rotate_queries_or_keys as called at
  * attention.py:649-651): first rot_dim channels of every head, interleaved pairs (x0,x1) -> (x0 c - x1 s, x1 c + x0 s),
@@ -232,6 +249,71 @@ int seer_clamp01(float* x, int64_t n, void* stream);
  *   out[n, c, i] = mean + exp(0.5 * clamp(logvar, -30, 20)) * noise[n, c, i]        (noise NULL: the mode) */
 int seer_gaussian_sample(const float* moments, int32_t N, int32_t C, int32_t HW, const float* noise, float* out,
                          void* stream);
+
+/* ---- training step (train.py:319-389) --------------------------------------------------------------
+ * The backward pass reuses seer_gemm_bf16 for every matrix product:
+ *   dX[M,K] = dY[M,N] W[N,K]       -> A = dY, W' = W^T ([K][N], a transposed copy of the weight: seer_transpose_bf16)
+ *   dW[N,K] = dY^T[N,M] X[M,K]     -> A = dY^T, W' = X^T (both through seer_transpose_bf16, contraction padded to 64), fp32 out
+ *   conv3x3 dX                     -> the CONV3X3 mode with the weight repacked as w'[ci][2-ky][2-kx][co]; a stride-2 conv
+ *                                     first spreads dY with seer_zero_insert2x_bf16, a conv behind the nearest-2x upsample
+ *                                     folds its dX with seer_sumpool2x_bf16
+ * and seer_attn_bwd for attention.  The entry points below are the HBM-bound remainder.  Every reduction is two-stage through
+ * a caller workspace (no float atomics). */
+
+/* y[c*ldy + r] = x[r*ldx + c]; columns rows..ldy-1 of y are zero filled */
+int seer_transpose_bf16(const void* x, int64_t rows, int32_t cols, int32_t ldx, void* y, int64_t ldy, void* stream);
+
+/* out[c] = sum_r x[r][c] (bias gradients).  workspace: seer_colsum_workspace_floats(rows, cols) floats (the same size
+ * serves seer_layernorm_bwd). */
+int64_t seer_colsum_workspace_floats(int64_t rows, int32_t cols);
+int seer_colsum_bf16(const void* x, int64_t rows, int32_t cols, int32_t ldx, float* out, float* workspace, void* stream);
+
+/* nn.LayerNorm backward (attention.py:198-200,275-277): dx = rstd (g - mean(g) - xhat mean(g xhat)) (+ dres), g = dy gamma;
+ * dgamma = sum_r dy xhat, dbeta = sum_r dy (both NULL for a frozen norm).  dres: gradient arriving on the residual path
+ * that shares x (fused add), or NULL. */
+int seer_layernorm_bwd(const void* x, const void* dy, int64_t rows, int32_t C, int32_t ldx, int32_t lddy, const float* gamma,
+                       float eps, const void* dres, int32_t ldres, void* dx, int32_t lddx, float* dgamma, float* dbeta,
+                       float* workspace, void* stream);
+
+/* GroupNorm (+ optional SiLU) backward over (C/G, F, H, W) per (b, g); stats/count/eps/gamma/beta/silu as in the forward
+ * pair seer_groupnorm_stats / seer_groupnorm_apply.  dy bf16 [rows, C1+C2]; dx1/dx2 are the gradients of the two concat
+ * sources (+ dres1/dres2 when given). */
+int64_t seer_groupnorm_bwd_workspace_floats(int32_t C, int32_t batch, int64_t rows_per_batch, int32_t groups);
+int seer_groupnorm_bwd(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t batch, int64_t rows_per_batch,
+                       int32_t groups, const float* stats, double count, float eps, const float* gamma, const float* beta,
+                       int32_t silu, const void* dy, const void* dres1, const void* dres2, void* dx1, void* dx2,
+                       float* dgamma, float* dbeta, float* workspace, void* stream);
+
+/* GEGLU (attention.py:785-793) outside the GEMM epilogue, on the interleaved projection layout of SEER_EPI_GEGLU
+ * (columns [32g, 32g+16) values, [32g+16, 32g+32) gates -> output columns [16g, 16g+16)): the training forward keeps the
+ * pre-activation for the backward. */
+int seer_geglu_fwd(const void* pre, int64_t rows, int32_t inner, int32_t ldp, void* out, int32_t ldo, void* stream);
+int seer_geglu_bwd(const void* pre, const void* dout, int64_t rows, int32_t inner, int32_t ldp, int32_t lddo, void* dpre,
+                   int32_t lddp, void* stream);
+
+/* y = a + b on bf16 [rows, cols] views (gradient fan-in) */
+int seer_add_bf16(const void* a, int32_t lda, const void* b, int32_t ldb, void* y, int32_t ldy, int64_t rows, int32_t cols,
+                  void* stream);
+/* backward of the nearest-2x upsample (resnet.py:39): dx[img,y,x,:] = sum of the 2x2 block of du [n_img, 2H, 2W, C] */
+int seer_sumpool2x_bf16(const void* du, int32_t n_img, int32_t H, int32_t W, int32_t C, void* dx, void* stream);
+/* z [n_img, 2H, 2W, C]: z[2y, 2x] = d[y, x], zero elsewhere (input-gradient of a stride-2 conv, resnet.py:52-57) */
+int seer_zero_insert2x_bf16(const void* d, int32_t n_img, int32_t H, int32_t W, int32_t C, void* z, void* stream);
+
+/* epsilon-MSE of train.py:380: loss = mean((pred[:, :, cond_f:] - target)^2) over [B, C, F_total - cond_f, HW];
+ * dpred fp32 [B, C, F_total, HW] = d loss / d pred (zero on the conditioning frames).  workspace: 1024 floats. */
+int seer_mse_loss_grad(const float* pred, const float* target, int32_t B, int32_t C, int32_t F_total, int32_t cond_f,
+                       int32_t HW, float* loss, float* dpred, float* workspace, void* stream);
+/* input gradient of conv_out (frozen): dpred fp32 [B, Cout, F, H, W] -> dx bf16 [B*F, H*W, C0]; W fp32 [Cout][3][3][C0] */
+int seer_conv_out_bwd(const float* dpred, int32_t B, int32_t C0, int32_t F, int32_t H, int32_t W, const float* Wt,
+                      int32_t Cout, void* dx, void* stream);
+
+/* out[0] = sum g^2 (workspace: 1024 floats) */
+int seer_sumsq_f32(const float* g, int64_t n, float* out, float* workspace, void* stream);
+/* torch.optim.AdamW step (train.py:226-232,385) on flat fp32 buffers; when grad_sumsq != NULL the gradient is first scaled
+ * by min(1, max_norm / (sqrt(*grad_sumsq) + 1e-6)) (clip_grad_norm_, train.py:384).  step = 1, 2, ...; p_bf16 (optional)
+ * receives the bf16 working copy of the updated parameters. */
+int seer_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int32_t step, const float* grad_sumsq, float max_norm, void* p_bf16, void* stream);
 
 #ifdef __cplusplus
 }

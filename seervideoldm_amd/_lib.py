@@ -13,7 +13,7 @@ _PKG = Path(__file__).resolve().parent
 _LIB_PATH = _PKG / "lib" / "libseer_hip.so"
 _lib = None
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 SEER_GEMM_PLAIN = 0
 SEER_GEMM_CONV3X3 = 1
@@ -57,6 +57,17 @@ class AttnDesc(C.Structure):
         ("Sq", C.c_int32), ("Sk", C.c_int32), ("causal", C.c_int32), ("scale", C.c_float),
         ("window_ws", C.c_int32), ("F", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
         ("Fq", C.c_int32), ("causal_offset", C.c_int32),
+        ("lse", C.c_void_p),
+    ]
+
+
+class AttnBwdDesc(C.Structure):
+    _fields_ = [
+        ("fwd", AttnDesc),
+        ("dO", C.c_void_p), ("dQ", C.c_void_p), ("dK", C.c_void_p), ("dV", C.c_void_p),
+        ("do_bs", C.c_int64), ("dq_bs", C.c_int64), ("dk_bs", C.c_int64), ("dv_bs", C.c_int64),
+        ("do_ss", C.c_int32), ("dq_ss", C.c_int32), ("dk_ss", C.c_int32), ("dv_ss", C.c_int32),
+        ("delta", C.c_void_p),
     ]
 
 
@@ -88,6 +99,24 @@ SIGNATURES = {
     "seer_cfg_ddim_step": ([_vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i32, _vp, _vp, _vp, _vp, _vp], C.c_int),
     "seer_clamp01": ([_vp, _i64, _vp], C.c_int),
     "seer_gaussian_sample": ([_vp, _i32, _i32, _i32, _vp, _vp, _vp], C.c_int),
+    # training step
+    "seer_attn_bwd": ([C.POINTER(AttnBwdDesc), _vp], C.c_int),
+    "seer_transpose_bf16": ([_vp, _i64, _i32, _i32, _vp, _i64, _vp], C.c_int),
+    "seer_colsum_workspace_floats": ([_i64, _i32], C.c_int64),
+    "seer_colsum_bf16": ([_vp, _i64, _i32, _i32, _vp, _vp, _vp], C.c_int),
+    "seer_layernorm_bwd": ([_vp, _vp, _i64, _i32, _i32, _i32, _vp, _f32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp], C.c_int),
+    "seer_groupnorm_bwd_workspace_floats": ([_i32, _i32, _i64, _i32], C.c_int64),
+    "seer_groupnorm_bwd": ([_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _f64, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp,
+                            _vp, _vp, _vp, _vp], C.c_int),
+    "seer_geglu_fwd": ([_vp, _i64, _i32, _i32, _vp, _i32, _vp], C.c_int),
+    "seer_geglu_bwd": ([_vp, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp], C.c_int),
+    "seer_add_bf16": ([_vp, _i32, _vp, _i32, _vp, _i32, _i64, _i32, _vp], C.c_int),
+    "seer_sumpool2x_bf16": ([_vp, _i32, _i32, _i32, _i32, _vp, _vp], C.c_int),
+    "seer_zero_insert2x_bf16": ([_vp, _i32, _i32, _i32, _i32, _vp, _vp], C.c_int),
+    "seer_mse_loss_grad": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp], C.c_int),
+    "seer_conv_out_bwd": ([_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp], C.c_int),
+    "seer_sumsq_f32": ([_vp, _i64, _vp, _vp, _vp], C.c_int),
+    "seer_adamw_step": ([_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _f32, _vp, _vp], C.c_int),
 }
 
 

@@ -359,6 +359,8 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
     if constexpr (LSUM_MFMA) l_tot = lower_half_value(oacc[L_TT][L_REG]);   // row D of O^T sits in the lh = 0 lanes
     else l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    // training: log2-domain log-sum-exp of the scaled scores, read back by seer_attn_bwd
+    if (p.lse && lh == 0 && qi < p.Sq) p.lse[(int64_t)y * p.Sq + qi] = m_run + __builtin_amdgcn_logf(l_tot);
     if (qi < p.Sq) {
         bf16* orow = Og + (int64_t)tok(qi) * p.o_ss;
 #pragma unroll

@@ -1,0 +1,787 @@
+// Training-step kernels for gfx950 (MI355X): the backward / optimizer side of the hot path (SURVEY 8(f) rank 1,
+// train.py:319-389).  Everything here is HBM-bound elementwise / reduction work; the MFMA work of the backward pass reuses
+// seer_gemm_bf16 (dX = dY W through a transposed weight copy, dW = dY^T X through seer_transpose_bf16) and seer_attn_bwd.
+// All reductions are two-stage (per-block partials in a caller workspace, added in block order): no float atomics, so a
+// step is bit-reproducible.
+#include "seer_common.h"
+
+namespace {
+
+constexpr int CS_ROWS = 32;       // rows per block of the column-owner partial-sum kernels
+
+__device__ __forceinline__ float silu_grad_f(float z) {
+    const float s = 1.0f / (1.0f + __expf(-z));
+    return s * (1.0f + z * (1.0f - s));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// transpose: y[c][r] = x[r][c] for r < rows, c < cols; columns rows .. rows_pad-1 of y are zero filled (the dW GEMM's
+// contraction length must be a multiple of 64)
+__global__ void __launch_bounds__(256) transpose_kernel(const bf16* __restrict__ x, int64_t rows, int cols, int ldx,
+                                                        bf16* __restrict__ y, int64_t ldy, int64_t rows_pad) {
+    __shared__ unsigned short tile[64][66];
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+    const unsigned short* xs = reinterpret_cast<const unsigned short*>(x);
+    unsigned short* ys = reinterpret_cast<unsigned short*>(y);
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        unsigned short v = 0;
+        if (r0 + r < rows && c0 + c < cols) v = xs[(r0 + r) * ldx + c0 + c];
+        tile[r][c] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int c = i >> 6, r = i & 63;
+        if (c0 + c < cols && r0 + r < rows_pad) ys[(int64_t)(c0 + c) * ldy + r0 + r] = tile[r][c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// column-owner partial sums: a thread owns 8 adjacent columns and walks CS_ROWS rows; NV values per element.
+// ws layout: [batch][chunk][NV][C]
+struct ColGeom {
+    int C, nchunks;
+    int64_t rows_per_batch;
+};
+
+// KIND 0: sum x          (bias gradients)
+// KIND 1: LayerNorm      v0 = dy, v1 = dy * xhat        (rowstats = mean, rstd per row)
+// KIND 2: GroupNorm      v0 = gy, v1 = gy * xhat        gy = dy * act'(z)   (x = concat x1|x2)
+struct ColArgs {
+    const bf16* x1; const bf16* x2; const bf16* dy;
+    int C1, ldx, lddy;
+    const float* rowstats;       // KIND 1
+    const float* mean_rstd;      // KIND 2: [batch][groups][2]
+    const float* gamma; const float* beta;
+    int cpg, groups, silu;
+};
+
+template <int KIND>
+__global__ void __launch_bounds__(256) colpartial_kernel(const ColArgs a, const ColGeom g, float* __restrict__ ws) {
+    constexpr int NV = KIND == 0 ? 1 : 2;
+    const int c0 = (blockIdx.y * 256 + threadIdx.x) * 8;
+    if (c0 >= g.C) return;
+    const int b = blockIdx.z;
+    const int64_t r0 = (int64_t)blockIdx.x * CS_ROWS;
+    const int64_t r1 = min(r0 + (int64_t)CS_ROWS, g.rows_per_batch);
+    float s0[8], s1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
+    float sc[8], sh[8], gm[8], bt[8];
+    if constexpr (KIND == 2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int grp = (c0 + e) / a.cpg;
+            const float mean = a.mean_rstd[((int64_t)b * a.groups + grp) * 2], rstd = a.mean_rstd[((int64_t)b * a.groups + grp) * 2 + 1];
+            sc[e] = rstd;
+            sh[e] = -mean * rstd;
+            gm[e] = a.gamma[c0 + e];
+            bt[e] = a.beta[c0 + e];
+        }
+    }
+    const bf16* src = a.x1;
+    int ld = a.ldx, cc = c0;
+    if constexpr (KIND == 2) {
+        if (c0 >= a.C1) { src = a.x2; ld = g.C - a.C1; cc = c0 - a.C1; }
+        else ld = a.C1;
+    }
+    for (int64_t r = r0; r < r1; ++r) {
+        const int64_t row = (int64_t)b * g.rows_per_batch + r;
+        float f[8];
+        unpack8(*reinterpret_cast<const u32x4*>(src + row * ld + cc), f);
+        if constexpr (KIND == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s0[e] += f[e];
+        } else {
+            float d[8];
+            unpack8(*reinterpret_cast<const u32x4*>(a.dy + row * a.lddy + c0), d);
+            if constexpr (KIND == 1) {
+                const float mean = a.rowstats[row * 2], rstd = a.rowstats[row * 2 + 1];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    s0[e] += d[e];
+                    s1[e] += d[e] * (f[e] - mean) * rstd;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = f[e] * sc[e] + sh[e];
+                    float gy = d[e];
+                    if (a.silu) gy *= silu_grad_f(xh * gm[e] + bt[e]);
+                    s0[e] += gy;
+                    s1[e] += gy * xh;
+                }
+            }
+        }
+    }
+    float* o = ws + (((int64_t)b * g.nchunks + blockIdx.x) * NV) * g.C + c0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = s0[e];
+    if constexpr (NV == 2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[g.C + e] = s1[e];
+    }
+}
+
+// out[v][c] (+)= sum over (batch, chunk) of ws[b][chunk][v][c], in order
+__global__ void __launch_bounds__(256) colfinal_kernel(const float* __restrict__ ws, int nblocks, int NV, int C,
+                                                       float* __restrict__ out0, float* __restrict__ out1) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    for (int v = 0; v < NV; ++v) {
+        float s = 0.f;
+        for (int k = 0; k < nblocks; ++k) s += ws[((int64_t)k * NV + v) * C + c];
+        float* o = v == 0 ? out0 : out1;
+        if (o) o[c] = s;
+    }
+}
+
+// GroupNorm: per (b, c) sums -> per (b, g) projections s1 = sum_c gamma_c A_bc, s2 = sum_c gamma_c B_bc (scaled by
+// 1/count), and dgamma_c = sum_b B_bc, dbeta_c = sum_b A_bc.  One block per group.
+__global__ void __launch_bounds__(64) gn_bwd_group_kernel(const float* __restrict__ ws, int batch, int nchunks, int C, int cpg,
+                                                          int groups, const float* __restrict__ gamma, float inv_count,
+                                                          float* __restrict__ proj /* [batch][groups][2] */,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int grp = blockIdx.x;
+    const int t = threadIdx.x;
+    __shared__ float red[2][64];
+    float dg[2] = {0.f, 0.f}, db[2] = {0.f, 0.f};       // a thread owns channels t and t + 64 of the group (cpg <= 128)
+    for (int b = 0; b < batch; ++b) {
+        float pa = 0.f, pb = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const int cl = t + 64 * k2;
+            if (cl < cpg) {
+                const int c = grp * cpg + cl;
+                float A = 0.f, Bv = 0.f;
+                for (int k = 0; k < nchunks; ++k) {
+                    const float* w = ws + (((int64_t)b * nchunks + k) * 2) * C + c;
+                    A += w[0];
+                    Bv += w[C];
+                }
+                pa += gamma[c] * A;
+                pb += gamma[c] * Bv;
+                dg[k2] += Bv;
+                db[k2] += A;
+            }
+        }
+        red[0][t] = pa;
+        red[1][t] = pb;
+        __syncthreads();
+        if (t == 0) {
+            float s1 = 0.f, s2 = 0.f;
+            for (int i = 0; i < 64; ++i) { s1 += red[0][i]; s2 += red[1][i]; }
+            proj[((int64_t)b * groups + grp) * 2] = s1 * inv_count;
+            proj[((int64_t)b * groups + grp) * 2 + 1] = s2 * inv_count;
+        }
+        __syncthreads();
+    }
+    if (dgamma) {
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const int cl = t + 64 * k2;
+            if (cl < cpg) {
+                dgamma[grp * cpg + cl] = dg[k2];
+                dbeta[grp * cpg + cl] = db[k2];
+            }
+        }
+    }
+}
+
+// dx = rstd * (gy*gamma - s1 - xhat*s2) (+ dres), bf16, split back into the two concat sources
+__global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const ColArgs a, const ColGeom g, const float* __restrict__ proj,
+                                                           const bf16* __restrict__ dres1, const bf16* __restrict__ dres2,
+                                                           bf16* __restrict__ dx1, bf16* __restrict__ dx2) {
+    const int c0 = (blockIdx.y * 256 + threadIdx.x) * 8;
+    if (c0 >= g.C) return;
+    const int b = blockIdx.z;
+    const int64_t r0 = (int64_t)blockIdx.x * CS_ROWS;
+    const int64_t r1 = min(r0 + (int64_t)CS_ROWS, g.rows_per_batch);
+    float sc[8], sh[8], gm[8], bt[8], p1[8], p2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int grp = (c0 + e) / a.cpg;
+        const int64_t gi = ((int64_t)b * a.groups + grp) * 2;
+        const float mean = a.mean_rstd[gi], rstd = a.mean_rstd[gi + 1];
+        sc[e] = rstd;
+        sh[e] = -mean * rstd;
+        gm[e] = a.gamma[c0 + e];
+        bt[e] = a.beta[c0 + e];
+        p1[e] = proj[gi];
+        p2[e] = proj[gi + 1];
+    }
+    const bool second = c0 >= a.C1;
+    const bf16* src = second ? a.x2 : a.x1;
+    const bf16* dres = second ? dres2 : dres1;
+    bf16* dst = second ? dx2 : dx1;
+    const int ld = second ? g.C - a.C1 : a.C1;
+    const int cc = second ? c0 - a.C1 : c0;
+    for (int64_t r = r0; r < r1; ++r) {
+        const int64_t row = (int64_t)b * g.rows_per_batch + r;
+        float f[8], d[8], o[8];
+        unpack8(*reinterpret_cast<const u32x4*>(src + row * ld + cc), f);
+        unpack8(*reinterpret_cast<const u32x4*>(a.dy + row * a.lddy + c0), d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xh = f[e] * sc[e] + sh[e];
+            float gy = d[e];
+            if (a.silu) gy *= silu_grad_f(xh * gm[e] + bt[e]);
+            o[e] = sc[e] * (gy * gm[e] - p1[e] - xh * p2[e]);
+        }
+        if (dres) {
+            float q[8];
+            unpack8(*reinterpret_cast<const u32x4*>(dres + row * ld + cc), q);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += q[e];
+        }
+        *reinterpret_cast<u32x4*>(dst + row * ld + cc) = pack8(o);
+    }
+}
+
+// (sum, sumsq) -> (mean, rstd) per (b, g), the arithmetic of gn_apply_kernel
+__global__ void gn_mean_rstd_kernel(const float* __restrict__ stats, int n, float inv_count, float eps, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float mean = stats[2 * i] * inv_count;
+    const float var = fmaxf(stats[2 * i + 1] * inv_count - mean * mean, 0.f);
+    out[2 * i] = mean;
+    out[2 * i + 1] = rsqrtf(var + eps);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LayerNorm backward rows: one wave per row (C <= 1536)
+template <int MAXC>
+__global__ void __launch_bounds__(256) ln_bwd_rows_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, int64_t rows,
+                                                          int C, int ldx, int lddy, const float* __restrict__ gamma, float eps,
+                                                          const bf16* __restrict__ dres, int ldres, bf16* __restrict__ dx,
+                                                          int lddx, float* __restrict__ rowstats) {
+    const int lane = threadIdx.x & 63;
+    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+    const int nch = C / 8;
+    float gm[MAXC][8];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gm[i][e] = gamma[ch * 8 + e];
+        }
+    }
+    const float invC = 1.0f / (float)C;
+    for (int64_t r = wave_global; r < rows; r += nwaves) {
+        float f[MAXC][8], d[MAXC][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+                unpack8(*reinterpret_cast<const u32x4*>(x + r * ldx + ch * 8), f[i]);
+                unpack8(*reinterpret_cast<const u32x4*>(dy + r * lddy + ch * 8), d[i]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += f[i][e];
+            }
+        }
+        const float mean = wave_sum(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float t = f[i][e] - mean; q += t * t; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) * invC + eps);
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = (f[i][e] - mean) * rstd;
+                    const float gg = d[i][e] * gm[i][e];
+                    f[i][e] = xh;
+                    d[i][e] = gg;
+                    c1 += gg;
+                    c2 += gg * xh;
+                }
+            }
+        }
+        c1 = wave_sum(c1) * invC;
+        c2 = wave_sum(c2) * invC;
+        if (rowstats && lane == 0) { rowstats[r * 2] = mean; rowstats[r * 2 + 1] = rstd; }
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rstd * (d[i][e] - c1 - f[i][e] * c2);
+                if (dres) {
+                    float qv[8];
+                    unpack8(*reinterpret_cast<const u32x4*>(dres + r * ldres + ch * 8), qv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] += qv[e];
+                }
+                *reinterpret_cast<u32x4*>(dx + r * lddx + ch * 8) = pack8(o);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// GEGLU on the interleaved projection layout of the GEMM epilogue: columns [32g, 32g+16) values, [32g+16, 32g+32) gates
+__global__ void __launch_bounds__(256) geglu_fwd_kernel(const bf16* __restrict__ pre, int64_t n_out8, int inner8, int ldp,
+                                                        bf16* __restrict__ out, int ldo) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_out8) return;
+    const int64_t row = i / inner8;
+    const int c8 = (int)(i - row * inner8);          // 8-column chunk of the output
+    const int g = c8 >> 1, half = c8 & 1;
+    const bf16* p = pre + row * ldp + 32 * g + 8 * half;
+    float v[8], gt[8], o[8];
+    unpack8(*reinterpret_cast<const u32x4*>(p), v);
+    unpack8(*reinterpret_cast<const u32x4*>(p + 16), gt);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = v[e] * gelu_erf_f(gt[e]);
+    *reinterpret_cast<u32x4*>(out + row * ldo + c8 * 8) = pack8(o);
+}
+
+__global__ void __launch_bounds__(256) geglu_bwd_kernel(const bf16* __restrict__ pre, const bf16* __restrict__ dout, int64_t n_out8,
+                                                        int inner8, int ldp, int lddo, bf16* __restrict__ dpre, int lddp) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_out8) return;
+    const int64_t row = i / inner8;
+    const int c8 = (int)(i - row * inner8);
+    const int g = c8 >> 1, half = c8 & 1;
+    const bf16* p = pre + row * ldp + 32 * g + 8 * half;
+    float v[8], gt[8], d[8], dv[8], dg[8];
+    unpack8(*reinterpret_cast<const u32x4*>(p), v);
+    unpack8(*reinterpret_cast<const u32x4*>(p + 16), gt);
+    unpack8(*reinterpret_cast<const u32x4*>(dout + row * lddo + c8 * 8), d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = gt[e];
+        const float cdf = 0.5f * (1.0f + erff(x * 0.7071067811865476f));
+        const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+        dv[e] = d[e] * x * cdf;
+        dg[e] = d[e] * v[e] * (cdf + x * pdf);
+    }
+    bf16* q = dpre + row * lddp + 32 * g + 8 * half;
+    *reinterpret_cast<u32x4*>(q) = pack8(dv);
+    *reinterpret_cast<u32x4*>(q + 16) = pack8(dg);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) add_bf16_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, bf16* __restrict__ y,
+                                                       int64_t rows, int cols8, int lda, int ldb, int ldy) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * cols8) return;
+    const int64_t r = i / cols8;
+    const int c = (int)(i - r * cols8) * 8;
+    float f[8], g[8];
+    unpack8(*reinterpret_cast<const u32x4*>(a + r * lda + c), f);
+    unpack8(*reinterpret_cast<const u32x4*>(b + r * ldb + c), g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] += g[e];
+    *reinterpret_cast<u32x4*>(y + r * ldy + c) = pack8(f);
+}
+
+// nearest-2x upsample backward: dx[img, y, x, :] = sum of the 2x2 block of du[img, 2y.., 2x.., :]
+__global__ void __launch_bounds__(256) sumpool2x_kernel(const bf16* __restrict__ du, int n_img, int H, int W, int C8,
+                                                        bf16* __restrict__ dx) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)n_img * H * W * C8;
+    if (i >= total) return;
+    const int c = (int)(i % C8) * 8;
+    int64_t pix = i / C8;
+    const int x = (int)(pix % W);
+    pix /= W;
+    const int y = (int)(pix % H);
+    const int64_t img = pix / H;
+    const int C = C8 * 8;
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dxx = 0; dxx < 2; ++dxx) {
+            float f[8];
+            unpack8(*reinterpret_cast<const u32x4*>(du + ((img * 2 * H + 2 * y + dy) * (2 * W) + 2 * x + dxx) * C + c), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += f[e];
+        }
+    *reinterpret_cast<u32x4*>(dx + ((img * H + y) * W + x) * C + c) = pack8(s);
+}
+
+// stride-2 conv backward helper: z[img, 2y, 2x, :] = d[img, y, x, :], zero elsewhere (z is [n_img, 2H, 2W, C])
+__global__ void __launch_bounds__(256) zero_insert2x_kernel(const bf16* __restrict__ d, int n_img, int H, int W, int C8,
+                                                            bf16* __restrict__ z) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)n_img * 2 * H * 2 * W * C8;
+    if (i >= total) return;
+    const int c = (int)(i % C8) * 8;
+    int64_t pix = i / C8;
+    const int x = (int)(pix % (2 * W));
+    pix /= 2 * W;
+    const int y = (int)(pix % (2 * H));
+    const int64_t img = pix / (2 * H);
+    const int C = C8 * 8;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (!(x & 1) && !(y & 1)) v = *reinterpret_cast<const u32x4*>(d + ((img * H + (y >> 1)) * W + (x >> 1)) * C + c);
+    *reinterpret_cast<u32x4*>(z + i * 8) = v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// epsilon-MSE (train.py:380): loss = mean((pred[:, :, cond:] - target)^2); dpred = 2 (pred - target) / N, zero on the
+// conditioning frames.  Block partials -> ordered final sum.
+__global__ void __launch_bounds__(256) mse_kernel(const float* __restrict__ pred, const float* __restrict__ target, int BC, int F_total,
+                                                  int cond_f, int HW, float inv_n, float* __restrict__ dpred,
+                                                  float* __restrict__ partial) {
+    const int64_t total = (int64_t)BC * F_total * HW;
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int hw = (int)(i % HW);
+        const int64_t t = i / HW;
+        const int f = (int)(t % F_total);
+        const int64_t bc = t / F_total;
+        float g = 0.f;
+        if (f >= cond_f) {
+            const float d = pred[i] - target[(bc * (F_total - cond_f) + (f - cond_f)) * HW + hw];
+            s += d * d;
+            g = 2.0f * d * inv_n;
+        }
+        dpred[i] = g;
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ void sum_partials_kernel(const float* __restrict__ partial, int n, float scale, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += partial[i];
+        *out = s * scale;
+    }
+}
+
+// conv_out backward (input gradient only; conv_out is frozen): dx[b,f,y,x,ci] = sum_{co,ky,kx} dpred[b,co,f,y+1-ky,x+1-kx]
+// * w[co,ci,ky,kx].  Wt fp32 [Cout][3][3][C0] (the direct conv_out layout).  One block per (image row), weights in LDS.
+template <int COUT>
+__global__ void __launch_bounds__(256) conv_out_bwd_kernel(const float* __restrict__ dpred, int B, int C0, int F, int H, int W_,
+                                                           const float* __restrict__ Wt, bf16* __restrict__ dx) {
+    extern __shared__ float sm[];
+    float* ws = sm;                                   // [COUT*9][C0]
+    float* patch = sm + COUT * 9 * C0;                // [COUT][3][W_+2]
+    for (int i = threadIdx.x; i < COUT * 9 * C0; i += 256) ws[i] = Wt[i];
+    const int y = blockIdx.x % H;
+    const int img = blockIdx.x / H;                   // b*F + f
+    const int b = img / F, f = img % F;
+    const int PW = W_ + 2;
+    for (int i = threadIdx.x; i < COUT * 3 * PW; i += 256) {
+        const int px = i % PW, r = (i / PW) % 3, co = i / (3 * PW);
+        const int yy = y + 1 - r, xx = px - 1;        // r = ky: source row y + 1 - ky
+        float v = 0.f;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W_) v = dpred[((((int64_t)b * COUT + co) * F + f) * H + yy) * W_ + xx];
+        patch[i] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < W_ * C0; i += 256) {
+        const int ci = i % C0, x = i / C0;
+        float s = 0.f;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                    s += patch[(co * 3 + ky) * PW + (x + 1 - kx) + 1] * ws[((co * 3 + ky) * 3 + kx) * C0 + ci];
+        dx[(((int64_t)img * H + y) * W_ + x) * C0 + ci] = (bf16)s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ partial) {
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += g[i] * g[i];
+    __shared__ float red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// torch.optim.AdamW (train.py:226-232) on flat fp32 buffers; the gradient is first scaled by
+// min(1, max_norm / (sqrt(*sumsq) + 1e-6)) when sumsq != NULL (torch.nn.utils.clip_grad_norm_, train.py:384).
+// Also refreshes the bf16 working copy of the parameters.
+__global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                                    float wd, float bc1, float bc2_sqrt, const float* __restrict__ sumsq,
+                                                    float max_norm, bf16* __restrict__ p_bf16) {
+    float coef = 1.0f;
+    if (sumsq) coef = fminf(1.0f, max_norm / (sqrtf(*sumsq) + 1e-6f));
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i] * coef;
+        float pi = p[i] * (1.0f - lr * wd);
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi -= (lr / bc1) * (mi / denom);
+        p[i] = pi;
+        m[i] = mi;
+        v[i] = vi;
+        if (p_bf16) p_bf16[i] = (bf16)pi;
+    }
+}
+
+int col_blocks(int C) { return (C / 8 + 255) / 256; }
+
+}  // namespace
+
+extern "C" int seer_transpose_bf16(const void* x, int64_t rows, int32_t cols, int32_t ldx, void* y, int64_t ldy,
+                                   void* stream) {
+    if (!x || !y || rows <= 0 || cols <= 0 || ldx < cols || ldy < rows) return SEER_EINVAL;
+    const int64_t rows_pad = ldy;
+    dim3 grid((unsigned)((rows_pad + 63) / 64), (unsigned)((cols + 63) / 64));
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const bf16*>(x), rows, cols, ldx, reinterpret_cast<bf16*>(y), ldy, rows_pad);
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int64_t seer_colsum_workspace_floats(int64_t rows, int32_t cols) {
+    if (rows <= 0 || cols <= 0) return SEER_EINVAL;
+    return ((rows + CS_ROWS - 1) / CS_ROWS) * 2 * (int64_t)cols + 2 * rows;
+}
+
+extern "C" int seer_colsum_bf16(const void* x, int64_t rows, int32_t cols, int32_t ldx, float* out, float* workspace,
+                                void* stream) {
+    if (!x || !out || !workspace || rows <= 0 || cols <= 0 || cols % 8 || ldx % 8) return SEER_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    ColGeom g{cols, (int)((rows + CS_ROWS - 1) / CS_ROWS), rows};
+    ColArgs a{};
+    a.x1 = reinterpret_cast<const bf16*>(x);
+    a.ldx = ldx;
+    hipLaunchKernelGGL(colpartial_kernel<0>, dim3(g.nchunks, col_blocks(cols), 1), dim3(256), 0, st, a, g, workspace);
+    SEER_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colfinal_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, workspace, g.nchunks, 1, cols, out,
+                       (float*)nullptr);
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int seer_layernorm_bwd(const void* x, const void* dy, int64_t rows, int32_t C, int32_t ldx, int32_t lddy,
+                                  const float* gamma, float eps, const void* dres, int32_t ldres, void* dx, int32_t lddx,
+                                  float* dgamma, float* dbeta, float* workspace, void* stream) {
+    if (!x || !dy || !gamma || !dx || rows <= 0 || C <= 0 || C % 8 || (ldx | lddy | lddx) % 8) return SEER_EINVAL;
+    if (dres && ldres % 8) return SEER_EINVAL;
+    if ((dgamma != nullptr) != (dbeta != nullptr)) return SEER_EINVAL;
+    if (dgamma && !workspace) return SEER_EINVAL;
+    if (C > 64 * 8 * 3) return SEER_ENOSYS;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bf16* xb = reinterpret_cast<const bf16*>(x);
+    const bf16* dyb = reinterpret_cast<const bf16*>(dy);
+    const bf16* rb = reinterpret_cast<const bf16*>(dres);
+    bf16* dxb = reinterpret_cast<bf16*>(dx);
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    ColGeom g{C, (int)((rows + CS_ROWS - 1) / CS_ROWS), rows};
+    float* rowstats = dgamma ? workspace + (int64_t)g.nchunks * 2 * C : nullptr;
+#define SEER_LNB(MC) hipLaunchKernelGGL(ln_bwd_rows_kernel<MC>, dim3((unsigned)blocks), dim3(256), 0, st, xb, dyb, rows, C, ldx, \
+                                        lddy, gamma, eps, rb, ldres, dxb, lddx, rowstats)
+    if (C <= 512) SEER_LNB(1);
+    else if (C <= 1024) SEER_LNB(2);
+    else SEER_LNB(3);
+#undef SEER_LNB
+    SEER_LAUNCH_CHECK();
+    if (dgamma) {
+        ColArgs a{};
+        a.x1 = xb;
+        a.dy = dyb;
+        a.ldx = ldx;
+        a.lddy = lddy;
+        a.rowstats = rowstats;
+        hipLaunchKernelGGL(colpartial_kernel<1>, dim3(g.nchunks, col_blocks(C), 1), dim3(256), 0, st, a, g, workspace);
+        SEER_LAUNCH_CHECK();
+        hipLaunchKernelGGL(colfinal_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, g.nchunks, 2, C, dbeta, dgamma);
+        SEER_LAUNCH_CHECK();
+    }
+    return SEER_OK;
+}
+
+extern "C" int64_t seer_groupnorm_bwd_workspace_floats(int32_t C, int32_t batch, int64_t rows_per_batch, int32_t groups) {
+    if (C <= 0 || batch <= 0 || rows_per_batch <= 0 || groups <= 0) return SEER_EINVAL;
+    const int64_t nchunks = (rows_per_batch + CS_ROWS - 1) / CS_ROWS;
+    return (int64_t)batch * nchunks * 2 * C + 4 * (int64_t)batch * groups;
+}
+
+extern "C" int seer_groupnorm_bwd(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t batch,
+                                  int64_t rows_per_batch, int32_t groups, const float* stats, double count, float eps,
+                                  const float* gamma, const float* beta, int32_t silu, const void* dy, const void* dres1,
+                                  const void* dres2, void* dx1, void* dx2, float* dgamma, float* dbeta, float* workspace,
+                                  void* stream) {
+    if (!x1 || !stats || !gamma || !beta || !dy || !dx1 || !workspace || batch <= 0 || rows_per_batch <= 0 || count <= 0)
+        return SEER_EINVAL;
+    if (!x2) C2 = 0;
+    if (x2 && !dx2) return SEER_EINVAL;
+    const int C = C1 + C2;
+    if (C1 <= 0 || C2 < 0 || C1 % 8 || C2 % 8 || groups <= 0 || C % groups) return SEER_EINVAL;
+    if ((dgamma != nullptr) != (dbeta != nullptr)) return SEER_EINVAL;
+    if (C / groups > 128) return SEER_ENOSYS;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    ColGeom g{C, (int)((rows_per_batch + CS_ROWS - 1) / CS_ROWS), rows_per_batch};
+    float* proj = workspace + (int64_t)batch * g.nchunks * 2 * C;       // [batch][groups][2]
+    float* mean_rstd = proj + 2 * (int64_t)batch * groups;
+    const float inv_count = (float)(1.0 / count);
+    hipLaunchKernelGGL(gn_mean_rstd_kernel, dim3((batch * groups + 255) / 256), dim3(256), 0, st, stats, batch * groups,
+                       inv_count, eps, mean_rstd);
+    SEER_LAUNCH_CHECK();
+    ColArgs a{};
+    a.x1 = reinterpret_cast<const bf16*>(x1);
+    a.x2 = reinterpret_cast<const bf16*>(x2);
+    a.dy = reinterpret_cast<const bf16*>(dy);
+    a.C1 = C1;
+    a.lddy = C;
+    a.mean_rstd = mean_rstd;
+    a.gamma = gamma;
+    a.beta = beta;
+    a.cpg = C / groups;
+    a.groups = groups;
+    a.silu = silu;
+    dim3 grid(g.nchunks, col_blocks(C), batch);
+    hipLaunchKernelGGL(colpartial_kernel<2>, grid, dim3(256), 0, st, a, g, workspace);
+    SEER_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(groups), dim3(64), 0, st, workspace, batch, g.nchunks, C, a.cpg, groups, gamma,
+                       inv_count, proj, dgamma, dbeta);
+    SEER_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, grid, dim3(256), 0, st, a, g, proj, reinterpret_cast<const bf16*>(dres1),
+                       reinterpret_cast<const bf16*>(dres2), reinterpret_cast<bf16*>(dx1), reinterpret_cast<bf16*>(dx2));
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int seer_geglu_fwd(const void* pre, int64_t rows, int32_t inner, int32_t ldp, void* out, int32_t ldo, void* stream) {
+    if (!pre || !out || rows <= 0 || inner <= 0 || inner % 16 || ldp % 8 || ldo % 8) return SEER_EINVAL;
+    const int64_t n = rows * (inner / 8);
+    hipLaunchKernelGGL(geglu_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const bf16*>(pre), n, inner / 8, ldp, reinterpret_cast<bf16*>(out), ldo);
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int seer_geglu_bwd(const void* pre, const void* dout, int64_t rows, int32_t inner, int32_t ldp, int32_t lddo,
+                              void* dpre, int32_t lddp, void* stream) {
+    if (!pre || !dout || !dpre || rows <= 0 || inner <= 0 || inner % 16 || (ldp | lddo | lddp) % 8) return SEER_EINVAL;
+    const int64_t n = rows * (inner / 8);
+    hipLaunchKernelGGL(geglu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const bf16*>(pre), reinterpret_cast<const bf16*>(dout), n, inner / 8, ldp, lddo,
+                       reinterpret_cast<bf16*>(dpre), lddp);
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int seer_add_bf16(const void* a, int32_t lda, const void* b, int32_t ldb, void* y, int32_t ldy, int64_t rows,
+                             int32_t cols, void* stream) {
+    if (!a || !b || !y || rows <= 0 || cols <= 0 || cols % 8 || (lda | ldb | ldy) % 8) return SEER_EINVAL;
+    const int64_t n = rows * (cols / 8);
+    hipLaunchKernelGGL(add_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const bf16*>(a), reinterpret_cast<const bf16*>(b), reinterpret_cast<bf16*>(y), rows,
+                       cols / 8, lda, ldb, ldy);
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int seer_sumpool2x_bf16(const void* du, int32_t n_img, int32_t H, int32_t W_, int32_t C, void* dx, void* stream) {
+    if (!du || !dx || n_img <= 0 || H <= 0 || W_ <= 0 || C <= 0 || C % 8) return SEER_EINVAL;
+    const int64_t n = (int64_t)n_img * H * W_ * (C / 8);
+    hipLaunchKernelGGL(sumpool2x_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const bf16*>(du), n_img, H, W_, C / 8, reinterpret_cast<bf16*>(dx));
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int seer_zero_insert2x_bf16(const void* d, int32_t n_img, int32_t H, int32_t W_, int32_t C, void* z, void* stream) {
+    if (!d || !z || n_img <= 0 || H <= 0 || W_ <= 0 || C <= 0 || C % 8) return SEER_EINVAL;
+    const int64_t n = (int64_t)n_img * 4 * H * W_ * (C / 8);
+    hipLaunchKernelGGL(zero_insert2x_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const bf16*>(d), n_img, H, W_, C / 8, reinterpret_cast<bf16*>(z));
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int seer_mse_loss_grad(const float* pred, const float* target, int32_t B, int32_t C, int32_t F_total, int32_t cond_f,
+                                  int32_t HW, float* loss, float* dpred, float* workspace /* 1024 floats */, void* stream) {
+    if (!pred || !target || !loss || !dpred || !workspace || B <= 0 || C <= 0 || HW <= 0 || cond_f < 0 || cond_f >= F_total)
+        return SEER_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t total = (int64_t)B * C * F_total * HW;
+    const double n = (double)B * C * (F_total - cond_f) * HW;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(mse_kernel, dim3(blocks), dim3(256), 0, st, pred, target, B * C, F_total, cond_f, HW, (float)(1.0 / n),
+                       dpred, workspace);
+    SEER_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, st, workspace, blocks, (float)(1.0 / n), loss);
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int seer_conv_out_bwd(const float* dpred, int32_t B, int32_t C0, int32_t F, int32_t H, int32_t W_, const float* Wt,
+                                 int32_t Cout, void* dx, void* stream) {
+    if (!dpred || !Wt || !dx || B <= 0 || C0 <= 0 || F <= 0 || H <= 0 || W_ <= 0) return SEER_EINVAL;
+    if (Cout != 4) return SEER_ENOSYS;
+    const size_t lds = ((size_t)Cout * 9 * C0 + (size_t)Cout * 3 * (W_ + 2)) * sizeof(float);
+    if (lds > 160 * 1024) return SEER_ENOSYS;
+    if (lds > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_out_bwd_kernel<4>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            done = true;
+        }
+    }
+    hipLaunchKernelGGL(conv_out_bwd_kernel<4>, dim3((unsigned)(B * F * H)), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
+                       dpred, B, C0, F, H, W_, Wt, reinterpret_cast<bf16*>(dx));
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int seer_sumsq_f32(const float* g, int64_t n, float* out, float* workspace /* 1024 floats */, void* stream) {
+    if (!g || !out || !workspace || n <= 0) return SEER_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int blocks = (int)((n + 256 * 16 - 1) / (256 * 16));
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, st, g, n, workspace);
+    SEER_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, st, workspace, blocks, 1.0f, out);
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int seer_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                               float eps, float weight_decay, int32_t step, const float* grad_sumsq, float max_norm,
+                               void* p_bf16, void* stream) {
+    if (!p || !g || !m || !v || n <= 0 || step <= 0) return SEER_EINVAL;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    int64_t blocks = (n + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v, n,
+                       lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_sumsq, max_norm,
+                       reinterpret_cast<bf16*>(p_bf16));
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}

@@ -170,7 +170,8 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, n_img: int, Hin: int, Win: int, *,
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *, batch: int, heads: int,
               head_dim: int, Sq: int, Sk: int, causal=False, scale: Optional[float] = None,
               window=None, Fq: Optional[int] = None, causal_offset: int = 0,
-              seq_stride_rows: int = 1, batch_stride_rows: Optional[int] = None) -> torch.Tensor:
+              seq_stride_rows: int = 1, batch_stride_rows: Optional[int] = None,
+              lse: Optional[torch.Tensor] = None, _desc_only: bool = False) -> torch.Tensor:
     """q/k/v/out are 2-D token-major views [batch*S, >=heads*head_dim] (row stride = token stride, e.g. column slices
     of a fused qkv buffer).  window = (ws, F, H, W) selects the temporal window form (K/V: F*H*W tokens per batch
     element in memory, Sk = F*ws*ws per window; Q/O hold Fq frames, Fq = F unless frame-sharded).  causal_offset is the
@@ -201,6 +202,13 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     d.batch, d.heads, d.head_dim, d.Sq, d.Sk = batch, heads, head_dim, Sq, Sk
     d.causal = int(causal)
     d.scale = float(scale if scale is not None else head_dim ** -0.5)
+    if lse is not None:         # training: keep the softmax statistics for seer_attn_bwd
+        _req(lse, torch.float32, "lse")
+        nb = batch if window is None else batch * (window[2] // window[0]) * (window[3] // window[0])
+        assert lse.is_contiguous() and lse.numel() == nb * heads * Sq
+        d.lse = _p(lse)
+    if _desc_only:
+        return d
     check(_lib.load().seer_attn_fwd(C.byref(d), _stream()), "seer_attn_fwd")
     return out
 
