@@ -145,6 +145,8 @@ def main():
 
     gen_fstext(ref)
     gen_vae_encode(ref)
+    with torch.enable_grad():
+        gen_train(ref)
 
 
 TINY_FSTEXT = dict(num_frames=6, num_layers=2, channels=192, n_heads=2, cross_attention_dim=192)
@@ -192,8 +194,82 @@ def gen_vae_encode(ref):
     _save("vae_enc_tiny.npz", x=x, moments=moments, noise=noise, sample=sample)
 
 
+TINY_TRAIN_UNET = dict(sample_size=16, in_channels=4, out_channels=4, block_out_channels=(32, 64, 64, 64),
+                       cross_attention_dim=64, attention_head_dim=8, layers_per_block=2)
+TINY_TRAIN_FSTEXT = dict(num_frames=16, num_layers=1, channels=64, n_heads=2, cross_attention_dim=64)
+TRAIN_HP = dict(lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8, max_grad_norm=0.3)
+TRAIN_FULL_KEYS_U = ("down_blocks.0.temporal_attentions.0.transformer_blocks.0.attn1.to_q.weight",
+                     "down_blocks.0.temporal_attentions.0.norm.weight",
+                     "mid_block.temporal_attentions.0.transformer_blocks.0.ff.net.0.proj.weight",
+                     "up_blocks.3.temporal_attentions.1.proj_out.bias",
+                     "up_blocks.1.temporal_attentions.0.transformer_blocks.0.norm3.weight")
+TRAIN_FULL_KEYS_F = ("learnable_query", "trf_blocks.0.transformer_blocks.0.attn2.to_k.weight",
+                     "trf_blocks.0.transformer_blocks.1.attn1.to_q.weight", "trf_blocks.0.transformer_blocks.1.ff.net.2.bias",
+                     "norm.weight")
+
+
+def gen_train(ref):
+    """8. one fine-tuning step of train.py:319-389 on the real reference modules: FSText -> SeerUNet -> eps-MSE -> backward ->
+    clip_grad_norm_(sunet) -> AdamW, at 4 frames with 2 conditioning frames.  Stored: the inputs, the loss, per-parameter
+    gradient statistics (L2 norm, sum) for EVERY trainable tensor, full gradients and updated values of a few tensors."""
+    unet = ref.unet.SeerUNet(**TINY_TRAIN_UNET)
+    ref_import.enable_xformers_path(unet)
+    ushapes = synth.unet_param_shapes(TINY_TRAIN_UNET)
+    unet.load_state_dict(synth.synth_state_dict(ushapes), strict=True)
+    c = TINY_TRAIN_FSTEXT
+    fst = ref.unet.FSTextTransformer(num_frames=c["num_frames"], in_channels=c["channels"], out_channels=c["channels"],
+                                     n_heads=c["n_heads"], num_layers=c["num_layers"], cross_attention_dim=c["cross_attention_dim"])
+    ref_import.enable_xformers_path(fst)
+    fst.load_state_dict(synth.synth_state_dict(synth.fstext_param_shapes(**c)), strict=True)
+    Fr, cond = 4, 2
+    fst.set_numframe(Fr)                                                  # train.py:187
+    unet.requires_grad_(False)                                            # train.py:188-192
+    for name, module in unet.named_modules():
+        if name.endswith(("temporal_attentions",)):
+            for prm in module.parameters():
+                prm.requires_grad = True
+    unet.train(); fst.train()
+    params = [p for p in unet.parameters() if p.requires_grad] + list(fst.parameters())
+    hp = TRAIN_HP
+    opt = torch.optim.AdamW(params, lr=hp["lr"], betas=hp["betas"], weight_decay=hp["weight_decay"], eps=hp["eps"])
+    latents_x0, latents = _randn((1, 4, cond, 16, 16), 80), _randn((1, 4, Fr - cond, 16, 16), 81)
+    noise, text = _randn((1, 4, Fr - cond, 16, 16), 82), _randn((1, 77, 64), 83)
+    t = torch.tensor([417])
+    # DDPMScheduler.add_noise with the SD scaled-linear schedule (train.py:234,363)
+    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float32) ** 2
+    acp = torch.cumprod(1.0 - betas, 0)
+    a = acp[t].reshape(-1, 1, 1, 1, 1)
+    noisy = a.sqrt() * latents + (1 - a).sqrt() * noise
+    x = torch.cat([latents_x0, noisy], 2)
+    text_seq = fst(context=text)
+    pred = unet(x, t, text_seq, cond)
+    loss = torch.nn.functional.mse_loss(pred[:, :, cond:], noise, reduction="none").mean([1, 2, 3, 4]).mean()
+    loss.backward()
+    un = {k: p for k, p in unet.named_parameters() if p.requires_grad}
+    fn = dict(fst.named_parameters())
+    stats = lambda d: np.asarray([[float(p.grad.norm()) if p.grad is not None else 0.0,
+                                   float(p.grad.sum()) if p.grad is not None else 0.0] for p in d.values()])
+    out = dict(latents_x0=latents_x0, latents=latents, noise=noise, text=text, timestep=t, alphas_cumprod=acp, model_input=x,
+               loss=loss.detach(), pred=pred.detach(), unet_keys=np.asarray(list(un)), fstext_keys=np.asarray(list(fn)),
+               unet_grad_stats=stats(un), fstext_grad_stats=stats(fn))
+    for k in TRAIN_FULL_KEYS_U:
+        out["gu:" + k] = un[k].grad.detach().clone()
+    for k in TRAIN_FULL_KEYS_F:
+        out["gf:" + k] = fn[k].grad.detach().clone()
+    total = torch.nn.utils.clip_grad_norm_(unet.parameters(), hp["max_grad_norm"])      # train.py:384
+    opt.step()
+    out["unet_grad_norm"] = total
+    for k in TRAIN_FULL_KEYS_U:
+        out["pu:" + k] = un[k].detach().clone()
+    for k in TRAIN_FULL_KEYS_F:
+        out["pf:" + k] = fn[k].detach().clone()
+    _save("train_tiny.npz", **out)
+
+
 if __name__ == "__main__":
-    if "fstext" in sys.argv[1:]:
+    if "train" in sys.argv[1:]:
+        gen_train(ref_import.load_reference())
+    elif "fstext" in sys.argv[1:]:
         gen_fstext(ref_import.load_reference())
     elif "vae_encode" in sys.argv[1:]:
         gen_vae_encode(ref_import.load_reference())

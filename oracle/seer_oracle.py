@@ -423,3 +423,55 @@ def gaussian_sample(moments, noise):
     """DiagonalGaussianDistribution (ldm/modules/distributions/distributions.py:24-37): mean + std * noise"""
     mean, logvar = moments.chunk(2, dim=1)
     return mean + torch.exp(0.5 * logvar.clamp(-30.0, 20.0)) * noise
+
+
+# ------------------------------------------------------------------------------------------------ training step
+# SURVEY 8(f) rank 1: the reference's fine-tuning step (train.py:319-389) by autograd through the restatements above.
+def trainable_keys(unet_sd: SD, fstext_sd: SD):
+    """train.py:122-124,188-192,213: parameters under `*.temporal_attentions` of the UNet + the whole FSTextTransformer
+    (rotary `freqs` are buffers, not parameters)."""
+    u = [k for k in unet_sd if ".temporal_attentions." in k and not k.endswith("rotary_emb.freqs")]
+    f = [k for k in fstext_sd if not k.endswith("rotary_emb.freqs")]
+    return u, f
+
+
+def train_loss_and_grads(unet_sd: SD, cfg: dict, fstext_sd: SD, model_input, target, timesteps, text_cond_emb,
+                         cond_frames: int, fstext_heads: int = 8):
+    """train.py:344,367-380: text_seq = fstext(text); pred = sunet(cat[x0 latents, noisy latents], t, text_seq, cond);
+    loss = mse(pred[:, :, cond:], noise).mean over everything.  Returns (loss, {unet key: grad}, {fstext key: grad}, pred)."""
+    uk, fk = trainable_keys(unet_sd, fstext_sd)
+    usd = {k: v.detach().clone().float() for k, v in unet_sd.items()}
+    fsd = {k: v.detach().clone().float() for k, v in fstext_sd.items()}
+    for k in uk:
+        usd[k].requires_grad_(True)
+    for k in fk:
+        fsd[k].requires_grad_(True)
+    Fr = model_input.shape[2]
+    text_seq = fstext_forward(fsd, text_cond_emb.float(), Fr, fstext_heads)
+    pred = unet_forward(usd, cfg, model_input.float(), timesteps, text_seq, cond_frame=cond_frames)
+    loss = F.mse_loss(pred[:, :, cond_frames:], target.float(), reduction="none").mean([1, 2, 3, 4]).mean()
+    loss.backward()
+    zero = lambda t: torch.zeros_like(t)
+    gu = {k: (usd[k].grad if usd[k].grad is not None else zero(usd[k])) for k in uk}
+    gf = {k: (fsd[k].grad if fsd[k].grad is not None else zero(fsd[k])) for k in fk}
+    return loss.detach(), gu, gf, pred.detach()
+
+
+def clip_and_adamw(params: SD, grads: SD, m: SD, v: SD, step: int, lr: float, betas=(0.9, 0.999), eps=1e-8,
+                   weight_decay=1e-2, max_norm: Optional[float] = None):
+    """torch.nn.utils.clip_grad_norm_ (train.py:384) followed by torch.optim.AdamW (train.py:226-232,385), written out.
+    Updates params / m / v in place; returns the total gradient norm before clipping."""
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).float()
+    coef = 1.0
+    if max_norm is not None:
+        coef = min(1.0, float(max_norm / (total + 1e-6)))
+    b1, b2 = betas
+    bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+    for k, p in params.items():
+        g = grads[k] * coef
+        p.mul_(1 - lr * weight_decay)
+        m[k].mul_(b1).add_(g, alpha=1 - b1)
+        v[k].mul_(b2).addcmul_(g, g, value=1 - b2)
+        denom = (v[k].sqrt() / math.sqrt(bc2)).add_(eps)
+        p.addcdiv_(m[k], denom, value=-lr / bc1)
+    return total
