@@ -351,7 +351,7 @@ class SeerTrainer:
             lse = tops.attn_lse_buffer(B, heads, Fr * HW, x.device)
         ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], a1, lse=lse, **kw)
         h1 = ops.gemm(a1, w[tb + ".attn1.to_out.0.weight"], bias=w[tb + ".attn1.to_out.0.bias"], residual=h0)
-        sl = self._ff_slices(B, Fr, HW, max(cond_frame, 0))
+        sl = self._ff_slices(B, Fr, HW, cond_frame) if cond_frame > 0 else [slice(0, B * Fr * HW)]
         hf2, sff = self._ff_fwd(self.pu, w, self._unet_ff_names(tb), self._gather(h1, sl))
         if cond_frame > 0:
             h2 = h1.clone()
@@ -476,7 +476,7 @@ class SeerTrainer:
             elif kind == "temporal":
                 dx = self._temporal_bwd(s, dx)
             elif kind == "push":                         # this activation was also a skip: add the gradient that came back
-                dx = tops.add(dx, dskips.pop(0)) if dx is not None else dskips.pop(0)
+                dx = tops.add(dx, dskips.pop())            # LIFO: the last skip pushed is the first one consumed
             elif kind == "down":
                 key, geo = s
                 B, Fr, H, W = geo
@@ -655,9 +655,13 @@ class SeerTrainer:
     # ================================================================================================ checkpoints
     def trainable_state_dict(self) -> "Dict[str, Dict[str, torch.Tensor]]":
         """{'unet': {...}, 'fstext': {...}} fp32 tensors under the REFERENCE's parameter names (unpacked)."""
+        return self.trainable_state_dict_of(self.pu.p, self.pf.p)
+
+    def trainable_state_dict_of(self, flat_u: torch.Tensor, flat_f: torch.Tensor) -> "Dict[str, Dict[str, torch.Tensor]]":
+        """the same unpacking applied to any pair of flat buffers (parameters, gradients, Adam moments)"""
         out_u: Dict[str, torch.Tensor] = {}
         for k in self.pu.names:
-            v = self.pu.view(self.pu.p, k).detach().clone()
+            v = self.pu.view(flat_u, k).detach().clone()
             if k.endswith(".qkv"):
                 p = k[: -len(".qkv")]
                 q, kk, vv = v.chunk(3, 0)
@@ -673,7 +677,7 @@ class SeerTrainer:
                 out_u[k] = v
         out_f: Dict[str, torch.Tensor] = {}
         for k in self.pf.names:
-            v = self.pf.view(self.pf.p, k).detach().clone()
+            v = self.pf.view(flat_f, k).detach().clone()
             if k.endswith(".attn1.qkv"):
                 p = k[: -len(".qkv")]
                 q, kk, vv = v.chunk(3, 0)

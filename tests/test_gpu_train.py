@@ -1,0 +1,92 @@
+"""The training step on a real MI355X: seervideoldm_amd.trainer.SeerTrainer over libseer_hip.so against autograd of the CPU
+oracle (oracle/seer_oracle.py::train_loss_and_grads, itself pinned to the reference's step by tests/golden/train_tiny.npz)
+on the same seeded weights and inputs.  Tolerances are relative L2 over all trainable tensors: bf16 activations and bf16
+P / dS inside the attention backward give 1-3e-2."""
+import pytest
+import torch
+
+from oracle import seer_oracle as O
+from seervideoldm_amd import FSTextTransformer, SeerUNet, synth
+from seervideoldm_amd.trainer import SeerTrainer
+
+pytestmark = pytest.mark.gpu
+
+CFG_MINI = dict(block_out_channels=(320, 320, 320, 320), layers_per_block=1, cross_attention_dim=192, attention_head_dim=8)
+CFG_WIDE = dict(block_out_channels=(320, 640, 1280, 1280), layers_per_block=1, cross_attention_dim=192, attention_head_dim=8)
+FS = dict(num_frames=16, num_layers=1, channels=192, n_heads=2, cross_attention_dim=192)
+HP = dict(lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8, max_grad_norm=0.3)
+
+
+def _randn(shape, seed):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+
+
+def _models(cfg, device):
+    usd = synth.synth_state_dict(synth.unet_param_shapes(cfg))
+    fsd = synth.synth_state_dict(synth.fstext_param_shapes(**FS))
+    unet = SeerUNet(**cfg)
+    unet.load_state_dict(usd, strict=True)
+    fst = FSTextTransformer(num_frames=FS["num_frames"], in_channels=192, out_channels=192, n_heads=2, num_layers=1,
+                            cross_attention_dim=192)
+    fst.load_state_dict(fsd, strict=True)
+    return usd, fsd, unet.to(device), fst.to(device)
+
+
+def _compare(tr, gu, gf, tol, worst_tol):
+    got = tr.trainable_state_dict_of(tr.pu.g, tr.pf.g)
+    for name, ref, mine in (("unet", gu, got["unet"]), ("fstext", gf, got["fstext"])):
+        assert set(ref) == set(mine)
+        mine = {k: v.cpu() for k, v in mine.items()}
+        num = sum(((mine[k].reshape(ref[k].shape) - ref[k]) ** 2).sum() for k in ref) ** 0.5
+        den = sum((ref[k] ** 2).sum() for k in ref) ** 0.5
+        assert torch.isfinite(num) and num / den < tol, (name, float(num / den))
+        w = max(float((mine[k].reshape(ref[k].shape) - ref[k]).norm() / (ref[k].norm() + 1e-3 * den)) for k in ref)
+        assert w < worst_tol, (name, w)
+
+
+@pytest.mark.parametrize("cfg,B,Fr,cond,H", [(CFG_MINI, 1, 3, 1, 16), (CFG_MINI, 2, 4, 2, 8), (CFG_WIDE, 1, 4, 2, 32)])
+def test_train_step_matches_oracle(device, cfg, B, Fr, cond, H):
+    usd, fsd, unet, fst = _models(cfg, device)
+    fst.set_numframe(Fr)
+    tr = SeerTrainer(unet, fst, **HP)
+    x, noise = _randn((B, 4, Fr, H, H), 1), _randn((B, 4, Fr - cond, H, H), 2)
+    text, t = _randn((B, 77, 192), 3), torch.tensor([417] * B)
+    loss = tr.forward_backward(x.to(device), noise.to(device), t.to(device), text.to(device), cond)
+    ref_loss, gu, gf, pred = O.train_loss_and_grads(usd, {**O.DEFAULT_CFG, **cfg}, fsd, x, noise, t, text, cond, fstext_heads=2)
+    assert abs(float(loss) - float(ref_loss)) < 2e-2 * float(ref_loss), (float(loss), float(ref_loss))
+    assert (tr.last_pred.cpu() - pred).norm() / pred.norm() < 3e-2
+    _compare(tr, gu, gf, 4e-2, 0.12)
+    # clip + AdamW: the oracle's update applied to OUR gradients must give OUR new parameters (kernel arithmetic), and the
+    # clip coefficient must come from the UNet gradients only
+    mine_g = {n: {k: v.cpu() for k, v in d.items()} for n, d in tr.trainable_state_dict_of(tr.pu.g, tr.pf.g).items()}
+    pu = {k: usd[k].clone().float() for k in gu}
+    pf = {k: fsd[k].clone().float() for k in gf}
+    z = lambda d: {k: torch.zeros_like(v) for k, v in d.items()}
+    O.clip_and_adamw(pu, {k: mine_g["unet"][k].reshape(pu[k].shape) for k in pu}, z(pu), z(pu), 1, HP["lr"], HP["betas"],
+                     HP["eps"], HP["weight_decay"], HP["max_grad_norm"])
+    O.clip_and_adamw(pf, {k: mine_g["fstext"][k].reshape(pf[k].shape) for k in pf}, z(pf), z(pf), 1, HP["lr"], HP["betas"],
+                     HP["eps"], HP["weight_decay"], None)
+    tr.optimizer_step()
+    new = tr.trainable_state_dict()
+    for name, ref, mine in (("unet", pu, new["unet"]), ("fstext", pf, new["fstext"])):
+        for k in ref:
+            assert (mine[k].cpu().reshape(ref[k].shape) - ref[k]).abs().max() < 1e-5, (name, k)
+
+
+def test_train_step_is_deterministic_and_loss_decreases(device):
+    usd, fsd, unet, fst = _models(CFG_MINI, device)
+    fst.set_numframe(3)
+    x, noise = _randn((1, 4, 3, 16, 16), 1).to(device), _randn((1, 4, 2, 16, 16), 2).to(device)
+    text, t = _randn((1, 77, 192), 3).to(device), torch.tensor([417], device=device)
+    grads = []
+    for _ in range(2):
+        tr = SeerTrainer(unet, fst, **HP)
+        tr.forward_backward(x, noise, t, text, 1)
+        grads.append((tr.pu.g.clone(), tr.pf.g.clone()))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+    tr = SeerTrainer(unet, fst, lr=2e-4, max_grad_norm=1.0)
+    losses = []
+    for _ in range(6):
+        losses.append(float(tr.forward_backward(x, noise, t, text, 1)))
+        tr.optimizer_step()
+    assert losses[-1] < losses[0], losses

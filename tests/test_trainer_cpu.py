@@ -1,0 +1,69 @@
+"""Host-logic test (CPU) of seervideoldm_amd.trainer.SeerTrainer: its hand-written reverse schedule (what is kept, gradient
+fan-in at residuals / skips, the stop point below the first trainable block, packed parameter layouts, clip + AdamW
+bookkeeping) driven through plain-torch stand-ins for the kernel library must reproduce autograd of the oracle.
+NOT a product path -- on a GPU box the same schedule runs on libseer_hip.so (tests/test_gpu_train.py)."""
+import pytest
+import torch
+
+from oracle import seer_oracle as O
+from seervideoldm_amd import FSTextTransformer, SeerUNet, synth
+from seervideoldm_amd.trainer import SeerTrainer
+from tests import torch_ops_backend as tob
+from tests import torch_train_ops_backend as ttob
+
+CFG = dict(block_out_channels=(320, 320, 320, 320), layers_per_block=1, cross_attention_dim=192, attention_head_dim=8)
+FS = dict(num_frames=16, num_layers=1, channels=192, n_heads=2, cross_attention_dim=192)
+HP = dict(lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8, max_grad_norm=0.3)
+
+
+def _randn(shape, seed):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+
+
+@pytest.fixture(scope="module")
+def setup():
+    usd = synth.synth_state_dict(synth.unet_param_shapes(CFG))
+    fsd = synth.synth_state_dict(synth.fstext_param_shapes(**FS))
+    unet = SeerUNet(**CFG)
+    unet.load_state_dict(usd, strict=True)
+    fst = FSTextTransformer(num_frames=FS["num_frames"], in_channels=192, out_channels=192, n_heads=2, num_layers=1,
+                            cross_attention_dim=192)
+    fst.load_state_dict(fsd, strict=True)
+    return usd, fsd, unet, fst
+
+
+@pytest.mark.parametrize("B,Fr,cond,H", [(1, 3, 1, 8), (2, 3, 2, 8)])
+def test_trainer_schedule_matches_oracle_autograd(setup, B, Fr, cond, H):
+    usd, fsd, unet, fst = setup
+    fst.set_numframe(Fr)
+    tr = SeerTrainer(unet, fst, ops=tob, tops=ttob, **HP)
+    x = _randn((B, 4, Fr, H, H), 1)
+    noise = _randn((B, 4, Fr - cond, H, H), 2)
+    text = _randn((B, 77, 192), 3)
+    t = torch.tensor([417] * B)
+    loss = tr.forward_backward(x, noise, t, text, cond)
+    ref_loss, gu, gf, pred = O.train_loss_and_grads(usd, {**O.DEFAULT_CFG, **CFG}, fsd, x, noise, t, text, cond, fstext_heads=2)
+    assert abs(float(loss) - float(ref_loss)) < 2e-2 * float(ref_loss)
+    got = tr.trainable_state_dict_of(tr.pu.g, tr.pf.g)
+    for name, ref, mine in (("unet", gu, got["unet"]), ("fstext", gf, got["fstext"])):
+        assert set(ref) == set(mine), (name, set(ref) ^ set(mine))
+        num = sum(((mine[k].reshape(ref[k].shape) - ref[k]) ** 2).sum() for k in ref) ** 0.5
+        den = sum((ref[k] ** 2).sum() for k in ref) ** 0.5
+        assert num / den < 3e-2, (name, float(num / den))
+        worst = max(ref, key=lambda k: float((mine[k].reshape(ref[k].shape) - ref[k]).norm() / (ref[k].norm() + 1e-3 * den)))
+        w = float((mine[worst].reshape(ref[worst].shape) - ref[worst]).norm() / (ref[worst].norm() + 1e-3 * den))
+        assert w < 0.08, (name, worst, w)
+    # optimizer: clip over the UNet parameters only, AdamW on both segments
+    pu = {k: usd[k].clone().float() for k in gu}
+    pf = {k: fsd[k].clone().float() for k in gf}
+    z = lambda d: {k: torch.zeros_like(v) for k, v in d.items()}
+    mine_g = tr.trainable_state_dict_of(tr.pu.g, tr.pf.g)
+    O.clip_and_adamw(pu, {k: mine_g["unet"][k].reshape(pu[k].shape) for k in pu}, z(pu), z(pu), 1, HP["lr"], HP["betas"],
+                     HP["eps"], HP["weight_decay"], HP["max_grad_norm"])
+    O.clip_and_adamw(pf, {k: mine_g["fstext"][k].reshape(pf[k].shape) for k in pf}, z(pf), z(pf), 1, HP["lr"], HP["betas"],
+                     HP["eps"], HP["weight_decay"], None)
+    tr.optimizer_step()
+    new = tr.trainable_state_dict()
+    for name, ref, mine in (("unet", pu, new["unet"]), ("fstext", pf, new["fstext"])):
+        for k in ref:
+            assert (mine[k].reshape(ref[k].shape) - ref[k]).abs().max() < 1e-5, (name, k)

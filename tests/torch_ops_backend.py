@@ -93,7 +93,7 @@ def _tok_index(batch, ws, Fr, H, W):
 
 
 def attention(q, k, v, out, *, batch, heads, head_dim, Sq, Sk, causal=False, scale=None, window=None, Fq=None,
-              causal_offset=0, seq_stride_rows=1, batch_stride_rows=None):
+              causal_offset=0, seq_stride_rows=1, batch_stride_rows=None, lse=None):
     assert head_dim in (40, 80, 96, 160), "the flash kernels are built for head_dim 40/80/96/160"
     C = heads * head_dim
     scale = head_dim ** -0.5 if scale is None else scale
