@@ -37,13 +37,61 @@ __global__ void __launch_bounds__(256) transpose_kernel(const bf16* __restrict__
     }
 }
 
+// 16-byte version (cols % 8 == 0, ldx % 8 == 0, ldy % 64 == 0): a 64x64 tile goes global -> LDS by rows (8 lanes read 128
+// contiguous bytes of a row) and LDS -> global by columns (8 lanes write 128 contiguous bytes of an output row)
+__global__ void __launch_bounds__(256) transpose_vec_kernel(const bf16* __restrict__ x, int64_t rows, int cols, int ldx,
+                                                            bf16* __restrict__ y, int64_t ldy) {
+    __shared__ unsigned int tile[64][33];            // [r][c/2]: row pitch 33 words -> conflict-free column reads
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        const int r = idx >> 3, ch = idx & 7;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (r0 + r < rows && c0 + 8 * ch < cols) v = *reinterpret_cast<const u32x4*>(x + (r0 + r) * ldx + c0 + 8 * ch);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) tile[r][4 * ch + w] = v[w];
+    }
+    __syncthreads();
+    const unsigned short* t16 = reinterpret_cast<const unsigned short*>(&tile[0][0]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        const int rc = idx & 7, c = idx >> 3;            // output row c0 + c, columns r0 + 8*rc .. +7
+        if (c0 + c < cols) {
+            unsigned short e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = t16[(8 * rc + j) * 66 + c];
+            u32x4 o;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) o[w] = (unsigned int)e[2 * w] | ((unsigned int)e[2 * w + 1] << 16);
+            *reinterpret_cast<u32x4*>(y + (int64_t)(c0 + c) * ldy + r0 + 8 * rc) = o;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
-// column-owner partial sums: a thread owns 8 adjacent columns and walks CS_ROWS rows; NV values per element.
+// column partial sums: the block's 256 threads are cpp column owners (8 adjacent columns each) x rows_par row lanes over a
+// chunk of g.chunk_rows rows; row lanes are added through LDS in lane order; NV values per element.
 // ws layout: [batch][chunk][NV][C]
 struct ColGeom {
-    int C, nchunks;
+    int C, nchunks, chunk_rows, cpp, rows_par;
     int64_t rows_per_batch;
 };
+
+ColGeom col_geom(int C, int64_t rows_per_batch) {
+    ColGeom g;
+    g.C = C;
+    const int nc8 = C / 8;
+    g.cpp = nc8 < 256 ? nc8 : 256;
+    g.rows_par = 256 / g.cpp;
+    g.chunk_rows = g.rows_par >= 2 ? 64 : CS_ROWS;
+    g.nchunks = (int)((rows_per_batch + g.chunk_rows - 1) / g.chunk_rows);
+    g.rows_per_batch = rows_per_batch;
+    return g;
+}
+int col_blocks(const ColGeom& g) { return (g.C / 8 + g.cpp - 1) / g.cpp; }
 
 // KIND 0: sum x          (bias gradients)
 // KIND 1: LayerNorm      v0 = dy, v1 = dy * xhat        (rowstats = mean, rstd per row)
@@ -52,101 +100,147 @@ struct ColArgs {
     const bf16* x1; const bf16* x2; const bf16* dy;
     int C1, ldx, lddy;
     const float* rowstats;       // KIND 1
-    const float* mean_rstd;      // KIND 2: [batch][groups][2]
+    const float* stats;          // KIND 2: (sum, sumsq) [batch][groups][2] of the forward
+    float inv_count, eps;
     const float* gamma; const float* beta;
     int cpg, groups, silu;
 };
 
+// (sum, sumsq) -> (mean, rstd): the arithmetic of gn_apply_kernel
+__device__ __forceinline__ void gn_mean_rstd(const ColArgs& a, int b, int grp, float& mean, float& rstd) {
+    const float* st = a.stats + ((int64_t)b * a.groups + grp) * 2;
+    mean = st[0] * a.inv_count;
+    const float var = fmaxf(st[1] * a.inv_count - mean * mean, 0.f);
+    rstd = rsqrtf(var + a.eps);
+}
+
 template <int KIND>
 __global__ void __launch_bounds__(256) colpartial_kernel(const ColArgs a, const ColGeom g, float* __restrict__ ws) {
     constexpr int NV = KIND == 0 ? 1 : 2;
-    const int c0 = (blockIdx.y * 256 + threadIdx.x) * 8;
-    if (c0 >= g.C) return;
+    extern __shared__ float red[];                   // [rows_par][cpp][NV*8]
+    const int tc = threadIdx.x % g.cpp, rl = threadIdx.x / g.cpp;
+    const int c0 = (blockIdx.y * g.cpp + tc) * 8;
+    const bool active = c0 < g.C && rl < g.rows_par;
     const int b = blockIdx.z;
-    const int64_t r0 = (int64_t)blockIdx.x * CS_ROWS;
-    const int64_t r1 = min(r0 + (int64_t)CS_ROWS, g.rows_per_batch);
+    const int64_t r0 = (int64_t)blockIdx.x * g.chunk_rows;
+    const int64_t r1 = min(r0 + (int64_t)g.chunk_rows, g.rows_per_batch);
     float s0[8], s1[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
-    float sc[8], sh[8], gm[8], bt[8];
-    if constexpr (KIND == 2) {
+    if (active) {
+        float sc[8], sh[8], gm[8], bt[8];
+        if constexpr (KIND == 2) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int grp = (c0 + e) / a.cpg;
-            const float mean = a.mean_rstd[((int64_t)b * a.groups + grp) * 2], rstd = a.mean_rstd[((int64_t)b * a.groups + grp) * 2 + 1];
-            sc[e] = rstd;
-            sh[e] = -mean * rstd;
-            gm[e] = a.gamma[c0 + e];
-            bt[e] = a.beta[c0 + e];
+            for (int e = 0; e < 8; ++e) {
+                float mean, rstd;
+                gn_mean_rstd(a, b, (c0 + e) / a.cpg, mean, rstd);
+                sc[e] = rstd;
+                sh[e] = -mean * rstd;
+                gm[e] = a.gamma[c0 + e];
+                bt[e] = a.beta[c0 + e];
+            }
         }
-    }
-    const bf16* src = a.x1;
-    int ld = a.ldx, cc = c0;
-    if constexpr (KIND == 2) {
-        if (c0 >= a.C1) { src = a.x2; ld = g.C - a.C1; cc = c0 - a.C1; }
-        else ld = a.C1;
-    }
-    for (int64_t r = r0; r < r1; ++r) {
-        const int64_t row = (int64_t)b * g.rows_per_batch + r;
-        float f[8];
-        unpack8(*reinterpret_cast<const u32x4*>(src + row * ld + cc), f);
-        if constexpr (KIND == 0) {
+        const bf16* src = a.x1;
+        int ld = a.ldx, cc = c0;
+        if constexpr (KIND == 2) {
+            if (c0 >= a.C1) { src = a.x2; ld = g.C - a.C1; cc = c0 - a.C1; }
+            else ld = a.C1;
+        }
+        for (int64_t r = r0 + rl; r < r1; r += g.rows_par) {
+            const int64_t row = (int64_t)b * g.rows_per_batch + r;
+            float f[8];
+            unpack8(*reinterpret_cast<const u32x4*>(src + row * ld + cc), f);
+            if constexpr (KIND == 0) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s0[e] += f[e];
-        } else {
-            float d[8];
-            unpack8(*reinterpret_cast<const u32x4*>(a.dy + row * a.lddy + c0), d);
-            if constexpr (KIND == 1) {
-                const float mean = a.rowstats[row * 2], rstd = a.rowstats[row * 2 + 1];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    s0[e] += d[e];
-                    s1[e] += d[e] * (f[e] - mean) * rstd;
-                }
+                for (int e = 0; e < 8; ++e) s0[e] += f[e];
             } else {
+                float d[8];
+                unpack8(*reinterpret_cast<const u32x4*>(a.dy + row * a.lddy + c0), d);
+                if constexpr (KIND == 1) {
+                    const float mean = a.rowstats[row * 2], rstd = a.rowstats[row * 2 + 1];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float xh = f[e] * sc[e] + sh[e];
-                    float gy = d[e];
-                    if (a.silu) gy *= silu_grad_f(xh * gm[e] + bt[e]);
-                    s0[e] += gy;
-                    s1[e] += gy * xh;
+                    for (int e = 0; e < 8; ++e) {
+                        s0[e] += d[e];
+                        s1[e] += d[e] * (f[e] - mean) * rstd;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float xh = f[e] * sc[e] + sh[e];
+                        float gy = d[e];
+                        if (a.silu) gy *= silu_grad_f(xh * gm[e] + bt[e]);
+                        s0[e] += gy;
+                        s1[e] += gy * xh;
+                    }
                 }
             }
         }
     }
-    float* o = ws + (((int64_t)b * g.nchunks + blockIdx.x) * NV) * g.C + c0;
+    if (g.rows_par > 1) {
+        if (rl < g.rows_par) {
+            float* o = red + ((size_t)rl * g.cpp + tc) * (NV * 8);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = s0[e];
-    if constexpr (NV == 2) {
+            for (int e = 0; e < 8; ++e) o[e] = s0[e];
+            if constexpr (NV == 2) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[g.C + e] = s1[e];
+                for (int e = 0; e < 8; ++e) o[8 + e] = s1[e];
+            }
+        }
+        __syncthreads();
+        if (rl == 0) {
+            for (int l = 1; l < g.rows_par; ++l) {
+                const float* o = red + ((size_t)l * g.cpp + tc) * (NV * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s0[e] += o[e];
+                if constexpr (NV == 2) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s1[e] += o[8 + e];
+                }
+            }
+        }
+    }
+    if (rl == 0 && c0 < g.C) {
+        float* o = ws + (((int64_t)b * g.nchunks + blockIdx.x) * NV) * g.C + c0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = s0[e];
+        if constexpr (NV == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[g.C + e] = s1[e];
+        }
     }
 }
 
-// out[v][c] (+)= sum over (batch, chunk) of ws[b][chunk][v][c], in order
+// out_v[z][c] = sum over k < nblocks of ws[z][k][v][c], in a fixed order: 64 columns x 4 k-lanes per block
+// grid (ceil(C/64), NV, nz); outputs out0 / out1 are [nz][C] (either may be NULL)
 __global__ void __launch_bounds__(256) colfinal_kernel(const float* __restrict__ ws, int nblocks, int NV, int C,
                                                        float* __restrict__ out0, float* __restrict__ out1) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    for (int v = 0; v < NV; ++v) {
-        float s = 0.f;
-        for (int k = 0; k < nblocks; ++k) s += ws[((int64_t)k * NV + v) * C + c];
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, kl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int v = blockIdx.y, z = blockIdx.z;
+    float s = 0.f;
+    if (c < C) {
+        const float* w = ws + ((int64_t)z * nblocks * NV + v) * C + c;
+        for (int k = kl; k < nblocks; k += 4) s += w[(int64_t)k * NV * C];
+    }
+    red[kl][cl] = s;
+    __syncthreads();
+    if (kl == 0 && c < C) {
         float* o = v == 0 ? out0 : out1;
-        if (o) o[c] = s;
+        if (o) o[(int64_t)z * C + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
     }
 }
 
-// GroupNorm: per (b, c) sums -> per (b, g) projections s1 = sum_c gamma_c A_bc, s2 = sum_c gamma_c B_bc (scaled by
-// 1/count), and dgamma_c = sum_b B_bc, dbeta_c = sum_b A_bc.  One block per group.
-__global__ void __launch_bounds__(64) gn_bwd_group_kernel(const float* __restrict__ ws, int batch, int nchunks, int C, int cpg,
-                                                          int groups, const float* __restrict__ gamma, float inv_count,
-                                                          float* __restrict__ proj /* [batch][groups][2] */,
+// GroupNorm: per (b, c) sums A = sum gy, Bv = sum gy xhat (sums[b][{A,Bv}][C]) -> per (b, g) projections
+// s1 = sum_c gamma_c A_bc, s2 = sum_c gamma_c B_bc (scaled by 1/count), and dgamma_c = sum_b B_bc, dbeta_c = sum_b A_bc.
+// One block per group; a thread owns channels t and t + 64 of the group (cpg <= 128).
+__global__ void __launch_bounds__(64) gn_bwd_group_kernel(const float* __restrict__ sumsA, const float* __restrict__ sumsB, int batch,
+                                                          int C, int cpg, int groups, const float* __restrict__ gamma,
+                                                          float inv_count, float* __restrict__ proj /* [batch][groups][2] */,
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
     const int grp = blockIdx.x;
     const int t = threadIdx.x;
-    __shared__ float red[2][64];
-    float dg[2] = {0.f, 0.f}, db[2] = {0.f, 0.f};       // a thread owns channels t and t + 64 of the group (cpg <= 128)
+    float dg[2] = {0.f, 0.f}, db[2] = {0.f, 0.f};
     for (int b = 0; b < batch; ++b) {
         float pa = 0.f, pb = 0.f;
 #pragma unroll
@@ -154,28 +248,19 @@ __global__ void __launch_bounds__(64) gn_bwd_group_kernel(const float* __restric
             const int cl = t + 64 * k2;
             if (cl < cpg) {
                 const int c = grp * cpg + cl;
-                float A = 0.f, Bv = 0.f;
-                for (int k = 0; k < nchunks; ++k) {
-                    const float* w = ws + (((int64_t)b * nchunks + k) * 2) * C + c;
-                    A += w[0];
-                    Bv += w[C];
-                }
+                const float A = sumsA[(int64_t)b * C + c], Bv = sumsB[(int64_t)b * C + c];
                 pa += gamma[c] * A;
                 pb += gamma[c] * Bv;
                 dg[k2] += Bv;
                 db[k2] += A;
             }
         }
-        red[0][t] = pa;
-        red[1][t] = pb;
-        __syncthreads();
+        pa = wave_sum(pa);
+        pb = wave_sum(pb);
         if (t == 0) {
-            float s1 = 0.f, s2 = 0.f;
-            for (int i = 0; i < 64; ++i) { s1 += red[0][i]; s2 += red[1][i]; }
-            proj[((int64_t)b * groups + grp) * 2] = s1 * inv_count;
-            proj[((int64_t)b * groups + grp) * 2 + 1] = s2 * inv_count;
+            proj[((int64_t)b * groups + grp) * 2] = pa * inv_count;
+            proj[((int64_t)b * groups + grp) * 2 + 1] = pb * inv_count;
         }
-        __syncthreads();
     }
     if (dgamma) {
 #pragma unroll
@@ -193,17 +278,19 @@ __global__ void __launch_bounds__(64) gn_bwd_group_kernel(const float* __restric
 __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const ColArgs a, const ColGeom g, const float* __restrict__ proj,
                                                            const bf16* __restrict__ dres1, const bf16* __restrict__ dres2,
                                                            bf16* __restrict__ dx1, bf16* __restrict__ dx2) {
-    const int c0 = (blockIdx.y * 256 + threadIdx.x) * 8;
-    if (c0 >= g.C) return;
+    const int tc = threadIdx.x % g.cpp, rl = threadIdx.x / g.cpp;
+    const int c0 = (blockIdx.y * g.cpp + tc) * 8;
+    if (c0 >= g.C || rl >= g.rows_par) return;
     const int b = blockIdx.z;
-    const int64_t r0 = (int64_t)blockIdx.x * CS_ROWS;
-    const int64_t r1 = min(r0 + (int64_t)CS_ROWS, g.rows_per_batch);
+    const int64_t r0 = (int64_t)blockIdx.x * g.chunk_rows;
+    const int64_t r1 = min(r0 + (int64_t)g.chunk_rows, g.rows_per_batch);
     float sc[8], sh[8], gm[8], bt[8], p1[8], p2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int grp = (c0 + e) / a.cpg;
         const int64_t gi = ((int64_t)b * a.groups + grp) * 2;
-        const float mean = a.mean_rstd[gi], rstd = a.mean_rstd[gi + 1];
+        float mean, rstd;
+        gn_mean_rstd(a, b, grp, mean, rstd);
         sc[e] = rstd;
         sh[e] = -mean * rstd;
         gm[e] = a.gamma[c0 + e];
@@ -217,7 +304,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const ColArgs a, cons
     bf16* dst = second ? dx2 : dx1;
     const int ld = second ? g.C - a.C1 : a.C1;
     const int cc = second ? c0 - a.C1 : c0;
-    for (int64_t r = r0; r < r1; ++r) {
+    for (int64_t r = r0 + rl; r < r1; r += g.rows_par) {
         const int64_t row = (int64_t)b * g.rows_per_batch + r;
         float f[8], d[8], o[8];
         unpack8(*reinterpret_cast<const u32x4*>(src + row * ld + cc), f);
@@ -237,16 +324,6 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const ColArgs a, cons
         }
         *reinterpret_cast<u32x4*>(dst + row * ld + cc) = pack8(o);
     }
-}
-
-// (sum, sumsq) -> (mean, rstd) per (b, g), the arithmetic of gn_apply_kernel
-__global__ void gn_mean_rstd_kernel(const float* __restrict__ stats, int n, float inv_count, float eps, float* __restrict__ out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float mean = stats[2 * i] * inv_count;
-    const float var = fmaxf(stats[2 * i + 1] * inv_count - mean * mean, 0.f);
-    out[2 * i] = mean;
-    out[2 * i + 1] = rsqrtf(var + eps);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -546,7 +623,6 @@ __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const
     }
 }
 
-int col_blocks(int C) { return (C / 8 + 255) / 256; }
 
 }  // namespace
 
@@ -555,6 +631,13 @@ extern "C" int seer_transpose_bf16(const void* x, int64_t rows, int32_t cols, in
     if (!x || !y || rows <= 0 || cols <= 0 || ldx < cols || ldy < rows) return SEER_EINVAL;
     const int64_t rows_pad = ldy;
     dim3 grid((unsigned)((rows_pad + 63) / 64), (unsigned)((cols + 63) / 64));
+    if (cols % 8 == 0 && ldx % 8 == 0 && ldy % 64 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
+        hipLaunchKernelGGL(transpose_vec_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           reinterpret_cast<const bf16*>(x), rows, cols, ldx, reinterpret_cast<bf16*>(y), ldy);
+        SEER_LAUNCH_CHECK();
+        return SEER_OK;
+    }
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        reinterpret_cast<const bf16*>(x), rows, cols, ldx, reinterpret_cast<bf16*>(y), ldy, rows_pad);
     SEER_LAUNCH_CHECK();
@@ -570,13 +653,14 @@ extern "C" int seer_colsum_bf16(const void* x, int64_t rows, int32_t cols, int32
                                 void* stream) {
     if (!x || !out || !workspace || rows <= 0 || cols <= 0 || cols % 8 || ldx % 8) return SEER_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    ColGeom g{cols, (int)((rows + CS_ROWS - 1) / CS_ROWS), rows};
+    const ColGeom g = col_geom(cols, rows);
     ColArgs a{};
     a.x1 = reinterpret_cast<const bf16*>(x);
     a.ldx = ldx;
-    hipLaunchKernelGGL(colpartial_kernel<0>, dim3(g.nchunks, col_blocks(cols), 1), dim3(256), 0, st, a, g, workspace);
+    const size_t lds = (size_t)g.rows_par * g.cpp * 8 * sizeof(float);
+    hipLaunchKernelGGL(colpartial_kernel<0>, dim3(g.nchunks, col_blocks(g), 1), dim3(256), lds, st, a, g, workspace);
     SEER_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colfinal_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, workspace, g.nchunks, 1, cols, out,
+    hipLaunchKernelGGL(colfinal_kernel, dim3((cols + 63) / 64, 1, 1), dim3(256), 0, st, workspace, g.nchunks, 1, cols, out,
                        (float*)nullptr);
     SEER_LAUNCH_CHECK();
     return SEER_OK;
@@ -597,7 +681,7 @@ extern "C" int seer_layernorm_bwd(const void* x, const void* dy, int64_t rows, i
     bf16* dxb = reinterpret_cast<bf16*>(dx);
     int64_t blocks = (rows + 3) / 4;
     if (blocks > 4096) blocks = 4096;
-    ColGeom g{C, (int)((rows + CS_ROWS - 1) / CS_ROWS), rows};
+    const ColGeom g = col_geom(C, rows);
     float* rowstats = dgamma ? workspace + (int64_t)g.nchunks * 2 * C : nullptr;
 #define SEER_LNB(MC) hipLaunchKernelGGL(ln_bwd_rows_kernel<MC>, dim3((unsigned)blocks), dim3(256), 0, st, xb, dyb, rows, C, ldx, \
                                         lddy, gamma, eps, rb, ldres, dxb, lddx, rowstats)
@@ -613,9 +697,10 @@ extern "C" int seer_layernorm_bwd(const void* x, const void* dy, int64_t rows, i
         a.ldx = ldx;
         a.lddy = lddy;
         a.rowstats = rowstats;
-        hipLaunchKernelGGL(colpartial_kernel<1>, dim3(g.nchunks, col_blocks(C), 1), dim3(256), 0, st, a, g, workspace);
+        const size_t lds = (size_t)g.rows_par * g.cpp * 16 * sizeof(float);
+        hipLaunchKernelGGL(colpartial_kernel<1>, dim3(g.nchunks, col_blocks(g), 1), dim3(256), lds, st, a, g, workspace);
         SEER_LAUNCH_CHECK();
-        hipLaunchKernelGGL(colfinal_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, g.nchunks, 2, C, dbeta, dgamma);
+        hipLaunchKernelGGL(colfinal_kernel, dim3((C + 63) / 64, 2, 1), dim3(256), 0, st, workspace, g.nchunks, 2, C, dbeta, dgamma);
         SEER_LAUNCH_CHECK();
     }
     return SEER_OK;
@@ -623,8 +708,8 @@ extern "C" int seer_layernorm_bwd(const void* x, const void* dy, int64_t rows, i
 
 extern "C" int64_t seer_groupnorm_bwd_workspace_floats(int32_t C, int32_t batch, int64_t rows_per_batch, int32_t groups) {
     if (C <= 0 || batch <= 0 || rows_per_batch <= 0 || groups <= 0) return SEER_EINVAL;
-    const int64_t nchunks = (rows_per_batch + CS_ROWS - 1) / CS_ROWS;
-    return (int64_t)batch * nchunks * 2 * C + 4 * (int64_t)batch * groups;
+    const int64_t nchunks = (rows_per_batch + CS_ROWS - 1) / CS_ROWS;          // upper bound over the chunk sizes in use
+    return (int64_t)batch * nchunks * 2 * C + 2 * (int64_t)batch * C + 2 * (int64_t)batch * groups;
 }
 
 extern "C" int seer_groupnorm_bwd(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t batch,
@@ -641,30 +726,32 @@ extern "C" int seer_groupnorm_bwd(const void* x1, int32_t C1, const void* x2, in
     if ((dgamma != nullptr) != (dbeta != nullptr)) return SEER_EINVAL;
     if (C / groups > 128) return SEER_ENOSYS;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    ColGeom g{C, (int)((rows_per_batch + CS_ROWS - 1) / CS_ROWS), rows_per_batch};
-    float* proj = workspace + (int64_t)batch * g.nchunks * 2 * C;       // [batch][groups][2]
-    float* mean_rstd = proj + 2 * (int64_t)batch * groups;
-    const float inv_count = (float)(1.0 / count);
-    hipLaunchKernelGGL(gn_mean_rstd_kernel, dim3((batch * groups + 255) / 256), dim3(256), 0, st, stats, batch * groups,
-                       inv_count, eps, mean_rstd);
-    SEER_LAUNCH_CHECK();
+    const ColGeom g = col_geom(C, rows_per_batch);
+    float* sums = workspace + (int64_t)batch * ((rows_per_batch + CS_ROWS - 1) / CS_ROWS) * 2 * C;      // [2][batch][C]
+    float* proj = sums + 2 * (int64_t)batch * C;                                                      // [batch][groups][2]
     ColArgs a{};
     a.x1 = reinterpret_cast<const bf16*>(x1);
     a.x2 = reinterpret_cast<const bf16*>(x2);
     a.dy = reinterpret_cast<const bf16*>(dy);
     a.C1 = C1;
     a.lddy = C;
-    a.mean_rstd = mean_rstd;
+    a.stats = stats;
+    a.inv_count = (float)(1.0 / count);
+    a.eps = eps;
     a.gamma = gamma;
     a.beta = beta;
     a.cpg = C / groups;
     a.groups = groups;
     a.silu = silu;
-    dim3 grid(g.nchunks, col_blocks(C), batch);
-    hipLaunchKernelGGL(colpartial_kernel<2>, grid, dim3(256), 0, st, a, g, workspace);
+    dim3 grid(g.nchunks, col_blocks(g), batch);
+    const size_t lds = (size_t)g.rows_par * g.cpp * 16 * sizeof(float);
+    hipLaunchKernelGGL(colpartial_kernel<2>, grid, dim3(256), lds, st, a, g, workspace);
     SEER_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(groups), dim3(64), 0, st, workspace, batch, g.nchunks, C, a.cpg, groups, gamma,
-                       inv_count, proj, dgamma, dbeta);
+    hipLaunchKernelGGL(colfinal_kernel, dim3((C + 63) / 64, 2, batch), dim3(256), 0, st, workspace, g.nchunks, 2, C, sums,
+                       sums + (int64_t)batch * C);
+    SEER_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(groups), dim3(64), 0, st, sums, sums + (int64_t)batch * C, batch, C, a.cpg, groups,
+                       gamma, a.inv_count, proj, dgamma, dbeta);
     SEER_LAUNCH_CHECK();
     hipLaunchKernelGGL(gn_bwd_apply_kernel, grid, dim3(256), 0, st, a, g, proj, reinterpret_cast<const bf16*>(dres1),
                        reinterpret_cast<const bf16*>(dres2), reinterpret_cast<bf16*>(dx1), reinterpret_cast<bf16*>(dx2));
