@@ -23,7 +23,7 @@ def build(device, cfg=None, fs_layers=8):
     return unet.to(device), fst.to(device)
 
 
-def time_train(device, steps=5, warmup=2, Fr=12, cond=2, lat=32, b=1):
+def time_train(device, steps=5, warmup=2, Fr=12, cond=2, lat=32, b=1, use_graph=True):
     unet, fst = build(device)
     fst.set_numframe(Fr)
     tr = SeerTrainer(unet, fst, lr=1e-5, max_grad_norm=0.3)
@@ -33,11 +33,14 @@ def time_train(device, steps=5, warmup=2, Fr=12, cond=2, lat=32, b=1):
     text = torch.randn((b, 77, 768), generator=g).to(device)
     t = torch.tensor([500] * b, device=device)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    fb, opt, losses = [], [], []
+    fb, opt, losses, host = [], [], [], []
     for i in range(warmup + steps):
+        torch.cuda.synchronize()
+        h0 = time.perf_counter()
         ev[0].record()
-        loss = tr.forward_backward(x, noise, t, text, cond)
+        loss = tr.forward_backward(x, noise, t, text, cond, use_graph=use_graph)
         ev[1].record()
+        host.append((time.perf_counter() - h0) * 1e3)
         tr.optimizer_step()
         ev[2].record()
         torch.cuda.synchronize()
@@ -47,7 +50,7 @@ def time_train(device, steps=5, warmup=2, Fr=12, cond=2, lat=32, b=1):
             opt.append(ev[1].elapsed_time(ev[2]))
     n_u, n_f = tr.pu.n, tr.pf.n
     return {"config": f"b={b} F={Fr} cond={cond} latent={lat}x{lat} (BASELINE config 5), bf16 compute, fp32 master/AdamW",
-            "fwd_bwd_ms": sum(fb) / len(fb), "optimizer_ms": sum(opt) / len(opt),
+            "hipgraph": bool(use_graph and not getattr(tr, "_graph_broken", False)), "fwd_bwd_ms": sum(fb) / len(fb), "optimizer_ms": sum(opt) / len(opt), "host_enqueue_ms": sum(host[warmup:]) / len(host[warmup:]),
             "ms_per_step": (sum(fb) + sum(opt)) / len(fb), "steps": steps, "trainable_params": int(n_u + n_f),
             "loss_first": losses[0], "loss_last": losses[-1],
             "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
@@ -58,6 +61,6 @@ if __name__ == "__main__":
     Fr = int(sys.argv[2]) if len(sys.argv) > 2 else 12
     lat = int(sys.argv[3]) if len(sys.argv) > 3 else 32
     t0 = time.time()
-    r = time_train(torch.device("cuda:0"), steps=steps, Fr=Fr, lat=lat)
+    r = time_train(torch.device("cuda:0"), steps=steps, Fr=Fr, lat=lat, use_graph="--eager" not in sys.argv)
     r["wall_s"] = time.time() - t0
     print(json.dumps(r))

@@ -520,7 +520,12 @@ class SeerTrainer:
         rot_dim = min(32, d)
         ctx = context.reshape(b * l, cdim)
         ctx = ops.cast_bf16(ctx.float().contiguous()) if ctx.dtype != bf16 else ctx.contiguous()
-        src = self._pos_frames(Fr).to(context.device)
+        src = self._pos_src.get(Fr) if hasattr(self, "_pos_src") else None
+        if src is None:
+            if not hasattr(self, "_pos_src"):
+                self._pos_src = {}
+            src = self._pos_frames(Fr).to(context.device)
+            self._pos_src[Fr] = src
         pos = W["pos_embed"][0, src, :l, :]                                   # fp32 master [F, l, C]
         x = (W["learnable_query"].reshape(1, 1, C) + pos).unsqueeze(0).expand(b, Fr, l, C).reshape(b * Fr * l, C)
         x = ops.cast_bf16(x.contiguous())
@@ -604,16 +609,55 @@ class SeerTrainer:
         gp = G("pos_embed")
         gp.zero_()
         dxf = dx.float().reshape(b, Fr, l, C).sum(0) if b > 1 else dx.float().reshape(Fr, l, C)
-        gp[0, :, :l, :].index_add_(0, src, dxf)
+        if Fr <= gp.shape[1]:
+            gp[0, src, :l, :] = dxf                 # every source frame is read by at most one output frame
+        else:
+            gp[0, :, :l, :].index_add_(0, src, dxf)
 
     # ================================================================================================ the step
     def forward_backward(self, model_input: torch.Tensor, target: torch.Tensor, timesteps: torch.Tensor,
-                         text_cond_emb: torch.Tensor, cond_frames: int) -> torch.Tensor:
+                         text_cond_emb: torch.Tensor, cond_frames: int, use_graph: bool = False) -> torch.Tensor:
         """model_input [b, 4, F, h, w] fp32 = cat[latents_x0, noisy_latents] (train.py:364-365); target = the noise
         [b, 4, F - cond, h, w]; text_cond_emb [b, 77, 768] (CLIP last hidden state).  Fills the gradient buffers and returns
-        the loss (1-element device tensor)."""
+        the loss (1-element device tensor).  use_graph: replay the whole forward + backward (~2.5k launches, shape-static) as
+        one hipGraph -- eager, the step is bound by the host's launch rate, not by the GPU."""
         if not model_input.is_cuda and self.ops is hip_ops:
             raise hip_ops._lib.SeerHipError("SeerTrainer needs ROCm tensors: the HIP kernels are the only compute path")
+        if use_graph and not getattr(self, "_graph_broken", False):
+            return self._forward_backward_graph(model_input, target, timesteps, text_cond_emb, cond_frames)
+        return self._forward_backward(model_input, target, timesteps, text_cond_emb, cond_frames)
+
+    def _forward_backward_graph(self, model_input, target, timesteps, text_cond_emb, cond_frames):
+        b = model_input.shape[0]
+        t = timesteps if torch.is_tensor(timesteps) else torch.tensor([timesteps] * b)
+        t = t.to(model_input.device, torch.int64).expand(b).contiguous()
+        key = (tuple(model_input.shape), tuple(text_cond_emb.shape), cond_frames)
+        if not hasattr(self, "_graphs"):
+            self._graphs = {}
+        g = self._graphs.get(key)
+        if g is None:
+            bufs = [model_input.float().clone(), target.float().clone(), t.clone(), text_cond_emb.float().clone()]
+            self._forward_backward(*bufs, cond_frames)            # eager warm-up: builds the transposed frozen weights, tables
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(graph):
+                    loss = self._forward_backward(*bufs, cond_frames)
+            except Exception as e:                                 # capture refused: stay correct, run eagerly
+                self._graph_broken = True
+                import warnings
+                warnings.warn(f"hipGraph capture of the training step failed ({type(e).__name__}: {e}); running eagerly")
+                return self._forward_backward(model_input, target, timesteps, text_cond_emb, cond_frames)
+            g = (graph, bufs, loss, self.last_pred)
+            self._graphs = {key: g}
+        graph, bufs, loss, pred = g
+        for dst, src in zip(bufs, (model_input, target, t, text_cond_emb)):
+            dst.copy_(src)
+        graph.replay()
+        self.last_pred = pred
+        return loss
+
+    def _forward_backward(self, model_input, target, timesteps, text_cond_emb, cond_frames):
         b, _, Fr, _, _ = model_input.shape
         assert self.fstext.num_frames == Fr, "fstext.set_numframe(F) first (train.py:187)"
         y, fs_saved = self._fstext_fwd(text_cond_emb)                     # [b*F*l, Dc] bf16, rows (b, f, l)

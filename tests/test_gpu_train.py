@@ -90,3 +90,24 @@ def test_train_step_is_deterministic_and_loss_decreases(device):
         losses.append(float(tr.forward_backward(x, noise, t, text, 1)))
         tr.optimizer_step()
     assert losses[-1] < losses[0], losses
+
+
+def test_train_step_graph_replay_is_bit_identical(device):
+    """the hipGraph replay of forward + backward must reproduce the eager step bit for bit, also after the weights moved"""
+    usd, fsd, unet, fst = _models(CFG_MINI, device)
+    fst.set_numframe(4)
+    mk = lambda s: (_randn((1, 4, 4, 16, 16), s).to(device), _randn((1, 4, 2, 16, 16), s + 1).to(device),
+                    _randn((1, 77, 192), s + 2).to(device), torch.tensor([100 + s], device=device))
+    runs = []
+    for use_graph in (False, True):
+        tr = SeerTrainer(unet, fst, **HP)
+        out = []
+        for s in (1, 11, 21):
+            x, noise, text, t = mk(s)
+            loss = tr.forward_backward(x, noise, t, text, 2, use_graph=use_graph)
+            out.append((float(loss), tr.pu.g.clone(), tr.pf.g.clone()))
+            tr.optimizer_step()
+        assert use_graph is False or not getattr(tr, "_graph_broken", False)
+        runs.append(out)
+    for (l0, gu0, gf0), (l1, gu1, gf1) in zip(*runs):
+        assert l0 == l1 and torch.equal(gu0, gu1) and torch.equal(gf0, gf1)
