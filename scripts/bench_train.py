@@ -57,9 +57,10 @@ def time_train(device, steps=5, warmup=2, Fr=12, cond=2, lat=32, b=1, use_graph=
 
 
 if __name__ == "__main__":
-    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-    Fr = int(sys.argv[2]) if len(sys.argv) > 2 else 12
-    lat = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+    pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+    steps = int(pos[0]) if len(pos) > 0 else 5
+    Fr = int(pos[1]) if len(pos) > 1 else 12
+    lat = int(pos[2]) if len(pos) > 2 else 32
     t0 = time.time()
     r = time_train(torch.device("cuda:0"), steps=steps, Fr=Fr, lat=lat, use_graph="--eager" not in sys.argv)
     r["wall_s"] = time.time() - t0

@@ -7,7 +7,7 @@
 
 namespace {
 
-constexpr int CS_ROWS = 32;       // rows per block of the column-owner partial-sum kernels
+constexpr int CS_ROWS_MIN = 8;    // fewest rows a block of the column partial-sum kernels covers (bounds the workspace)
 
 __device__ __forceinline__ float silu_grad_f(float z) {
     const float s = 1.0f / (1.0f + __expf(-z));
@@ -80,13 +80,20 @@ struct ColGeom {
     int64_t rows_per_batch;
 };
 
-ColGeom col_geom(int C, int64_t rows_per_batch) {
+ColGeom col_geom(int C, int64_t rows_per_batch, int batch = 1) {
     ColGeom g;
     g.C = C;
     const int nc8 = C / 8;
     g.cpp = nc8 < 256 ? nc8 : 256;
     g.rows_par = 256 / g.cpp;
-    g.chunk_rows = g.rows_par >= 2 ? 64 : CS_ROWS;
+    // rows per block: aim at ~1024 blocks so that every level fills the 256 CUs, at least two rows per row lane and
+    // CS_ROWS_MIN rows (the workspace bound), at most 64
+    const int colblocks = (nc8 + g.cpp - 1) / g.cpp;
+    int64_t cr = rows_per_batch * colblocks * batch / 1024;
+    if (cr < 2 * g.rows_par) cr = 2 * g.rows_par;
+    if (cr < CS_ROWS_MIN) cr = CS_ROWS_MIN;
+    if (cr > 64) cr = 64;
+    g.chunk_rows = (int)cr;
     g.nchunks = (int)((rows_per_batch + g.chunk_rows - 1) / g.chunk_rows);
     g.rows_per_batch = rows_per_batch;
     return g;
@@ -210,24 +217,27 @@ __global__ void __launch_bounds__(256) colpartial_kernel(const ColArgs a, const 
     }
 }
 
-// out_v[z][c] = sum over k < nblocks of ws[z][k][v][c], in a fixed order: 64 columns x 4 k-lanes per block
+// out_v[z][c] = sum over k < nblocks of ws[z][k][v][c], in a fixed order: 64 columns x 16 k-lanes per block
 // grid (ceil(C/64), NV, nz); outputs out0 / out1 are [nz][C] (either may be NULL)
-__global__ void __launch_bounds__(256) colfinal_kernel(const float* __restrict__ ws, int nblocks, int NV, int C,
-                                                       float* __restrict__ out0, float* __restrict__ out1) {
-    __shared__ float red[4][64];
+__global__ void __launch_bounds__(1024) colfinal_kernel(const float* __restrict__ ws, int nblocks, int NV, int C,
+                                                        float* __restrict__ out0, float* __restrict__ out1) {
+    __shared__ float red[16][64];
     const int cl = threadIdx.x & 63, kl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     const int v = blockIdx.y, z = blockIdx.z;
     float s = 0.f;
     if (c < C) {
         const float* w = ws + ((int64_t)z * nblocks * NV + v) * C + c;
-        for (int k = kl; k < nblocks; k += 4) s += w[(int64_t)k * NV * C];
+        for (int k = kl; k < nblocks; k += 16) s += w[(int64_t)k * NV * C];
     }
     red[kl][cl] = s;
     __syncthreads();
     if (kl == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) t += red[l][cl];
         float* o = v == 0 ? out0 : out1;
-        if (o) o[(int64_t)z * C + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        if (o) o[(int64_t)z * C + c] = t;
     }
 }
 
@@ -646,7 +656,7 @@ extern "C" int seer_transpose_bf16(const void* x, int64_t rows, int32_t cols, in
 
 extern "C" int64_t seer_colsum_workspace_floats(int64_t rows, int32_t cols) {
     if (rows <= 0 || cols <= 0) return SEER_EINVAL;
-    return ((rows + CS_ROWS - 1) / CS_ROWS) * 2 * (int64_t)cols + 2 * rows;
+    return ((rows + CS_ROWS_MIN - 1) / CS_ROWS_MIN) * 2 * (int64_t)cols + 2 * rows;
 }
 
 extern "C" int seer_colsum_bf16(const void* x, int64_t rows, int32_t cols, int32_t ldx, float* out, float* workspace,
@@ -660,7 +670,7 @@ extern "C" int seer_colsum_bf16(const void* x, int64_t rows, int32_t cols, int32
     const size_t lds = (size_t)g.rows_par * g.cpp * 8 * sizeof(float);
     hipLaunchKernelGGL(colpartial_kernel<0>, dim3(g.nchunks, col_blocks(g), 1), dim3(256), lds, st, a, g, workspace);
     SEER_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colfinal_kernel, dim3((cols + 63) / 64, 1, 1), dim3(256), 0, st, workspace, g.nchunks, 1, cols, out,
+    hipLaunchKernelGGL(colfinal_kernel, dim3((cols + 63) / 64, 1, 1), dim3(1024), 0, st, workspace, g.nchunks, 1, cols, out,
                        (float*)nullptr);
     SEER_LAUNCH_CHECK();
     return SEER_OK;
@@ -682,7 +692,7 @@ extern "C" int seer_layernorm_bwd(const void* x, const void* dy, int64_t rows, i
     int64_t blocks = (rows + 3) / 4;
     if (blocks > 4096) blocks = 4096;
     const ColGeom g = col_geom(C, rows);
-    float* rowstats = dgamma ? workspace + (int64_t)g.nchunks * 2 * C : nullptr;
+    float* rowstats = dgamma ? workspace + ((rows + CS_ROWS_MIN - 1) / CS_ROWS_MIN) * 2 * (int64_t)C : nullptr;
 #define SEER_LNB(MC) hipLaunchKernelGGL(ln_bwd_rows_kernel<MC>, dim3((unsigned)blocks), dim3(256), 0, st, xb, dyb, rows, C, ldx, \
                                         lddy, gamma, eps, rb, ldres, dxb, lddx, rowstats)
     if (C <= 512) SEER_LNB(1);
@@ -700,7 +710,7 @@ extern "C" int seer_layernorm_bwd(const void* x, const void* dy, int64_t rows, i
         const size_t lds = (size_t)g.rows_par * g.cpp * 16 * sizeof(float);
         hipLaunchKernelGGL(colpartial_kernel<1>, dim3(g.nchunks, col_blocks(g), 1), dim3(256), lds, st, a, g, workspace);
         SEER_LAUNCH_CHECK();
-        hipLaunchKernelGGL(colfinal_kernel, dim3((C + 63) / 64, 2, 1), dim3(256), 0, st, workspace, g.nchunks, 2, C, dbeta, dgamma);
+        hipLaunchKernelGGL(colfinal_kernel, dim3((C + 63) / 64, 2, 1), dim3(1024), 0, st, workspace, g.nchunks, 2, C, dbeta, dgamma);
         SEER_LAUNCH_CHECK();
     }
     return SEER_OK;
@@ -708,7 +718,7 @@ extern "C" int seer_layernorm_bwd(const void* x, const void* dy, int64_t rows, i
 
 extern "C" int64_t seer_groupnorm_bwd_workspace_floats(int32_t C, int32_t batch, int64_t rows_per_batch, int32_t groups) {
     if (C <= 0 || batch <= 0 || rows_per_batch <= 0 || groups <= 0) return SEER_EINVAL;
-    const int64_t nchunks = (rows_per_batch + CS_ROWS - 1) / CS_ROWS;          // upper bound over the chunk sizes in use
+    const int64_t nchunks = (rows_per_batch + CS_ROWS_MIN - 1) / CS_ROWS_MIN;  // upper bound over the chunk sizes in use
     return (int64_t)batch * nchunks * 2 * C + 2 * (int64_t)batch * C + 2 * (int64_t)batch * groups;
 }
 
@@ -726,8 +736,8 @@ extern "C" int seer_groupnorm_bwd(const void* x1, int32_t C1, const void* x2, in
     if ((dgamma != nullptr) != (dbeta != nullptr)) return SEER_EINVAL;
     if (C / groups > 128) return SEER_ENOSYS;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const ColGeom g = col_geom(C, rows_per_batch);
-    float* sums = workspace + (int64_t)batch * ((rows_per_batch + CS_ROWS - 1) / CS_ROWS) * 2 * C;      // [2][batch][C]
+    const ColGeom g = col_geom(C, rows_per_batch, batch);
+    float* sums = workspace + (int64_t)batch * ((rows_per_batch + CS_ROWS_MIN - 1) / CS_ROWS_MIN) * 2 * C;      // [2][batch][C]
     float* proj = sums + 2 * (int64_t)batch * C;                                                      // [batch][groups][2]
     ColArgs a{};
     a.x1 = reinterpret_cast<const bf16*>(x1);
@@ -747,7 +757,7 @@ extern "C" int seer_groupnorm_bwd(const void* x1, int32_t C1, const void* x2, in
     const size_t lds = (size_t)g.rows_par * g.cpp * 16 * sizeof(float);
     hipLaunchKernelGGL(colpartial_kernel<2>, grid, dim3(256), lds, st, a, g, workspace);
     SEER_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colfinal_kernel, dim3((C + 63) / 64, 2, batch), dim3(256), 0, st, workspace, g.nchunks, 2, C, sums,
+    hipLaunchKernelGGL(colfinal_kernel, dim3((C + 63) / 64, 2, batch), dim3(1024), 0, st, workspace, g.nchunks, 2, C, sums,
                        sums + (int64_t)batch * C);
     SEER_LAUNCH_CHECK();
     hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(groups), dim3(64), 0, st, sums, sums + (int64_t)batch * C, batch, C, a.cpg, groups,
