@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
+    ap.add_argument("--no-train", action="store_true", help="skip the extra fine-tuning step measurement (config 5)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="sthv2",
                     help="default = BASELINE.json's metric configuration; the others are extra measurements")
     return ap.parse_args()
@@ -289,6 +290,23 @@ def main():
                          "once per sample before it: fstext_ms = FSTextTransformer (8 layers, 182.6M params) -> context "
                          "[1,12,77,768]; vae_encode_ms = SD-VAE encoder on the 2 conditioning frames -> x0_emb")
 
+    # ---- extra: one fine-tuning step (BASELINE config 5: b=1 per GPU, 12 frames, 2 conditioning frames).
+    # Data parallel for N > 1: one micro-batch per rank and one RCCL all-reduce of the flat fp32 gradient buffers.
+    train = None
+    if not args.no_train and args.workload == "sthv2":
+        from scripts.bench_train import time_train
+        pg = None
+        if world > 1:
+            import torch.distributed as dist
+            pg = dist.group.WORLD
+        train = time_train(device, steps=5, warmup=2, unet=model, process_group=pg)
+        if world > 1:
+            tms = torch.tensor([train["ms_per_step"]], device=device)
+            dist.all_reduce(tms, op=dist.ReduceOp.MAX)
+            train["ms_per_step"] = float(tms)
+        train["samples_per_s"] = round(world * 1e3 / train["ms_per_step"], 3)
+        train["parallelism"] = "single" if world == 1 else f"dp{world}"
+
     cpu = None
     if sd_cpu is not None:
         cpu = cpu_baseline(sd_cpu, cfg, args.cpu_budget_s)
@@ -304,7 +322,7 @@ def main():
             "config": {"workload": WORKLOADS[args.workload]["name"] + ", "
                                    "full-width SeerUNet 1.08G params, 50-step DDIM, scale 7.5",
                        "parallelism": par, "hip_graph": bool(not args.no_graph)},
-            "roofline": roofline, "cpu_baseline": cpu, "end_to_end": clip,
+            "roofline": roofline, "cpu_baseline": cpu, "end_to_end": clip, "train_step": train,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -79,3 +79,63 @@ def test_shard_geometry():
         covered |= {(b, f) for b in range(b0, b1) for f in range(f0, f1)}
         assert sh.local_cond_frames(2) == max(0, min(f1 - f0, 2 - f0))
     assert covered == {(b, f) for b in range(2) for f in range(12)}
+
+
+# ---- data-parallel training step (seervideoldm_amd/trainer.py): one all-reduce of the flat gradient buffers -----------------
+CFG_TRAIN = dict(block_out_channels=(320, 320, 320, 320), layers_per_block=1, cross_attention_dim=192, attention_head_dim=8)
+FS_TRAIN = dict(num_frames=16, num_layers=1, channels=192, n_heads=2, cross_attention_dim=192)
+
+
+def _train_models():
+    from seervideoldm_amd import FSTextTransformer, SeerUNet, synth
+    unet = SeerUNet(**CFG_TRAIN)
+    unet.load_state_dict(synth.synth_state_dict(synth.unet_param_shapes(CFG_TRAIN)), strict=True)
+    fst = FSTextTransformer(num_frames=16, in_channels=192, out_channels=192, n_heads=2, num_layers=1, cross_attention_dim=192)
+    fst.load_state_dict(synth.synth_state_dict(synth.fstext_param_shapes(**FS_TRAIN)), strict=True)
+    fst.set_numframe(2)
+    return unet, fst
+
+
+def _train_batch(seed):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn((1, 4, 2, 8, 8), generator=g), torch.randn((1, 4, 1, 8, 8), generator=g),
+            torch.tensor([300 + seed]), torch.randn((1, 77, 192), generator=g))
+
+
+def _train_worker(rank, world, port, out_path):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from seervideoldm_amd.trainer import SeerTrainer
+        from tests import torch_ops_backend as tob
+        from tests import torch_train_ops_backend as ttob
+        unet, fst = _train_models()
+        tr = SeerTrainer(unet, fst, lr=1e-3, max_grad_norm=0.3, ops=tob, tops=ttob, process_group=dist.group.WORLD)
+        x, noise, t, text = _train_batch(rank)                    # every rank its own micro-batch
+        loss = tr.forward_backward(x, noise, t, text, 1)
+        local = (tr.pu.g.clone(), tr.pf.g.clone())
+        tr.optimizer_step()
+        torch.save(dict(loss=loss, gu=local[0], gf=local[1], pu=tr.pu.p.clone(), pf=tr.pf.p.clone()), f"{out_path}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_train_step(tmp_path):
+    """2 ranks, one micro-batch each: after the step both hold the SAME parameters, equal to a single process stepping on the
+    mean of the two gradients (DDP semantics of accelerate, train.py:265-266,382)."""
+    out = tmp_path / "tr"
+    mp.spawn(_train_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
+    r0, r1 = torch.load(f"{out}.0"), torch.load(f"{out}.1")
+    assert torch.equal(r0["pu"], r1["pu"]) and torch.equal(r0["pf"], r1["pf"])
+    assert not torch.equal(r0["gu"], r1["gu"])
+    from seervideoldm_amd.trainer import SeerTrainer
+    from tests import torch_ops_backend as tob
+    from tests import torch_train_ops_backend as ttob
+    unet, fst = _train_models()
+    tr = SeerTrainer(unet, fst, lr=1e-3, max_grad_norm=0.3, ops=tob, tops=ttob)
+    tr.pu.g.copy_((r0["gu"] + r1["gu"]) * 0.5)
+    tr.pf.g.copy_((r0["gf"] + r1["gf"]) * 0.5)
+    tr.optimizer_step()
+    assert torch.allclose(tr.pu.p, r0["pu"], atol=1e-7) and torch.allclose(tr.pf.p, r0["pf"], atol=1e-7)
