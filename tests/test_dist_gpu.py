@@ -92,3 +92,47 @@ def test_sharded_step_on_hip_kernels(tmp_path, batch_groups, B, Fr, cond_frame):
     assert torch.equal(r["rep1"], r["eager"]) and torch.equal(r["rep2"], r["eager"])      # replay == eager, bit for bit
     if batch_groups == 1:
         assert r["nseg"] > 10        # one segment per stretch between two exchanges
+
+
+# ---- data-parallel training step on the HIP kernels: two processes on cuda:0, gloo all-reduce of the flat device gradients ----
+def _train_worker(rank, world, port, out_path):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from seervideoldm_amd import FSTextTransformer, SeerUNet, synth
+        from seervideoldm_amd.trainer import SeerTrainer
+        dev = torch.device("cuda:0")
+        cfg = dict(block_out_channels=(320, 320, 320, 320), layers_per_block=1, cross_attention_dim=192, attention_head_dim=8)
+        fs = dict(num_frames=16, num_layers=1, channels=192, n_heads=2, cross_attention_dim=192)
+        unet = SeerUNet(**cfg)
+        unet.load_state_dict(synth.synth_state_dict(synth.unet_param_shapes(cfg)), strict=True)
+        fst = FSTextTransformer(num_frames=16, in_channels=192, out_channels=192, n_heads=2, num_layers=1, cross_attention_dim=192)
+        fst.load_state_dict(synth.synth_state_dict(synth.fstext_param_shapes(**fs)), strict=True)
+        fst.set_numframe(3)
+        tr = SeerTrainer(unet.to(dev), fst.to(dev), lr=2e-5, max_grad_norm=1.0, process_group=dist.group.WORLD)
+        g = torch.Generator().manual_seed(100 + rank)                    # every rank its own micro-batch
+        x, noise = torch.randn((1, 4, 3, 16, 16), generator=g).to(dev), torch.randn((1, 4, 2, 16, 16), generator=g).to(dev)
+        text, t = torch.randn((1, 77, 192), generator=g).to(dev), torch.tensor([400 + rank], device=dev)
+        res = []
+        for step in range(4):
+            loss = tr.forward_backward(x, noise, t, text, 1, use_graph=True)
+            local = (tr.pu.g.clone().cpu(), tr.pf.g.clone().cpu())
+            tr.optimizer_step()
+            res.append(dict(loss=float(loss), gu=local[0], gf=local[1], pu=tr.pu.p.clone().cpu(), pf=tr.pf.p.clone().cpu()))
+        torch.save(dict(res=res, broken=bool(getattr(tr, "_graph_broken", False))), f"{out_path}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_train_step_on_hip_kernels(tmp_path):
+    out = tmp_path / "tr"
+    mp.spawn(_train_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
+    r0, r1 = torch.load(f"{out}.0"), torch.load(f"{out}.1")
+    assert not r0["broken"] and not r1["broken"]
+    for a, b in zip(r0["res"], r1["res"]):
+        assert torch.equal(a["pu"], b["pu"]) and torch.equal(a["pf"], b["pf"])      # replicas stay identical
+        assert not torch.equal(a["gu"], b["gu"])                                     # ... on different micro-batches
+    losses = [(a["loss"], b["loss"]) for a, b in zip(r0["res"], r1["res"])]
+    print("[ddp] losses per step (rank0, rank1):", losses)
+    assert sum(losses[-1]) < sum(losses[0]), losses
