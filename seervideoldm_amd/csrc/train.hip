@@ -634,6 +634,19 @@ __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const
 }
 
 
+// y = beta * y + alpha * x (gradient accumulation over micro-batches, train.py:321 `accelerator.accumulate`)
+__global__ void __launch_bounds__(256) axpby_kernel(float* __restrict__ y, const float* __restrict__ x, float alpha, float beta,
+                                                    int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+        f32x4 yv = {0.f, 0.f, 0.f, 0.f};
+        if (beta != 0.f) yv = reinterpret_cast<const f32x4*>(y)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) yv[e] = beta * yv[e] + alpha * xv[e];
+        reinterpret_cast<f32x4*>(y)[i] = yv;
+    }
+}
+
 }  // namespace
 
 extern "C" int seer_transpose_bf16(const void* x, int64_t rows, int32_t cols, int32_t ldx, void* y, int64_t ldy,
@@ -879,6 +892,16 @@ extern "C" int seer_adamw_step(float* p, const float* g, float* m, float* v, int
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v, n,
                        lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_sumsq, max_norm,
                        reinterpret_cast<bf16*>(p_bf16));
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int seer_axpby_f32(float* y, const float* x, float alpha, float beta, int64_t n, void* stream) {
+    if (!y || !x || n <= 0 || n % 4 || (reinterpret_cast<uintptr_t>(y) & 15) || (reinterpret_cast<uintptr_t>(x) & 15)) return SEER_EINVAL;
+    int64_t blocks = (n / 4 + 256 * 4 - 1) / (256 * 4);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), y, x, alpha, beta,
+                       n / 4);
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }

@@ -187,6 +187,13 @@ def conv_out_bwd(dpred: torch.Tensor, w_ohwc: torch.Tensor) -> torch.Tensor:
     return dx
 
 
+def axpby(y: torch.Tensor, x: torch.Tensor, alpha: float, beta: float) -> None:
+    """y = beta*y + alpha*x (flat fp32 buffers)"""
+    _req(y, torch.float32, "y"); _req(x, torch.float32, "x")
+    assert y.is_contiguous() and x.is_contiguous() and y.numel() == x.numel()
+    check(_lib.load().seer_axpby_f32(_p(y), _p(x), float(alpha), float(beta), y.numel(), _stream()), "seer_axpby_f32")
+
+
 def sumsq(g: torch.Tensor) -> torch.Tensor:
     _req(g, torch.float32, "g")
     assert g.is_contiguous()

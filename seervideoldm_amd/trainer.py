@@ -34,6 +34,16 @@ bf16 = torch.bfloat16
 f32 = torch.float32
 
 
+def cosine_lr(step: int, base_lr: float, warmup_steps: int, total_steps: int) -> float:
+    """diffusers.optimization.get_cosine_schedule_with_warmup (`lr_scheduler: "cosine"`, train.py:258-263): linear warm-up to
+    base_lr over warmup_steps, then half a cosine to zero at total_steps.  `step` = optimizer steps taken so far."""
+    import math
+    if step < warmup_steps:
+        return base_lr * step / max(1, warmup_steps)
+    progress = (step - warmup_steps) / max(1, total_steps - warmup_steps)
+    return base_lr * max(0.0, 0.5 * (1.0 + math.cos(math.pi * 2.0 * 0.5 * progress)))
+
+
 class _Params:
     """flat fp32 master / gradient / Adam buffers with named views (packed layouts)."""
 
@@ -111,9 +121,11 @@ def _pack_fstext_fp32(sd: Dict[str, torch.Tensor], num_layers: int) -> "Dict[str
 
 class SeerTrainer:
     def __init__(self, unet: SeerUNet, fstext: FSTextTransformer, *, lr: float = 1e-4, betas=(0.9, 0.999),
-                 weight_decay: float = 1e-2, eps: float = 1e-8, max_grad_norm: float = 1.0, ops=hip_ops, tops=hip_train_ops,
-                 process_group=None):
+                 weight_decay: float = 1e-2, eps: float = 1e-8, max_grad_norm: float = 1.0, gradient_accumulation_steps: int = 1,
+                 ops=hip_ops, tops=hip_train_ops, process_group=None):
         self.ops, self.tops = ops, tops
+        self.accum = int(gradient_accumulation_steps)           # configs/train.yaml:13, train.py:321 (accelerator.accumulate)
+        self._micro = 0
         self.lr, self.betas, self.weight_decay, self.eps, self.max_grad_norm = lr, betas, weight_decay, eps, max_grad_norm
         self.pg = process_group
         self.unet, self.fstext = unet, fstext
@@ -124,6 +136,8 @@ class SeerTrainer:
         sd_f = {k: v for k, v in fstext.state_dict().items()}
         self.pu = _Params(_pack_temporal_fp32(sd_u), self.device)
         self.pf = _Params(_pack_fstext_fp32(sd_f, fstext.num_layers), self.device)
+        for P in (self.pu, self.pf):                            # mean of the micro-batch gradients when accumulating
+            P.acc = torch.zeros_like(P.g) if self.accum > 1 else None
         # working weights: bf16 views for matrices, fp32 master views for biases / norm affine; the frozen rest comes from
         # the engine's packed dict
         self.w: Dict[str, torch.Tensor] = dict(self.eng.w)
@@ -670,30 +684,46 @@ class SeerTrainer:
         self.last_pred = pred
         return loss
 
+    def accumulate(self) -> bool:
+        """fold the gradients of the micro-batch just back-propagated into the running mean (accelerate divides the loss by
+        gradient_accumulation_steps, so the accumulated gradient is the MEAN over the micro-batches).  Returns True when the
+        optimizer should step (`accelerator.sync_gradients`, train.py:383,392)."""
+        self._micro += 1
+        if self.accum > 1:
+            first = (self._micro - 1) % self.accum == 0
+            for P in (self.pu, self.pf):
+                self.tops.axpby(P.acc, P.g, 1.0 / self.accum, 0.0 if first else 1.0)
+        return self._micro % self.accum == 0
+
     def optimizer_step(self, lr: Optional[float] = None) -> None:
         lr = self.lr if lr is None else lr
+        gu = self.pu.acc if self.accum > 1 else self.pu.g
+        gf = self.pf.acc if self.accum > 1 else self.pf.g
         if self.pg is not None:                                            # DDP: average the flat gradient buffers
             import torch.distributed as dist
             ws = dist.get_world_size(self.pg)
-            for P in (self.pu, self.pf):
-                dist.all_reduce(P.g, group=self.pg)
-                P.g.mul_(1.0 / ws)
+            for g in (gu, gf):
+                dist.all_reduce(g, group=self.pg)
+                self.tops.axpby(g, g, 1.0 / ws, 0.0)
         self.step_count += 1
-        ss = self.tops.sumsq(self.pu.g)                                    # clip_grad_norm_(sunet.parameters()) only
+        ss = self.tops.sumsq(gu)                                           # clip_grad_norm_(sunet.parameters()) only
         kw = dict(lr=lr, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay, step=self.step_count)
-        self.tops.adamw_step(self.pu.p, self.pu.g, self.pu.m, self.pu.v, grad_sumsq=ss, max_norm=self.max_grad_norm,
+        self.tops.adamw_step(self.pu.p, gu, self.pu.m, self.pu.v, grad_sumsq=ss, max_norm=self.max_grad_norm,
                              p_bf16=self.pu.pb, **kw)
-        self.tops.adamw_step(self.pf.p, self.pf.g, self.pf.m, self.pf.v, p_bf16=self.pf.pb, **kw)
+        self.tops.adamw_step(self.pf.p, gf, self.pf.m, self.pf.v, p_bf16=self.pf.pb, **kw)
         self.grad_norm_sq = ss
 
-    def train_step(self, latents_x0, latents, noise, timesteps, text_cond_emb, alphas_cumprod, lr: Optional[float] = None):
+    def train_step(self, latents_x0, latents, noise, timesteps, text_cond_emb, alphas_cumprod, lr: Optional[float] = None,
+                   use_graph: bool = False):
         """train.py:355-387 after the VAE encode: DDPM add_noise, concat the conditioning latents, forward, loss, backward,
-        clip, AdamW.  alphas_cumprod: the scheduler's table (fp32 [T])."""
+        clip, AdamW (the optimizer runs every `gradient_accumulation_steps` calls).  alphas_cumprod: the scheduler's table
+        (fp32 [T])."""
         a = alphas_cumprod.to(latents.device, f32)[timesteps].reshape(-1, 1, 1, 1, 1)
         noisy = a.sqrt() * latents + (1 - a).sqrt() * noise               # DDPMScheduler.add_noise (input preparation)
         x = torch.cat([latents_x0, noisy], 2)
-        loss = self.forward_backward(x, noise, timesteps, text_cond_emb, latents_x0.shape[2])
-        self.optimizer_step(lr)
+        loss = self.forward_backward(x, noise, timesteps, text_cond_emb, latents_x0.shape[2], use_graph=use_graph)
+        if self.accumulate():
+            self.optimizer_step(lr)
         return loss
 
     # ================================================================================================ checkpoints

@@ -336,3 +336,13 @@ def test_conv3x3_input_grad(device, stride, upsample):
     else:
         got = ops.conv3x3(dy, wt, n, Ho, Wo)
     _rel(got, ref, 1e-2, f"conv dX stride={stride} upsample={upsample}")
+
+
+def test_axpby(device):
+    from seervideoldm_amd import train_ops
+    y, x = _rand((100000,), device, 1), _rand((100000,), device, 2)
+    ref = 0.5 * x
+    train_ops.axpby(y, x, 0.5, 0.0)
+    assert torch.equal(y, ref)
+    train_ops.axpby(y, x, 0.25, 1.0)
+    assert torch.allclose(y, ref + 0.25 * x, atol=1e-7)

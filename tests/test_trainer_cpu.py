@@ -67,3 +67,29 @@ def test_trainer_schedule_matches_oracle_autograd(setup, B, Fr, cond, H):
     for name, ref, mine in (("unet", pu, new["unet"]), ("fstext", pf, new["fstext"])):
         for k in ref:
             assert (mine[k].reshape(ref[k].shape) - ref[k]).abs().max() < 1e-5, (name, k)
+
+
+def test_gradient_accumulation_and_lr_schedule(setup):
+    """configs/train.yaml gradient_accumulation_steps: 2 -- the optimizer sees the MEAN of the micro-batch gradients and steps
+    on every second call (accelerate's `accumulate` + loss / steps); cosine schedule with warm-up as diffusers defines it."""
+    from seervideoldm_amd.trainer import cosine_lr
+    usd, fsd, unet, fst = setup
+    tr = SeerTrainer(unet, fst, ops=tob, tops=ttob, gradient_accumulation_steps=2, **HP)
+    g1u, g2u = torch.randn_like(tr.pu.g), torch.randn_like(tr.pu.g)
+    g1f, g2f = torch.randn_like(tr.pf.g), torch.randn_like(tr.pf.g)
+    p0 = tr.pu.p.clone()
+    tr.pu.g.copy_(g1u); tr.pf.g.copy_(g1f)
+    assert tr.accumulate() is False
+    tr.pu.g.copy_(g2u); tr.pf.g.copy_(g2f)
+    assert tr.accumulate() is True
+    assert torch.allclose(tr.pu.acc, (g1u + g2u) / 2) and torch.allclose(tr.pf.acc, (g1f + g2f) / 2)
+    tr.optimizer_step()
+    ref = SeerTrainer(unet, fst, ops=tob, tops=ttob, **HP)
+    ref.pu.g.copy_((g1u + g2u) / 2); ref.pf.g.copy_((g1f + g2f) / 2)
+    ref.optimizer_step()
+    assert torch.allclose(tr.pu.p, ref.pu.p, atol=1e-7) and torch.allclose(tr.pf.p, ref.pf.p, atol=1e-7)
+    assert not torch.equal(tr.pu.p, p0)
+    tr.pu.g.copy_(g2u); tr.pf.g.copy_(g2f)
+    assert tr.accumulate() is False and torch.allclose(tr.pu.acc, g2u / 2)      # a new window starts from zero
+    lr = [cosine_lr(s, 1.0, 10, 110) for s in (0, 5, 10, 60, 110)]
+    assert lr[0] == 0.0 and abs(lr[1] - 0.5) < 1e-12 and lr[2] == 1.0 and abs(lr[3] - 0.5) < 1e-12 and abs(lr[4]) < 1e-12

@@ -173,6 +173,10 @@ def conv_out_bwd(dpred, w_ohwc):
     return x.grad.permute(0, 2, 3, 1).reshape(B * Fr * H * W, C0).to(bf16)
 
 
+def axpby(y, x, alpha, beta):
+    y.mul_(beta).add_(x, alpha=alpha)
+
+
 def sumsq(g):
     return (g.double() ** 2).sum().float().reshape(1)
 
