@@ -727,6 +727,45 @@ class SeerTrainer:
         return loss
 
     # ================================================================================================ checkpoints
+    @torch.no_grad()
+    def sync_modules(self) -> None:
+        """copy the fp32 master parameters back into the `SeerUNet` / `FSTextTransformer` modules (their `state_dict()` is what
+        `accelerator.save_state` serialises, train.py:395-399) and drop their packed inference weights, so that the same
+        objects sample with the fine-tuned weights."""
+        new = self.trainable_state_dict()
+        for mod, sd in ((self.unet, new["unet"]), (self.fstext, new["fstext"])):
+            params = dict(mod.named_parameters())
+            for k, v in sd.items():
+                params[k].copy_(v.reshape(params[k].shape))
+        for mod in (self.unet, self.fstext):          # packed bf16 copies are rebuilt on the next forward
+            if hasattr(mod, "_engine"):
+                mod._engine = None
+            if hasattr(mod, "_invalidate"):
+                mod._invalidate()
+
+    def save_state(self, save_path: str, global_step: Optional[int] = None, epoch: int = 0) -> str:
+        """the files of `accelerator.save_state(save_path)` that inference reads back (inference_img.py:98-104):
+        `pytorch_model.bin` (SeerUNet) and `pytorch_model_1.bin` (FSTextTransformer), plus the Adam state of this trainer
+        (`optimizer.bin`: flat packed buffers) and the step counters of train.py:398."""
+        import os
+        os.makedirs(save_path, exist_ok=True)
+        self.sync_modules()
+        cpu = lambda sd: {k: v.detach().cpu() for k, v in sd.items()}
+        torch.save(cpu(self.unet.state_dict()), os.path.join(save_path, "pytorch_model.bin"))
+        torch.save(cpu(self.fstext.state_dict()), os.path.join(save_path, "pytorch_model_1.bin"))
+        torch.save({"step_count": self.step_count, "micro": self._micro, "epoch": epoch, "global_step": global_step,
+                    "unet": {"m": self.pu.m.cpu(), "v": self.pu.v.cpu()}, "fstext": {"m": self.pf.m.cpu(), "v": self.pf.v.cpu()}},
+                   os.path.join(save_path, "optimizer.bin"))
+        return save_path
+
+    def load_optimizer_state(self, save_path: str) -> None:
+        import os
+        st = torch.load(os.path.join(save_path, "optimizer.bin"), map_location="cpu")
+        self.step_count, self._micro = int(st["step_count"]), int(st["micro"])
+        for P, key in ((self.pu, "unet"), (self.pf, "fstext")):
+            P.m.copy_(st[key]["m"])
+            P.v.copy_(st[key]["v"])
+
     def trainable_state_dict(self) -> "Dict[str, Dict[str, torch.Tensor]]":
         """{'unet': {...}, 'fstext': {...}} fp32 tensors under the REFERENCE's parameter names (unpacked)."""
         return self.trainable_state_dict_of(self.pu.p, self.pf.p)

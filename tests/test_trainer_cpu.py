@@ -93,3 +93,42 @@ def test_gradient_accumulation_and_lr_schedule(setup):
     assert tr.accumulate() is False and torch.allclose(tr.pu.acc, g2u / 2)      # a new window starts from zero
     lr = [cosine_lr(s, 1.0, 10, 110) for s in (0, 5, 10, 60, 110)]
     assert lr[0] == 0.0 and abs(lr[1] - 0.5) < 1e-12 and lr[2] == 1.0 and abs(lr[3] - 0.5) < 1e-12 and abs(lr[4]) < 1e-12
+
+
+def test_save_state_round_trip(setup, tmp_path):
+    """after a step, `save_state` writes the two files inference reads (inference_img.py:98-104) with the UPDATED trainable
+    tensors under the reference's names (unpacked q|k|v, de-interleaved GEGLU rows) and every frozen tensor untouched; the
+    modules themselves sample with the new weights; the Adam moments come back through load_optimizer_state."""
+    from seervideoldm_amd.io import load_seer_checkpoint
+    usd, fsd, _, _ = setup
+    unet = SeerUNet(**CFG)
+    unet.load_state_dict(usd, strict=True)
+    fst = FSTextTransformer(num_frames=16, in_channels=192, out_channels=192, n_heads=2, num_layers=1, cross_attention_dim=192)
+    fst.load_state_dict(fsd, strict=True)
+    fst.set_numframe(3)
+    tr = SeerTrainer(unet, fst, ops=tob, tops=ttob, **HP)
+    tr.pu.g.normal_(generator=torch.Generator().manual_seed(5)); tr.pf.g.normal_(generator=torch.Generator().manual_seed(6))
+    tr.optimizer_step()
+    path = tr.save_state(str(tmp_path / "learned_sdunet-steps-1"), global_step=1)
+    u2, f2 = SeerUNet(**CFG), FSTextTransformer(num_frames=16, in_channels=192, out_channels=192, n_heads=2, num_layers=1,
+                                                cross_attention_dim=192)
+    load_seer_checkpoint(path, u2, f2)                                        # strict=True on both
+    new = tr.trainable_state_dict()
+    sd_u, sd_f = u2.state_dict(), f2.state_dict()
+    changed = 0
+    for k, v in usd.items():
+        if k in new["unet"]:
+            assert torch.equal(sd_u[k], new["unet"][k].reshape(v.shape)) and not torch.equal(sd_u[k], v.float())
+            changed += 1
+        else:
+            assert torch.equal(sd_u[k], v), k                                  # frozen tensors and buffers: untouched
+    assert changed == len(new["unet"]) > 0
+    for k, v in fsd.items():
+        if k in new["fstext"]:
+            assert torch.equal(sd_f[k], new["fstext"][k].reshape(v.shape)), k
+    assert torch.equal(dict(unet.named_parameters())["mid_block.temporal_attentions.0.proj_out.bias"],
+                       new["unet"]["mid_block.temporal_attentions.0.proj_out.bias"])
+    tr2 = SeerTrainer(u2, f2, ops=tob, tops=ttob, **HP)
+    tr2.load_optimizer_state(path)
+    assert tr2.step_count == 1 and torch.equal(tr2.pu.m, tr.pu.m) and torch.equal(tr2.pf.v, tr.pf.v)
+    assert torch.equal(tr2.pu.p, tr.pu.p) and torch.equal(tr2.pf.p, tr.pf.p)   # repacking the saved files == the live masters
