@@ -155,6 +155,10 @@ class SeerTrainer:
         self._wT: Dict[str, torch.Tensor] = {}          # transposed copies of frozen matrices (dX GEMMs), built on first use
         self._rot_conj: Dict[int, torch.Tensor] = {}
         self._kv_cols = None
+        self._fs_rot: Dict[Tuple, torch.Tensor] = {}    # FSTextTransformer rotary tables, one row per (f, l) token
+        self._pos_src: Dict[int, torch.Tensor] = {}     # F -> source frame of pos_embed per output frame (device)
+        self._graphs: Dict[Tuple, Tuple] = {}           # captured forward+backward, keyed on the input shapes
+        self._graph_broken = False
 
     # ================================================================================================ helpers
     def _frozenT(self, key: str) -> torch.Tensor:
@@ -510,10 +514,8 @@ class SeerTrainer:
     # ================================================================================================ FSText
     def _fstext_rot(self, p, Fr, l):
         key = (p, Fr, l)
-        t = self._fs_rot.get(key) if hasattr(self, "_fs_rot") else None
+        t = self._fs_rot.get(key)
         if t is None:
-            if not hasattr(self, "_fs_rot"):
-                self._fs_rot = {}
             t = self.ops.rotary_table(self.wf[p + ".attn1.freqs"], Fr).repeat_interleave(l, dim=0).contiguous()
             self._fs_rot[key] = t
         return t
@@ -534,10 +536,8 @@ class SeerTrainer:
         rot_dim = min(32, d)
         ctx = context.reshape(b * l, cdim)
         ctx = ops.cast_bf16(ctx.float().contiguous()) if ctx.dtype != bf16 else ctx.contiguous()
-        src = self._pos_src.get(Fr) if hasattr(self, "_pos_src") else None
+        src = self._pos_src.get(Fr)
         if src is None:
-            if not hasattr(self, "_pos_src"):
-                self._pos_src = {}
             src = self._pos_frames(Fr).to(context.device)
             self._pos_src[Fr] = src
         pos = W["pos_embed"][0, src, :l, :]                                   # fp32 master [F, l, C]
@@ -637,7 +637,7 @@ class SeerTrainer:
         one hipGraph -- eager, the step is bound by the host's launch rate, not by the GPU."""
         if not model_input.is_cuda and self.ops is hip_ops:
             raise hip_ops._lib.SeerHipError("SeerTrainer needs ROCm tensors: the HIP kernels are the only compute path")
-        if use_graph and not getattr(self, "_graph_broken", False):
+        if use_graph and not self._graph_broken:
             return self._forward_backward_graph(model_input, target, timesteps, text_cond_emb, cond_frames)
         return self._forward_backward(model_input, target, timesteps, text_cond_emb, cond_frames)
 
@@ -646,8 +646,6 @@ class SeerTrainer:
         t = timesteps if torch.is_tensor(timesteps) else torch.tensor([timesteps] * b)
         t = t.to(model_input.device, torch.int64).expand(b).contiguous()
         key = (tuple(model_input.shape), tuple(text_cond_emb.shape), cond_frames)
-        if not hasattr(self, "_graphs"):
-            self._graphs = {}
         g = self._graphs.get(key)
         if g is None:
             bufs = [model_input.float().clone(), target.float().clone(), t.clone(), text_cond_emb.float().clone()]

@@ -25,10 +25,7 @@ def attention_bwd(q, k, v, out, lse, dout, dq, dk, dv, **kw):
     heads, d = kw["heads"], kw["head_dim"]
     C = heads * d
 
-    class _F32Out:          # tob.attention writes bf16 into `out`; here the fp32 result is needed for autograd
-        pass
-    # re-run the stand-in's math differentiably: temporarily route through a float "out" by monkey-free re-implementation
-    res = _attention_float(qf, kf, vf, **kw)
+    res = _attention_float(qf, kf, vf, **kw)          # differentiable fp32 twin of tob.attention
     res.backward(dout[:, :C].float())
     dq[:, :C].copy_(qf.grad[:, :C].to(bf16))
     dk[:, :C].copy_(kf.grad[:, :C].to(bf16))
