@@ -307,7 +307,7 @@ int seer_mse_loss_grad(const float* pred, const float* target, int32_t B, int32_
 int seer_conv_out_bwd(const float* dpred, int32_t B, int32_t C0, int32_t F, int32_t H, int32_t W, const float* Wt,
                       int32_t Cout, void* dx, void* stream);
 
-/* y = beta*y + alpha*x on fp32 buffers, n % 4 == 0 (gradient accumulation over micro-batches: train.py:321
+/* y = beta*y + alpha*x on fp32 buffers (x may alias y), n % 4 == 0 (gradient accumulation over micro-batches: train.py:321
  * `accelerator.accumulate`, configs/train.yaml gradient_accumulation_steps) */
 int seer_axpby_f32(float* y, const float* x, float alpha, float beta, int64_t n, void* stream);
 /* out[0] = sum g^2 (workspace: 1024 floats) */

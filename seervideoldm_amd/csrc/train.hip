@@ -635,7 +635,7 @@ __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const
 
 
 // y = beta * y + alpha * x (gradient accumulation over micro-batches, train.py:321 `accelerator.accumulate`)
-__global__ void __launch_bounds__(256) axpby_kernel(float* __restrict__ y, const float* __restrict__ x, float alpha, float beta,
+__global__ void __launch_bounds__(256) axpby_kernel(float* y, const float* x /* may alias y */, float alpha, float beta,
                                                     int64_t n4) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];

@@ -171,7 +171,7 @@ def conv_out_bwd(dpred, w_ohwc):
 
 
 def axpby(y, x, alpha, beta):
-    y.mul_(beta).add_(x, alpha=alpha)
+    y.copy_(alpha * x + (beta * y if beta != 0 else 0))          # x may alias y
 
 
 def sumsq(g):
