@@ -306,6 +306,12 @@ def main():
             train["ms_per_step"] = float(tms)
         train["samples_per_s"] = round(world * 1e3 / train["ms_per_step"], 3)
         train["parallelism"] = "single" if world == 1 else f"dp{world}"
+        if world == 1:
+            # the reference's micro-batch of 1 is a 24 GB-card setting (configs/train.yaml:11); with 288 GB per GPU the same
+            # step at micro-batch 8 fills the GEMMs (same kernels, same code path: train_batch_size is a config value)
+            big = time_train(device, steps=3, warmup=1, b=8, unet=model)
+            train["micro_batch_8"] = {"ms_per_step": round(big["ms_per_step"], 2), "peak_mem_gb": round(big["peak_mem_gb"], 1),
+                                      "samples_per_s": round(8e3 / big["ms_per_step"], 2)}
 
     cpu = None
     if sd_cpu is not None:

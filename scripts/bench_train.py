@@ -1,6 +1,6 @@
 """Time one fine-tuning step (BASELINE config 5: b=1, F=12, cond_frames=2, 32x32 latent, full-size SeerUNet + 8-layer
 FSTextTransformer, random-init weights, synthetic latents) on one MI355X: forward+loss+backward and the optimizer, with HIP
-events on the current stream.  Usage: python scripts/bench_train.py [steps] [frames] [latent]"""
+events on the current stream.  Usage: python scripts/bench_train.py [steps] [frames] [latent] [batch] [--eager]"""
 import json
 import sys
 import time
@@ -62,7 +62,8 @@ if __name__ == "__main__":
     steps = int(pos[0]) if len(pos) > 0 else 5
     Fr = int(pos[1]) if len(pos) > 1 else 12
     lat = int(pos[2]) if len(pos) > 2 else 32
+    b = int(pos[3]) if len(pos) > 3 else 1
     t0 = time.time()
-    r = time_train(torch.device("cuda:0"), steps=steps, Fr=Fr, lat=lat, use_graph="--eager" not in sys.argv)
+    r = time_train(torch.device("cuda:0"), steps=steps, Fr=Fr, lat=lat, b=b, use_graph="--eager" not in sys.argv)
     r["wall_s"] = time.time() - t0
     print(json.dumps(r))
