@@ -253,12 +253,20 @@ int seer_gaussian_sample(const float* moments, int32_t N, int32_t C, int32_t HW,
 /* ---- training step (train.py:319-389) --------------------------------------------------------------
  * The backward pass reuses seer_gemm_bf16 for every matrix product:
  *   dX[M,K] = dY[M,N] W[N,K]       -> A = dY, W' = W^T ([K][N], a transposed copy of the weight: seer_transpose_bf16)
- *   dW[N,K] = dY^T[N,M] X[M,K]     -> A = dY^T, W' = X^T (both through seer_transpose_bf16, contraction padded to 64), fp32 out
+ *   dW[N,K] = dY^T[N,M] X[M,K]     -> seer_gemm_tn_f32 (both operands read as they are, fragments by transposed LDS reads)
  *   conv3x3 dX                     -> the CONV3X3 mode with the weight repacked as w'[ci][2-ky][2-kx][co]; a stride-2 conv
  *                                     first spreads dY with seer_zero_insert2x_bf16, a conv behind the nearest-2x upsample
  *                                     folds its dX with seer_sumpool2x_bf16
  * and seer_attn_bwd for attention.  The entry points below are the HBM-bound remainder.  Every reduction is two-stage through
  * a caller workspace (no float atomics). */
+
+/* weight gradient without transposes: C[n*K + k] = sum_m A[m*lda + n] * B[m*ldb + k]   (dW[N,K] = dY[M,N]^T X[M,K]), bf16
+ * operands in their token-major layout, fp32 result.  N, K, lda, ldb multiples of 8.  The contraction is split across
+ * blocks; slices meet in `workspace` (seer_gemm_tn_workspace_bytes(M, N, K) bytes, 0 = not needed) and are added in slice
+ * order. */
+int64_t seer_gemm_tn_workspace_bytes(int32_t M, int32_t N, int32_t K);
+int seer_gemm_tn_f32(const void* A, int32_t lda, const void* B, int32_t ldb, int32_t M, int32_t N, int32_t K, float* C,
+                     void* workspace, int64_t workspace_bytes, void* stream);
 
 /* y[c*ldy + r] = x[r*ldx + c]; columns rows..ldy-1 of y are zero filled */
 int seer_transpose_bf16(const void* x, int64_t rows, int32_t cols, int32_t ldx, void* y, int64_t ldy, void* stream);

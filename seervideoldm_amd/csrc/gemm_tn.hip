@@ -1,0 +1,160 @@
+// Weight-gradient GEMM for gfx950 (MI355X): C[n][k] = sum_m A[m][n] * B[m][k]  (dW = dY^T X of the training step,
+// train.py:382 through every trainable nn.Linear), bf16 operands as they sit in memory -- token-major [rows, channels] -- fp32
+// result.  Both operands are "transposed" with respect to the MFMA fragment layouts (the contraction index m is the row),
+// so instead of materialising dY^T and X^T (seer_transpose_bf16 + the forward GEMM) the 64-row operand tiles go to LDS as
+// they are and BOTH fragments come out of ds_read_b64_tr_b16 -- the idiom of the attention kernels' V^T operand.
+//
+// Tile 128 (n) x 128 (k) per block, 4 waves (2 x 2) of 64 x 64 = 2 x 2 v_mfma_f32_32x32x16_bf16 accumulators; the long
+// contraction (rows of the activation: 12 288 at the 32x32 level) is split across grid.z, slices write fp32 partial tiles to a
+// workspace and a second kernel adds them in slice order (deterministic, no atomics).
+#include "seer_common.h"
+
+namespace {
+
+constexpr int TM = 64;            // contraction rows per LDS tile
+constexpr int TRS = 160;          // LDS row stride (elements): 320 B == 64 (mod 256) -> conflict-free transposed reads
+constexpr int NCH = 4;            // 16-byte chunks per thread per operand per tile (64 rows x 16 chunks / 256 threads)
+
+__global__ void __launch_bounds__(256) seer_gemm_tn_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb,
+                                                           int M, int N, int K, int m_chunk, float* __restrict__ C, int64_t slice_stride) {
+    __shared__ __attribute__((aligned(16))) bf16 imgA[TM * TRS];
+    __shared__ __attribute__((aligned(16))) bf16 imgB[TM * TRS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 1, wk = wave & 1;
+    const int lh = lane >> 5;
+    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+    const int m_begin = blockIdx.z * m_chunk;
+    const int m_end = min(M, m_begin + m_chunk);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    u32x4 ra[NCH], rb[NCH];
+    auto prefetch = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx >> 4, ch = idx & 15;
+            const int m = m0 + row;
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            ra[i] = (m < m_end && n0 + 8 * ch < N) ? *reinterpret_cast<const u32x4*>(A + (int64_t)m * lda + n0 + 8 * ch) : z;
+            rb[i] = (m < m_end && k0 + 8 * ch < K) ? *reinterpret_cast<const u32x4*>(B + (int64_t)m * ldb + k0 + 8 * ch) : z;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx >> 4, ch = idx & 15;
+            *reinterpret_cast<u32x4*>(imgA + row * TRS + 8 * ch) = ra[i];
+            *reinterpret_cast<u32x4*>(imgB + row * TRS + 8 * ch) = rb[i];
+        }
+    };
+
+    const int li = lane & 15, g16 = (lane >> 4) & 1;
+    // transposed-read base: contraction rows 4*lh + (li >> 2) (+8), columns 16*g16 + 4*(li & 3) of a 32-wide operand tile
+    const int toff = (4 * lh + (li >> 2)) * TRS + 16 * g16 + 4 * (li & 3);
+    auto frag = [&](const bf16* img, int col0, int s) -> bf16x8 {
+        const bf16* a0 = img + toff + (16 * s) * TRS + col0;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0 + 8 * TRS));
+        bf16x8 f;
+        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+        f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+        return f;
+    };
+
+    if (m_begin < m_end) prefetch(m_begin);
+    for (int m0 = m_begin; m0 < m_end; m0 += TM) {
+        __syncthreads();
+        commit();
+        __syncthreads();
+        if (m0 + TM < m_end) prefetch(m0 + TM);
+#pragma unroll
+        for (int s = 0; s < TM / 16; ++s) {
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = frag(imgA, 64 * wn + 32 * i, s);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bfr[j] = frag(imgB, 64 * wk + 32 * j, s);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    float* Cz = C + (int64_t)blockIdx.z * slice_stride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = k0 + 64 * wk + 32 * j + (lane & 31);
+            if (k < K) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + 64 * wn + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (n < N) Cz[(int64_t)n * K + k] = acc[i][j][r];
+                }
+            }
+        }
+}
+
+__global__ void __launch_bounds__(256) tn_reduce_kernel(const float* __restrict__ ws, int splits, int64_t n4, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 s = reinterpret_cast<const f32x4*>(ws)[i];
+    for (int z = 1; z < splits; ++z) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(ws + (int64_t)z * n4 * 4)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] += v[e];
+    }
+    reinterpret_cast<f32x4*>(out)[i] = s;
+}
+
+int tn_splits(int M, int N, int K) {
+    const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+    int s = (256 + tiles - 1) / tiles;
+    const int max_s = (M + 4 * TM - 1) / (4 * TM);          // at least four LDS tiles of contraction per slice
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    return s;
+}
+
+}  // namespace
+
+extern "C" int64_t seer_gemm_tn_workspace_bytes(int32_t M, int32_t N, int32_t K) {
+    if (M <= 0 || N <= 0 || K <= 0) return SEER_EINVAL;
+    const int s = tn_splits(M, N, K);
+    return s > 1 ? (int64_t)s * N * K * sizeof(float) : 0;
+}
+
+extern "C" int seer_gemm_tn_f32(const void* A, int32_t lda, const void* B, int32_t ldb, int32_t M, int32_t N, int32_t K, float* C,
+                                void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return SEER_EINVAL;
+    if (N % 8 || K % 8 || lda % 8 || ldb % 8 || lda < N || ldb < K) return SEER_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C)) & 15) return SEER_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int s = tn_splits(M, N, K);
+    if (s > 1 && (!workspace || workspace_bytes < (int64_t)s * N * K * (int64_t)sizeof(float))) return SEER_EINVAL;
+    int m_chunk = ((M + s - 1) / s + TM - 1) / TM * TM;
+    s = (M + m_chunk - 1) / m_chunk;
+    dim3 grid((N + 127) / 128, (K + 127) / 128, s);
+    float* dst = s > 1 ? reinterpret_cast<float*>(workspace) : C;
+    hipLaunchKernelGGL(seer_gemm_tn_kernel, grid, dim3(256), 0, st, reinterpret_cast<const bf16*>(A), lda,
+                       reinterpret_cast<const bf16*>(B), ldb, M, N, K, m_chunk, dst, (int64_t)N * K);
+    SEER_LAUNCH_CHECK();
+    if (s > 1) {
+        const int64_t n4 = (int64_t)N * K / 4;
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
+                           reinterpret_cast<const float*>(workspace), s, n4, C);
+        SEER_LAUNCH_CHECK();
+    }
+    return SEER_OK;
+}

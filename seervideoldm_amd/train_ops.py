@@ -44,6 +44,27 @@ def attention_bwd(q, k, v, out, lse, dout, dq, dk, dv, **kw) -> None:
     check(_lib.load().seer_attn_bwd(C.byref(d), _stream()), "seer_attn_bwd")
 
 
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[N, K] (fp32) = a[M, N]^T @ b[M, K]: the weight gradient dY^T X with both operands in their token-major layout
+    (row-strided views allowed)."""
+    _req(a, bf16, "a"); _req(b, bf16, "b")
+    assert a.dim() == 2 and b.dim() == 2 and a.shape[0] == b.shape[0] and a.stride(1) == 1 and b.stride(1) == 1
+    M, N = a.shape
+    K = b.shape[1]
+    if out is None:
+        out = torch.empty((N, K), device=a.device, dtype=torch.float32)
+    _req(out, torch.float32, "out")
+    assert out.shape == (N, K) and out.is_contiguous()
+    lib = _lib.load()
+    nbytes = lib.seer_gemm_tn_workspace_bytes(M, N, K)
+    if nbytes < 0:
+        check(int(nbytes), "seer_gemm_tn_workspace_bytes")
+    ws = torch.empty((nbytes // 4,), device=a.device, dtype=torch.float32) if nbytes else None
+    check(lib.seer_gemm_tn_f32(_p(a), a.stride(0), _p(b), b.stride(0), M, N, K, _p(out), _p(ws), nbytes, _stream()),
+          "seer_gemm_tn_f32")
+    return out
+
+
 def transpose(x: torch.Tensor, pad_to: int = 64) -> torch.Tensor:
     """x [rows, cols] (row-strided view) -> [cols, round_up(rows, pad_to)] with the pad columns zero."""
     _req(x, bf16, "x")

@@ -192,7 +192,7 @@ class SeerTrainer:
         """y = x W^T + b.  P != None: the layer trains (dW, db into P.g).  Returns dx (+ dres) or None."""
         ops, tops = self.ops, self.tops
         if P is not None:
-            ops.gemm(tops.transpose(dy), tops.transpose(x), out=P.view(P.g, wkey))
+            tops.gemm_tn(dy, x, out=P.view(P.g, wkey))
             if bkey is not None:
                 tops.colsum(dy, out=P.view(P.g, bkey))
         if not need_dx:

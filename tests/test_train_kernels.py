@@ -346,3 +346,15 @@ def test_axpby(device):
     assert torch.equal(y, ref)
     train_ops.axpby(y, x, 0.25, 1.0)
     assert torch.allclose(y, ref + 0.25 * x, atol=1e-7)
+
+
+@pytest.mark.parametrize("M,N,K", [(924, 768, 768), (12288, 960, 320), (1536, 320, 1280), (160, 1280, 1280), (100, 2560, 320),
+                                   (3072, 640, 2560), (64, 8, 8), (1000, 136, 72)])
+def test_gemm_tn(device, M, N, K):
+    """dW = dY^T X with both operands in their token-major layout (row-strided views), against fp32 matmul"""
+    from seervideoldm_amd import train_ops
+    dy = _rand((M, N + 8), device, 1).to(bf16)[:, :N]
+    x = _rand((M, K + 16), device, 2).to(bf16)[:, 8:8 + K]
+    got = train_ops.gemm_tn(dy, x)
+    _rel(got, dy.float().t() @ x.float(), 2e-3, f"gemm_tn {M}x{N}x{K}")
+    assert torch.equal(got, train_ops.gemm_tn(dy, x))

@@ -69,6 +69,14 @@ def _attention_float(q, k, v, *, batch, heads, head_dim, Sq, Sk, causal=False, s
     return res.reshape(-1, C)
 
 
+def gemm_tn(a, b, out=None):
+    r = a.float().t() @ b.float()
+    if out is None:
+        return r
+    out.copy_(r)
+    return out
+
+
 def transpose(x, pad_to=64):
     rows, cols = x.shape
     ld = (rows + pad_to - 1) // pad_to * pad_to
