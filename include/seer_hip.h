@@ -261,12 +261,12 @@ int seer_gaussian_sample(const float* moments, int32_t N, int32_t C, int32_t HW,
  * a caller workspace (no float atomics). */
 
 /* weight gradient without transposes: C[n*K + k] = sum_m A[m*lda + n] * B[m*ldb + k]   (dW[N,K] = dY[M,N]^T X[M,K]), bf16
- * operands in their token-major layout, fp32 result.  N, K, lda, ldb multiples of 8.  The contraction is split across
- * blocks; slices meet in `workspace` (seer_gemm_tn_workspace_bytes(M, N, K) bytes, 0 = not needed) and are added in slice
- * order. */
+ * operands in their token-major layout, fp32 result; colsum (optional) receives sum_m A[m][n] -- the bias gradient -- from
+ * one more MFMA against a fragment of ones.  N, K, lda, ldb multiples of 8.  The contraction is split across blocks; slices
+ * meet in `workspace` (seer_gemm_tn_workspace_bytes(M, N, K) bytes, 0 = not needed) and are added in slice order. */
 int64_t seer_gemm_tn_workspace_bytes(int32_t M, int32_t N, int32_t K);
 int seer_gemm_tn_f32(const void* A, int32_t lda, const void* B, int32_t ldb, int32_t M, int32_t N, int32_t K, float* C,
-                     void* workspace, int64_t workspace_bytes, void* stream);
+                     float* colsum, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* y[c*ldy + r] = x[r*ldx + c]; columns rows..ldy-1 of y are zero filled */
 int seer_transpose_bf16(const void* x, int64_t rows, int32_t cols, int32_t ldx, void* y, int64_t ldy, void* stream);

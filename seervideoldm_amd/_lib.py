@@ -13,7 +13,7 @@ _PKG = Path(__file__).resolve().parent
 _LIB_PATH = _PKG / "lib" / "libseer_hip.so"
 _lib = None
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 SEER_GEMM_PLAIN = 0
 SEER_GEMM_CONV3X3 = 1
@@ -102,7 +102,7 @@ SIGNATURES = {
     # training step
     "seer_attn_bwd": ([C.POINTER(AttnBwdDesc), _vp], C.c_int),
     "seer_gemm_tn_workspace_bytes": ([_i32, _i32, _i32], C.c_int64),
-    "seer_gemm_tn_f32": ([_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp], C.c_int),
+    "seer_gemm_tn_f32": ([_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp], C.c_int),
     "seer_transpose_bf16": ([_vp, _i64, _i32, _i32, _vp, _i64, _vp], C.c_int),
     "seer_colsum_workspace_floats": ([_i64, _i32], C.c_int64),
     "seer_colsum_bf16": ([_vp, _i64, _i32, _i32, _vp, _vp, _vp], C.c_int),

@@ -16,7 +16,8 @@ constexpr int TRS = 160;          // LDS row stride (elements): 320 B == 64 (mod
 constexpr int NCH = 4;            // 16-byte chunks per thread per operand per tile (64 rows x 16 chunks / 256 threads)
 
 __global__ void __launch_bounds__(256) seer_gemm_tn_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb,
-                                                           int M, int N, int K, int m_chunk, float* __restrict__ C, int64_t slice_stride) {
+                                                           int M, int N, int K, int m_chunk, float* __restrict__ C, int64_t slice_stride,
+                                                           float* __restrict__ colsum /* [N] per slice, or NULL */, int64_t colsum_stride) {
     __shared__ __attribute__((aligned(16))) bf16 imgA[TM * TRS];
     __shared__ __attribute__((aligned(16))) bf16 imgB[TM * TRS];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -34,6 +35,18 @@ __global__ void __launch_bounds__(256) seer_gemm_tn_kernel(const bf16* __restric
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // column sums of A (the bias gradient sum_m dY[m][n]) ride along as one more MFMA against a fragment of ones, in the
+    // waves that own the first 64 output columns of the first column tile
+    const bool do_colsum = colsum != nullptr && blockIdx.y == 0 && wk == 0;
+    f32x16 cacc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cacc[i][r] = 0.f;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
 
     u32x4 ra[NCH], rb[NCH];
     auto prefetch = [&](int m0) {
@@ -87,7 +100,21 @@ __global__ void __launch_bounds__(256) seer_gemm_tn_kernel(const bf16* __restric
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            if (do_colsum) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) cacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], ones, cacc[i], 0, 0, 0);
+            }
         }
+    }
+    if (do_colsum && (lane & 31) == 0) {          // every output column of cacc holds the same sums: lane column 0 writes them
+        float* cz = colsum + (int64_t)blockIdx.z * colsum_stride;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + 64 * wn + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (n < N) cz[n] = cacc[i][r];
+            }
     }
 
     float* Cz = C + (int64_t)blockIdx.z * slice_stride;
@@ -106,16 +133,19 @@ __global__ void __launch_bounds__(256) seer_gemm_tn_kernel(const bf16* __restric
         }
 }
 
-__global__ void __launch_bounds__(256) tn_reduce_kernel(const float* __restrict__ ws, int splits, int64_t n4, float* __restrict__ out) {
+// slices are [N*K (+ N column sums)] floats; float4 i of the sum goes to out (i < nk4) or to out2 (the column sums)
+__global__ void __launch_bounds__(256) tn_reduce_kernel(const float* __restrict__ ws, int splits, int64_t slice4, int64_t count4,
+                                                        int64_t nk4, float* __restrict__ out, float* __restrict__ out2) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
+    if (i >= count4) return;
     f32x4 s = reinterpret_cast<const f32x4*>(ws)[i];
     for (int z = 1; z < splits; ++z) {
-        const f32x4 v = reinterpret_cast<const f32x4*>(ws + (int64_t)z * n4 * 4)[i];
+        const f32x4 v = reinterpret_cast<const f32x4*>(ws + (int64_t)z * slice4 * 4)[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) s[e] += v[e];
     }
-    reinterpret_cast<f32x4*>(out)[i] = s;
+    if (i < nk4) reinterpret_cast<f32x4*>(out)[i] = s;
+    else reinterpret_cast<f32x4*>(out2)[i - nk4] = s;
 }
 
 int tn_splits(int M, int N, int K) {
@@ -132,28 +162,33 @@ int tn_splits(int M, int N, int K) {
 extern "C" int64_t seer_gemm_tn_workspace_bytes(int32_t M, int32_t N, int32_t K) {
     if (M <= 0 || N <= 0 || K <= 0) return SEER_EINVAL;
     const int s = tn_splits(M, N, K);
-    return s > 1 ? (int64_t)s * N * K * sizeof(float) : 0;
+    return s > 1 ? (int64_t)s * ((int64_t)N * K + N) * sizeof(float) : 0;
 }
 
 extern "C" int seer_gemm_tn_f32(const void* A, int32_t lda, const void* B, int32_t ldb, int32_t M, int32_t N, int32_t K, float* C,
-                                void* workspace, int64_t workspace_bytes, void* stream) {
+                                float* colsum, void* workspace, int64_t workspace_bytes, void* stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return SEER_EINVAL;
     if (N % 8 || K % 8 || lda % 8 || ldb % 8 || lda < N || ldb < K) return SEER_EINVAL;
-    if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C)) & 15) return SEER_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C) |
+         reinterpret_cast<uintptr_t>(colsum)) & 15) return SEER_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int s = tn_splits(M, N, K);
-    if (s > 1 && (!workspace || workspace_bytes < (int64_t)s * N * K * (int64_t)sizeof(float))) return SEER_EINVAL;
+    const int64_t slice = (int64_t)N * K + N;
+    if (s > 1 && (!workspace || workspace_bytes < s * slice * (int64_t)sizeof(float))) return SEER_EINVAL;
     int m_chunk = ((M + s - 1) / s + TM - 1) / TM * TM;
     s = (M + m_chunk - 1) / m_chunk;
     dim3 grid((N + 127) / 128, (K + 127) / 128, s);
-    float* dst = s > 1 ? reinterpret_cast<float*>(workspace) : C;
+    float* ws = reinterpret_cast<float*>(workspace);
+    float* dst = s > 1 ? ws : C;
+    float* cdst = !colsum ? nullptr : (s > 1 ? ws + (int64_t)N * K : colsum);
     hipLaunchKernelGGL(seer_gemm_tn_kernel, grid, dim3(256), 0, st, reinterpret_cast<const bf16*>(A), lda,
-                       reinterpret_cast<const bf16*>(B), ldb, M, N, K, m_chunk, dst, (int64_t)N * K);
+                       reinterpret_cast<const bf16*>(B), ldb, M, N, K, m_chunk, dst, s > 1 ? slice : 0, cdst, s > 1 ? slice : 0);
     SEER_LAUNCH_CHECK();
     if (s > 1) {
-        const int64_t n4 = (int64_t)N * K / 4;
-        hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
-                           reinterpret_cast<const float*>(workspace), s, n4, C);
+        const int64_t nk4 = (int64_t)N * K / 4;
+        const int64_t count4 = colsum ? slice / 4 : nk4;           // without column sums the tail of a slice is not read
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((count4 + 255) / 256)), dim3(256), 0, st, ws, s, slice / 4, count4,
+                           nk4, C, colsum);
         SEER_LAUNCH_CHECK();
     }
     return SEER_OK;

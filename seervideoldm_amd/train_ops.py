@@ -44,9 +44,10 @@ def attention_bwd(q, k, v, out, lse, dout, dq, dk, dv, **kw) -> None:
     check(_lib.load().seer_attn_bwd(C.byref(d), _stream()), "seer_attn_bwd")
 
 
-def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None,
+            colsum: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[N, K] (fp32) = a[M, N]^T @ b[M, K]: the weight gradient dY^T X with both operands in their token-major layout
-    (row-strided views allowed)."""
+    (row-strided views allowed); colsum[N] (optional, fp32) receives the column sums of a = the bias gradient."""
     _req(a, bf16, "a"); _req(b, bf16, "b")
     assert a.dim() == 2 and b.dim() == 2 and a.shape[0] == b.shape[0] and a.stride(1) == 1 and b.stride(1) == 1
     M, N = a.shape
@@ -60,7 +61,10 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     if nbytes < 0:
         check(int(nbytes), "seer_gemm_tn_workspace_bytes")
     ws = torch.empty((nbytes // 4,), device=a.device, dtype=torch.float32) if nbytes else None
-    check(lib.seer_gemm_tn_f32(_p(a), a.stride(0), _p(b), b.stride(0), M, N, K, _p(out), _p(ws), nbytes, _stream()),
+    if colsum is not None:
+        _req(colsum, torch.float32, "colsum")
+        assert colsum.is_contiguous() and colsum.numel() == N
+    check(lib.seer_gemm_tn_f32(_p(a), a.stride(0), _p(b), b.stride(0), M, N, K, _p(out), _p(colsum), _p(ws), nbytes, _stream()),
           "seer_gemm_tn_f32")
     return out
 

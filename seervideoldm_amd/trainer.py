@@ -192,9 +192,7 @@ class SeerTrainer:
         """y = x W^T + b.  P != None: the layer trains (dW, db into P.g).  Returns dx (+ dres) or None."""
         ops, tops = self.ops, self.tops
         if P is not None:
-            tops.gemm_tn(dy, x, out=P.view(P.g, wkey))
-            if bkey is not None:
-                tops.colsum(dy, out=P.view(P.g, bkey))
+            tops.gemm_tn(dy, x, out=P.view(P.g, wkey), colsum=P.view(P.g, bkey) if bkey is not None else None)
         if not need_dx:
             return None
         WT = tops.transpose(W[wkey]) if P is not None else self._frozenT(wkey)

@@ -358,3 +358,7 @@ def test_gemm_tn(device, M, N, K):
     got = train_ops.gemm_tn(dy, x)
     _rel(got, dy.float().t() @ x.float(), 2e-3, f"gemm_tn {M}x{N}x{K}")
     assert torch.equal(got, train_ops.gemm_tn(dy, x))
+    cs = torch.full((N,), float("nan"), device=device)
+    got2 = train_ops.gemm_tn(dy, x, colsum=cs)                       # bias gradient from the same pass
+    assert torch.equal(got2, got)
+    _rel(cs, dy.float().sum(0), 1e-5, f"gemm_tn colsum {M}x{N}")

@@ -69,8 +69,10 @@ def _attention_float(q, k, v, *, batch, heads, head_dim, Sq, Sk, causal=False, s
     return res.reshape(-1, C)
 
 
-def gemm_tn(a, b, out=None):
+def gemm_tn(a, b, out=None, colsum=None):
     r = a.float().t() @ b.float()
+    if colsum is not None:
+        colsum.copy_(a.float().sum(0))
     if out is None:
         return r
     out.copy_(r)
