@@ -245,18 +245,18 @@ class SeerTrainer:
             d1, d2 = dout, None
         return self._gn_bwd(s1, dh1, dres1=d1, dres2=d2)             # (dx, dskip)
 
-    def _ff_fwd(self, P, W, names, hf):
-        """GEGLU feed-forward on rows hf: returns (hf + FF(LN3 hf), saved)"""
+    def _ff_fwd(self, P, W, names, hf, out=None):
+        """GEGLU feed-forward on rows hf: returns (hf + FF(LN3 hf), saved); `out`: where to write the result"""
         ops, tops = self.ops, self.tops
         g3, b3, w1, b1, w2, b2 = names
         n3 = ops.layernorm(hf, W[g3], W[b3])
         pre = ops.gemm(n3, W[w1], bias=W[b1])
         g = tops.geglu_fwd(pre)
-        out = ops.gemm(g, W[w2], bias=W[b2], residual=hf)
+        out = ops.gemm(g, W[w2], bias=W[b2], residual=hf, out=out)
         return out, (hf, n3, pre)
 
-    def _ff_bwd(self, P, W, names, saved, dout):
-        """returns d hf (LayerNorm path + residual path)"""
+    def _ff_bwd(self, P, W, names, saved, dout, dx=None):
+        """returns d hf (LayerNorm path + residual path); `dx`: where to write it"""
         tops = self.tops
         g3, b3, w1, b1, w2, b2 = names
         hf, n3, pre = saved
@@ -264,7 +264,7 @@ class SeerTrainer:
         dg = self._lin_bwd(P, W, w2, b2, g, dout)
         dpre = tops.geglu_bwd(pre, dg)
         dn3 = self._lin_bwd(P, W, w1, b1, n3, dpre)
-        return tops.layernorm_bwd(hf, dn3, W[g3], dres=dout,
+        return tops.layernorm_bwd(hf, dn3, W[g3], dres=dout, dx=dx,
                                   dgamma=P.view(P.g, g3) if P is not None else None,
                                   dbeta=P.view(P.g, b3) if P is not None else None)
 
@@ -368,12 +368,17 @@ class SeerTrainer:
         ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], a1, lse=lse, **kw)
         h1 = ops.gemm(a1, w[tb + ".attn1.to_out.0.weight"], bias=w[tb + ".attn1.to_out.0.bias"], residual=h0)
         sl = self._ff_slices(B, Fr, HW, cond_frame) if cond_frame > 0 else [slice(0, B * Fr * HW)]
-        hf2, sff = self._ff_fwd(self.pu, w, self._unet_ff_names(tb), self._gather(h1, sl))
-        if cond_frame > 0:
-            h2 = h1.clone()
-            self._scatter(h2, hf2, sl)
+        if cond_frame > 0 and B == 1:        # FF rows are one contiguous slice: write them in place, copy only the cond rows
+            h2 = torch.empty_like(h1)
+            h2[:sl[0].start].copy_(h1[:sl[0].start])
+            _, sff = self._ff_fwd(self.pu, w, self._unet_ff_names(tb), h1[sl[0]], out=h2[sl[0]])
         else:
-            h2 = hf2
+            hf2, sff = self._ff_fwd(self.pu, w, self._unet_ff_names(tb), self._gather(h1, sl))
+            if cond_frame > 0:
+                h2 = h1.clone()
+                self._scatter(h2, hf2, sl)
+            else:
+                h2 = hf2
         out = ops.gemm(h2, w[p + ".proj_out.weight"], bias=w[p + ".proj_out.bias"], residual=x)
         return out, (p, C, d, rot_dim, cs, Fr * HW, sg, hn, h0, n1, qkv, a1, lse, kw, sl, cond_frame, sff, h2)
 
@@ -382,12 +387,17 @@ class SeerTrainer:
         p, C, d, rot_dim, cs, tpb, sg, hn, h0, n1, qkv, a1, lse, kw, sl, cond_frame, sff, h2 = saved
         tb = p + ".transformer_blocks.0"
         dh2 = self._lin_bwd(P, w, p + ".proj_out.weight", p + ".proj_out.bias", h2, dout)
-        d_hf = self._ff_bwd(P, w, self._unet_ff_names(tb), sff, self._gather(dh2, sl))
-        if cond_frame > 0:
-            dh1 = dh2.clone()
-            self._scatter(dh1, d_hf, sl)
+        if cond_frame > 0 and len(sl) == 1:
+            dh1 = torch.empty_like(dh2)
+            dh1[:sl[0].start].copy_(dh2[:sl[0].start])
+            self._ff_bwd(P, w, self._unet_ff_names(tb), sff, dh2[sl[0]], dx=dh1[sl[0]])
         else:
-            dh1 = d_hf
+            d_hf = self._ff_bwd(P, w, self._unet_ff_names(tb), sff, self._gather(dh2, sl))
+            if cond_frame > 0:
+                dh1 = dh2.clone()
+                self._scatter(dh1, d_hf, sl)
+            else:
+                dh1 = d_hf
         da1 = self._lin_bwd(P, w, tb + ".attn1.to_out.0.weight", tb + ".attn1.to_out.0.bias", a1, dh1)
         dqkv = torch.empty_like(qkv)
         tops.attention_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], a1, lse, da1, dqkv[:, :C], dqkv[:, C:2 * C],
