@@ -311,6 +311,11 @@ int seer_zero_insert2x_bf16(const void* d, int32_t n_img, int32_t H, int32_t W, 
  * dpred fp32 [B, C, F_total, HW] = d loss / d pred (zero on the conditioning frames).  workspace: 1024 floats. */
 int seer_mse_loss_grad(const float* pred, const float* target, int32_t B, int32_t C, int32_t F_total, int32_t cond_f,
                        int32_t HW, float* loss, float* dpred, float* workspace, void* stream);
+/* `--text_loss` of train.py:346-347 (the FSTextTransformer initialisation stage): loss = mean_{b,l,c} (mean_f y - target)^2
+ * with y bf16 [b, F, LC] (FSTextTransformer output), target fp32 [b, LC] (the CLIP sequence); its gradient is ADDED to dy
+ * (bf16 [b, F, LC], the gradient arriving from the UNet).  workspace: 1024 floats. */
+int seer_text_loss_grad(const void* y, const float* target, int32_t b, int32_t F, int64_t LC, void* dy, float* loss,
+                        float* workspace, void* stream);
 /* input gradient of conv_out (frozen): dpred fp32 [B, Cout, F, H, W] -> dx bf16 [B*F, H*W, C0]; W fp32 [Cout][3][3][C0] */
 int seer_conv_out_bwd(const float* dpred, int32_t B, int32_t C0, int32_t F, int32_t H, int32_t W, const float* Wt,
                       int32_t Cout, void* dx, void* stream);

@@ -244,6 +244,13 @@ def gen_train(ref):
     text_seq = fst(context=text)
     pred = unet(x, t, text_seq, cond)
     loss = torch.nn.functional.mse_loss(pred[:, :, cond:], noise, reduction="none").mean([1, 2, 3, 4]).mean()
+    # the same step with `text_loss: True` (train.py:346-347,377-378): only the FSTextTransformer gradients change
+    loss_text = torch.nn.functional.mse_loss(text_seq.mean(1), text.clone().detach(), reduction="none").mean([1, 2]).mean()
+    (loss + loss_text).backward(retain_graph=True)
+    tl_stats = np.asarray([[float(p.grad.norm()), float(p.grad.sum())] for p in fst.parameters()])
+    tl_q = fst.trf_blocks[0].transformer_blocks[1].attn1.to_q.weight.grad.detach().clone()
+    for p in list(unet.parameters()) + list(fst.parameters()):
+        p.grad = None
     loss.backward()
     un = {k: p for k, p in unet.named_parameters() if p.requires_grad}
     fn = dict(fst.named_parameters())
@@ -252,6 +259,8 @@ def gen_train(ref):
     out = dict(latents_x0=latents_x0, latents=latents, noise=noise, text=text, timestep=t, alphas_cumprod=acp, model_input=x,
                loss=loss.detach(), pred=pred.detach(), unet_keys=np.asarray(list(un)), fstext_keys=np.asarray(list(fn)),
                unet_grad_stats=stats(un), fstext_grad_stats=stats(fn))
+    out.update(loss_text=loss_text.detach(), fstext_grad_stats_text_loss=tl_stats,
+               **{"gft:trf_blocks.0.transformer_blocks.1.attn1.to_q.weight": tl_q})
     for k in TRAIN_FULL_KEYS_U:
         out["gu:" + k] = un[k].grad.detach().clone()
     for k in TRAIN_FULL_KEYS_F:

@@ -436,7 +436,7 @@ def trainable_keys(unet_sd: SD, fstext_sd: SD):
 
 
 def train_loss_and_grads(unet_sd: SD, cfg: dict, fstext_sd: SD, model_input, target, timesteps, text_cond_emb,
-                         cond_frames: int, fstext_heads: int = 8):
+                         cond_frames: int, fstext_heads: int = 8, text_loss: bool = False):
     """train.py:344,367-380: text_seq = fstext(text); pred = sunet(cat[x0 latents, noisy latents], t, text_seq, cond);
     loss = mse(pred[:, :, cond:], noise).mean over everything.  Returns (loss, {unet key: grad}, {fstext key: grad}, pred)."""
     uk, fk = trainable_keys(unet_sd, fstext_sd)
@@ -450,6 +450,8 @@ def train_loss_and_grads(unet_sd: SD, cfg: dict, fstext_sd: SD, model_input, tar
     text_seq = fstext_forward(fsd, text_cond_emb.float(), Fr, fstext_heads)
     pred = unet_forward(usd, cfg, model_input.float(), timesteps, text_seq, cond_frame=cond_frames)
     loss = F.mse_loss(pred[:, :, cond_frames:], target.float(), reduction="none").mean([1, 2, 3, 4]).mean()
+    if text_loss:           # train.py:346-347,377-378: the FSTextTransformer initialisation objective
+        loss = loss + F.mse_loss(text_seq.mean(1), text_cond_emb.float().clone().detach(), reduction="none").mean([1, 2]).mean()
     loss.backward()
     zero = lambda t: torch.zeros_like(t)
     gu = {k: (usd[k].grad if usd[k].grad is not None else zero(usd[k])) for k in uk}

@@ -13,7 +13,7 @@ _PKG = Path(__file__).resolve().parent
 _LIB_PATH = _PKG / "lib" / "libseer_hip.so"
 _lib = None
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 SEER_GEMM_PLAIN = 0
 SEER_GEMM_CONV3X3 = 1
@@ -116,6 +116,7 @@ SIGNATURES = {
     "seer_sumpool2x_bf16": ([_vp, _i32, _i32, _i32, _i32, _vp, _vp], C.c_int),
     "seer_zero_insert2x_bf16": ([_vp, _i32, _i32, _i32, _i32, _vp, _vp], C.c_int),
     "seer_mse_loss_grad": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp], C.c_int),
+    "seer_text_loss_grad": ([_vp, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp], C.c_int),
     "seer_conv_out_bwd": ([_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp], C.c_int),
     "seer_axpby_f32": ([_vp, _vp, _f32, _f32, _i64, _vp], C.c_int),
     "seer_sumsq_f32": ([_vp, _i64, _vp, _vp, _vp], C.c_int),

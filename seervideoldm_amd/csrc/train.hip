@@ -634,6 +634,52 @@ __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const
 }
 
 
+// text loss of the FSTextTransformer initialisation stage (train.py:346-347, `--text_loss`): loss_text = mean_{b,l,c}
+// (mean_f y[b,f,l,c] - t[b,l,c])^2; its gradient 2 (mean_f y - t) / (b l C F) is ADDED to dy for every frame.
+// y, dy: bf16 [b][F][LC]; t: fp32 [b][LC].  One thread per 8 channels.
+__global__ void __launch_bounds__(256) text_loss_kernel(const bf16* __restrict__ y, const float* __restrict__ t, int b, int F, int64_t LC8,
+                                                        float gscale, bf16* __restrict__ dy, float* __restrict__ partial) {
+    const int64_t total = (int64_t)b * LC8;
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t bi = i / LC8, c8 = i - bi * LC8;
+        const int64_t LC = LC8 * 8;
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = 0.f;
+        for (int f = 0; f < F; ++f) {
+            float v[8];
+            unpack8(*reinterpret_cast<const u32x4*>(y + ((bi * F + f) * LC) + c8 * 8), v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[e] += v[e];
+        }
+        float g[8];
+        const float invF = 1.0f / (float)F;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d = m[e] * invF - t[bi * LC + c8 * 8 + e];
+            s += d * d;
+            g[e] = d * gscale;
+        }
+        for (int f = 0; f < F; ++f) {
+            bf16* p = dy + ((bi * F + f) * LC) + c8 * 8;
+            float v[8];
+            unpack8(*reinterpret_cast<const u32x4*>(p), v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += g[e];
+            *reinterpret_cast<u32x4*>(p) = pack8(v);
+        }
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
 // y = beta * y + alpha * x (gradient accumulation over micro-batches, train.py:321 `accelerator.accumulate`)
 __global__ void __launch_bounds__(256) axpby_kernel(float* y, const float* x /* may alias y */, float alpha, float beta,
                                                     int64_t n4) {
@@ -902,6 +948,22 @@ extern "C" int seer_axpby_f32(float* y, const float* x, float alpha, float beta,
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), y, x, alpha, beta,
                        n / 4);
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int seer_text_loss_grad(const void* y, const float* target, int32_t b, int32_t F, int64_t LC, void* dy, float* loss,
+                                   float* workspace /* 1024 floats */, void* stream) {
+    if (!y || !target || !dy || !loss || !workspace || b <= 0 || F <= 0 || LC <= 0 || LC % 8) return SEER_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t total = (int64_t)b * (LC / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    const double n = (double)b * (double)LC;
+    hipLaunchKernelGGL(text_loss_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const bf16*>(y), target, b, F, LC / 8,
+                       (float)(2.0 / (n * F)), reinterpret_cast<bf16*>(dy), workspace);
+    SEER_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, st, workspace, blocks, (float)(1.0 / n), loss);
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }

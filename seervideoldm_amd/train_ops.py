@@ -201,6 +201,18 @@ def mse_loss_grad(pred: torch.Tensor, target: torch.Tensor, cond_f: int) -> Tupl
     return loss, dpred
 
 
+def text_loss_grad(y: torch.Tensor, target: torch.Tensor, b: int, Fr: int, dy: torch.Tensor) -> torch.Tensor:
+    """y, dy bf16 [b*F*l, C] (rows (b, f, l)); target fp32 [b, l, C].  Adds the text-loss gradient to dy, returns the loss [1]."""
+    _req(y, bf16, "y"); _req(dy, bf16, "dy"); _req(target, torch.float32, "target")
+    assert y.is_contiguous() and dy.is_contiguous() and target.is_contiguous() and y.shape == dy.shape
+    LC = target.numel() // b
+    assert y.numel() == b * Fr * LC
+    loss = torch.empty((1,), device=y.device, dtype=torch.float32)
+    ws = torch.empty((1024,), device=y.device, dtype=torch.float32)
+    check(_lib.load().seer_text_loss_grad(_p(y), _p(target), b, Fr, LC, _p(dy), _p(loss), _p(ws), _stream()), "seer_text_loss_grad")
+    return loss
+
+
 def conv_out_bwd(dpred: torch.Tensor, w_ohwc: torch.Tensor) -> torch.Tensor:
     """dpred [B, Cout, F, H, W] fp32, w fp32 [Cout, 3, 3, C0] -> dx bf16 [B*F*H*W, C0]"""
     _req(dpred, torch.float32, "dpred"); _req(w_ohwc, torch.float32, "w")

@@ -122,10 +122,11 @@ def _pack_fstext_fp32(sd: Dict[str, torch.Tensor], num_layers: int) -> "Dict[str
 class SeerTrainer:
     def __init__(self, unet: SeerUNet, fstext: FSTextTransformer, *, lr: float = 1e-4, betas=(0.9, 0.999),
                  weight_decay: float = 1e-2, eps: float = 1e-8, max_grad_norm: float = 1.0, gradient_accumulation_steps: int = 1,
-                 ops=hip_ops, tops=hip_train_ops, process_group=None):
+                 text_loss: bool = False, ops=hip_ops, tops=hip_train_ops, process_group=None):
         self.ops, self.tops = ops, tops
         self.accum = int(gradient_accumulation_steps)           # configs/train.yaml:13, train.py:321 (accelerator.accumulate)
         self._micro = 0
+        self.text_loss = bool(text_loss)                       # train.py:346-347,377-378 (configs/train.yaml text_loss)
         self.lr, self.betas, self.weight_decay, self.eps, self.max_grad_norm = lr, betas, weight_decay, eps, max_grad_norm
         self.pg = process_group
         self.unet, self.fstext = unet, fstext
@@ -686,6 +687,10 @@ class SeerTrainer:
         pred, tape = self._unet_fwd(model_input.float().contiguous(), t, y, text_cond_emb.shape[1], cond_frames)
         loss, dpred = self.tops.mse_loss_grad(pred, target.float().contiguous(), cond_frames)
         dctx = self._unet_bwd(tape, dpred)
+        if self.text_loss:      # loss += mse(text_seq.mean(1), text_cond_emb): its gradient joins the UNet's d context
+            lt = self.tops.text_loss_grad(y, text_cond_emb.float().contiguous(), b, Fr, dctx)
+            self.last_text_loss = lt
+            loss = loss + lt
         self._fstext_bwd(fs_saved, dctx)
         self.last_pred = pred
         return loss

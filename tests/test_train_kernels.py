@@ -362,3 +362,18 @@ def test_gemm_tn(device, M, N, K):
     got2 = train_ops.gemm_tn(dy, x, colsum=cs)                       # bias gradient from the same pass
     assert torch.equal(got2, got)
     _rel(cs, dy.float().sum(0), 1e-5, f"gemm_tn colsum {M}x{N}")
+
+
+def test_text_loss_grad(device):
+    from seervideoldm_amd import train_ops
+    b, Fr, L, C = 2, 5, 77, 192
+    y = _rand((b * Fr * L, C), device, 1).to(bf16)
+    t = _rand((b, L, C), device, 2)
+    dy0 = (_rand((b * Fr * L, C), device, 3) * 3e-5).to(bf16)      # the UNet's d context has the magnitude of this gradient
+    dy = dy0.clone()
+    loss = train_ops.text_loss_grad(y, t, b, Fr, dy)
+    yr = y.float().reshape(b, Fr, L, C).requires_grad_(True)
+    ref = Fn.mse_loss(yr.mean(1), t, reduction="none").mean([1, 2]).mean()
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-5 * ref.item()
+    _rel(dy.float() - dy0.float(), yr.grad.reshape(b * Fr * L, C), 2e-2, "text loss grad (bf16 accumulate into dy)")

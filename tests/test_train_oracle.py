@@ -72,3 +72,20 @@ def test_full_gradients_and_adamw_update(step):
             if name.startswith(pre):
                 ref = torch.from_numpy(g[name])
                 assert (params[name[3:]] - ref).abs().max() < 2e-5, name
+
+
+def test_text_loss_variant():
+    """`text_loss: True` (train.py:346-347,377-378): loss_text and the FSTextTransformer gradients of the reference's step"""
+    g = np.load(G, allow_pickle=False)
+    T = lambda k: torch.from_numpy(g[k])
+    usd = synth.synth_state_dict(synth.unet_param_shapes(UNET))
+    fsd = synth.synth_state_dict(synth.fstext_param_shapes(**FSTEXT))
+    loss, _, gf, _ = O.train_loss_and_grads(usd, {**O.DEFAULT_CFG, **UNET}, fsd, T("model_input"), T("noise"), T("timestep"),
+                                            T("text"), 2, fstext_heads=FSTEXT["n_heads"], text_loss=True)
+    ref = float(g["loss"]) + float(g["loss_text"])
+    assert abs(float(loss) - ref) < 1e-5 * max(1.0, ref)
+    for k, (norm, total) in zip(map(str, g["fstext_keys"]), g["fstext_grad_stats_text_loss"]):
+        assert abs(float(gf[k].norm()) - norm) <= 2e-4 * max(norm, 1e-3) + 1e-7, (k, float(gf[k].norm()), norm)
+    k = "trf_blocks.0.transformer_blocks.1.attn1.to_q.weight"
+    r = torch.from_numpy(g["gft:" + k])
+    assert (gf[k] - r).norm() <= 1e-3 * r.norm()

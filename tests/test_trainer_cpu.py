@@ -132,3 +132,19 @@ def test_save_state_round_trip(setup, tmp_path):
     tr2.load_optimizer_state(path)
     assert tr2.step_count == 1 and torch.equal(tr2.pu.m, tr.pu.m) and torch.equal(tr2.pf.v, tr.pf.v)
     assert torch.equal(tr2.pu.p, tr.pu.p) and torch.equal(tr2.pf.p, tr.pf.p)   # repacking the saved files == the live masters
+
+
+def test_text_loss_option(setup):
+    """train.py:346-347 `--text_loss`: the extra loss and its gradient into the FSTextTransformer"""
+    usd, fsd, unet, fst = setup
+    fst.set_numframe(3)
+    tr = SeerTrainer(unet, fst, ops=tob, tops=ttob, text_loss=True, **HP)
+    x, noise, text, t = _randn((1, 4, 3, 8, 8), 1), _randn((1, 4, 2, 8, 8), 2), _randn((1, 77, 192), 3), torch.tensor([417])
+    loss = tr.forward_backward(x, noise, t, text, 1)
+    ref_loss, gu, gf, _ = O.train_loss_and_grads(usd, {**O.DEFAULT_CFG, **CFG}, fsd, x, noise, t, text, 1, fstext_heads=2,
+                                                 text_loss=True)
+    assert abs(float(loss) - float(ref_loss)) < 2e-2 * float(ref_loss)
+    got = tr.trainable_state_dict_of(tr.pu.g, tr.pf.g)["fstext"]
+    num = sum(((got[k].reshape(gf[k].shape) - gf[k]) ** 2).sum() for k in gf) ** 0.5
+    den = sum((gf[k] ** 2).sum() for k in gf) ** 0.5
+    assert num / den < 3e-2, float(num / den)

@@ -172,6 +172,14 @@ def mse_loss_grad(pred, target, cond_f):
     return loss.detach().reshape(1), p.grad
 
 
+def text_loss_grad(y, target, b, Fr, dy):
+    yr = y.float().reshape(b, Fr, -1).requires_grad_(True)
+    loss = F.mse_loss(yr.mean(1), target.reshape(b, -1), reduction="none").mean(1).mean()
+    loss.backward()
+    dy.copy_((dy.float() + yr.grad.reshape(dy.shape)).to(bf16))
+    return loss.detach().reshape(1)
+
+
 def conv_out_bwd(dpred, w_ohwc):
     B, Cout, Fr, H, W = dpred.shape
     C0 = w_ohwc.shape[-1]
