@@ -32,7 +32,7 @@ def setup():
     return usd, fsd, unet, fst
 
 
-@pytest.mark.parametrize("B,Fr,cond,H", [(1, 3, 1, 8), (2, 3, 2, 8)])
+@pytest.mark.parametrize("B,Fr,cond,H", [(1, 3, 1, 8), (2, 3, 2, 8), (1, 2, 0, 16)])
 def test_trainer_schedule_matches_oracle_autograd(setup, B, Fr, cond, H):
     usd, fsd, unet, fst = setup
     fst.set_numframe(Fr)
