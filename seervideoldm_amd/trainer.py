@@ -710,17 +710,23 @@ class SeerTrainer:
         lr = self.lr if lr is None else lr
         gu = self.pu.acc if self.accum > 1 else self.pu.g
         gf = self.pf.acc if self.accum > 1 else self.pf.g
-        if self.pg is not None:                                            # DDP: average the flat gradient buffers
-            import torch.distributed as dist
+        ws, hu, hf = 1, None, None
+        if self.pg is not None:              # DDP: average the flat gradient buffers; both all-reduces are in flight at once and
+            import torch.distributed as dist  # the UNet segment's clip + AdamW run under the FSTextTransformer segment's
             ws = dist.get_world_size(self.pg)
-            for g in (gu, gf):
-                dist.all_reduce(g, group=self.pg)
-                self.tops.axpby(g, g, 1.0 / ws, 0.0)
+            hu = dist.all_reduce(gu, group=self.pg, async_op=True)
+            hf = dist.all_reduce(gf, group=self.pg, async_op=True)
         self.step_count += 1
-        ss = self.tops.sumsq(gu)                                           # clip_grad_norm_(sunet.parameters()) only
         kw = dict(lr=lr, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay, step=self.step_count)
+        if hu is not None:
+            hu.wait()
+            self.tops.axpby(gu, gu, 1.0 / ws, 0.0)
+        ss = self.tops.sumsq(gu)                                           # clip_grad_norm_(sunet.parameters()) only
         self.tops.adamw_step(self.pu.p, gu, self.pu.m, self.pu.v, grad_sumsq=ss, max_norm=self.max_grad_norm,
                              p_bf16=self.pu.pb, **kw)
+        if hf is not None:
+            hf.wait()
+            self.tops.axpby(gf, gf, 1.0 / ws, 0.0)
         self.tops.adamw_step(self.pf.p, gf, self.pf.m, self.pf.v, p_bf16=self.pf.pb, **kw)
         self.grad_norm_sq = ss
 
