@@ -111,3 +111,34 @@ def test_train_step_graph_replay_is_bit_identical(device):
         runs.append(out)
     for (l0, gu0, gf0), (l1, gu1, gf1) in zip(*runs):
         assert l0 == l1 and torch.equal(gu0, gu1) and torch.equal(gf0, gf1)
+
+
+def test_full_size_backward_is_the_gradient_of_the_forward(device):
+    """BASELINE config 5 at full size (1.08 G-parameter UNet + 8-layer FSTextTransformer, 12 frames, 32x32 latent), where the
+    CPU oracle is out of reach: a size-independent property instead.  Moving the 405.9 M trainable parameters a distance eps
+    along -g / |g| must lower the loss by eps * |g| (first order): the hand-written backward is the gradient of the forward
+    the same kernels compute.  Steps of 2.5e-4 .. 1e-3 keep eps*|g| at 0.5 .. 2 % of the loss (at 1e-2 the curvature already
+    halves the slope); the bf16 working copy quantises the move per element, which over 4e8 elements is a noise of |g| * 4e-5.
+    Measured on MI355X: |g| = 26.41, slopes 24.4 / 25.6 / 25.4."""
+    from scripts.bench_train import build
+    unet, fst = build(device)
+    fst.set_numframe(12)
+    tr = SeerTrainer(unet, fst, lr=1e-5)
+    g = torch.Generator().manual_seed(0)
+    x, noise = torch.randn((1, 4, 12, 32, 32), generator=g).to(device), torch.randn((1, 4, 10, 32, 32), generator=g).to(device)
+    text, t = torch.randn((1, 77, 768), generator=g).to(device), torch.tensor([500], device=device)
+    L0 = float(tr.forward_backward(x, noise, t, text, 2))
+    gu, gf = tr.pu.g.clone(), tr.pf.g.clone()
+    gnorm = float((gu.double().pow(2).sum() + gf.double().pow(2).sum()).sqrt())
+    assert gnorm > 0 and torch.isfinite(gu).all() and torch.isfinite(gf).all()
+    pu0, pf0 = tr.pu.p.clone(), tr.pf.p.clone()
+    slopes = []
+    for eps in (2.5e-4, 5e-4, 1e-3):
+        for P, p0, gg in ((tr.pu, pu0, gu), (tr.pf, pf0, gf)):
+            P.p.copy_(p0 - (eps / gnorm) * gg)
+            P.pb.copy_(P.p)                                   # the bf16 working copy the kernels read
+        L1 = float(tr.forward_backward(x, noise, t, text, 2))
+        slopes.append((L0 - L1) / eps)
+    print(f"[directional derivative] loss {L0:.5f}, |g| {gnorm:.4f}, measured slopes {slopes}")
+    for sl in slopes:
+        assert abs(sl - gnorm) < 0.2 * gnorm, (slopes, gnorm)
