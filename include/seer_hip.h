@@ -1,6 +1,7 @@
 /*
  * seer_hip.h -- C ABI of libseer_hip.so: the MI355X (gfx950) device kernels behind the
- * Seer DDIM denoising hot path (SeerUNet forward + CFG + DDIM update + VAE decode).
+ * Seer DDIM denoising hot path (SeerUNet forward + CFG + DDIM update + VAE decode), the two steps that feed it
+ * (FSTextTransformer, VAE encode) and the fine-tuning step of train.py (backward kernels, AdamW).
  *
  * Boundary rules (all entry points):
  *   - extern "C", plain pointers and sizes; every pointer is DEVICE memory unless it says "host".
@@ -251,7 +252,7 @@ int seer_gaussian_sample(const float* moments, int32_t N, int32_t C, int32_t HW,
                          void* stream);
 
 /* ---- training step (train.py:319-389) --------------------------------------------------------------
- * The backward pass reuses seer_gemm_bf16 for every matrix product:
+ * The backward pass reuses seer_gemm_bf16 for the input gradients and has one more MFMA kernel for the weight gradients:
  *   dX[M,K] = dY[M,N] W[N,K]       -> A = dY, W' = W^T ([K][N], a transposed copy of the weight: seer_transpose_bf16)
  *   dW[N,K] = dY^T[N,M] X[M,K]     -> seer_gemm_tn_f32 (both operands read as they are, fragments by transposed LDS reads)
  *   conv3x3 dX                     -> the CONV3X3 mode with the weight repacked as w'[ci][2-ky][2-kx][co]; a stride-2 conv
