@@ -110,6 +110,10 @@ typedef struct seer_gemm_desc {
 /* 8 waves (4 x 2), 256-row tiles */
 #define SEER_TILE_G256x128_2 14
 #define SEER_TILE_G256x64_3 15
+/* 96-row tiles: 24 576 rows (the 32x32 level at CFG batch 2) in 256 row tiles = a whole number of tiles per CU */
+#define SEER_TILE_G96x160_2 16
+#define SEER_TILE_G96x160_3 17
+#define SEER_TILE_G96x128_2 18
 
 int seer_gemm_bf16(const seer_gemm_desc* desc /* host */, void* stream);
 /* bytes of workspace the call would use for split-K with this descriptor (0: it will not split) */

@@ -520,13 +520,12 @@ __global__ void __launch_bounds__(128 * WM) seer_gemm_kernel(const seer_gemm_des
         constexpr int CPR = BNO / 8;                    // 16-byte chunks per staged row
         const int n0o = GEGLU ? (n0 >> 1) : n0;
         const int n_out = GEGLU ? (p.N >> 1) : p.N;
-        static_assert((BM * CPR) % NT == 0, "staged store passes must be whole");
 #pragma unroll
-        for (int it = 0; it < BM * CPR / NT; ++it) {
+        for (int it = 0; it < (BM * CPR + NT - 1) / NT; ++it) {
             const int c = tid + it * NT;
             const int row = c / CPR, ch = c - row * CPR;
             const int m = m0 + row, n = n0o + ch * 8;
-            if (m < p.M && n < n_out)
+            if (((BM * CPR) % NT == 0 || c < BM * CPR) && m < p.M && n < n_out)
                 *reinterpret_cast<u32x4*>(Cb + (int64_t)m * p.ldc + n) = *reinterpret_cast<const u32x4*>(smem + row * CPITCH + ch * 16);
         }
     }
@@ -740,8 +739,14 @@ extern "C" int seer_gemm_bf16(const seer_gemm_desc* desc, void* stream) {
         const int n128 = (d.N + 127) / 128 * 128;
         const bool n_fits_128 = (n128 - d.N) * 8 <= d.N;           // <= 12.5 % padded columns
         const long t128160 = (long)((d.M + 127) / 128) * ((d.N + 159) / 160) * d.batch;
-        if (d.N == 320 && nk >= 20 && t128160 >= 256 && !(d.epilogue & SEER_EPI_GEGLU))
-            tile = SEER_TILE_G128x160_2;   // N = 320 in two 160-wide tiles: no padded columns, 0.45x the L2->LDS traffic of 64x64
+        if (d.N == 320 && nk >= 20 && t128160 >= 256 && !(d.epilogue & SEER_EPI_GEGLU)) {
+            // N = 320 in two 160-wide tiles: no padded columns, 0.45x the L2->LDS traffic of 64x64.  Rows per tile: whichever
+            // of 128 / 96 leaves the last round of tiles fuller -- 24 576 rows (the 32x32 level at CFG batch 2) are 384 tiles
+            // of 128 rows (1.5 per CU) but 512 of 96 rows (2 per CU): +13 % on the 320->320 conv (profiles/r01_tile96.log)
+            const long t96160 = (long)((d.M + 95) / 96) * ((d.N + 159) / 160) * d.batch;
+            auto fill = [](long t) { return (double)t / (256.0 * (double)((t + 255) / 256)); };
+            tile = fill(t96160) > fill(t128160) + 0.05 ? SEER_TILE_G96x160_2 : SEER_TILE_G128x160_2;
+        }
         else if (t128 >= 256 && n_fits_128 && d.N >= 640) tile = SEER_TILE_G128x128_2;
         else if (t12864 >= 256 && nk >= 10) tile = SEER_TILE_G128x64_3;
         else if (nk >= 12) tile = SEER_TILE_G64x64_3;
@@ -762,6 +767,9 @@ extern "C" int seer_gemm_bf16(const seer_gemm_desc* desc, void* stream) {
         case SEER_TILE_G64x160_3: return launch_tile<64, 160, 3>(d, st);
         case SEER_TILE_G256x128_2: return launch_tile<256, 128, 2, 4>(d, st);
         case SEER_TILE_G256x64_3: return launch_tile<256, 64, 3, 4>(d, st);
+        case SEER_TILE_G96x160_2: return launch_tile<96, 160, 2>(d, st);
+        case SEER_TILE_G96x160_3: return launch_tile<96, 160, 3>(d, st);
+        case SEER_TILE_G96x128_2: return launch_tile<96, 128, 2>(d, st);
         default: return SEER_EINVAL;
     }
 }

@@ -47,6 +47,7 @@ def _close(got, ref, rtol=2e-2, atol=2e-2, what=""):
     (384, 320, 2560, 10), (1536, 1280, 1280, 11),      # deeper rings
     (384, 320, 320, 12), (6144, 640, 640, 12), (130, 68, 192, 12), (384, 320, 2560, 13), (1000, 640, 128, 13),   # 160-wide
     (512, 256, 1280, 14), (300, 132, 192, 14), (6144, 640, 640, 14), (1000, 64, 320, 15), (24576, 320, 320, 15),   # 8 waves
+    (24576, 320, 1280, 16), (1000, 320, 320, 16), (130, 68, 192, 17), (12288, 640, 640, 18), (100, 64, 128, 18),       # 96-row tiles
 ])
 def test_gemm_plain(device, M, N, K, tile):
     from seervideoldm_amd import ops
@@ -216,7 +217,7 @@ def test_gemm_batched_and_transposed(device):
     (2, 8, 8, 64, 64, 1, True), (24, 32, 32, 320, 320, 1, False), (4, 4, 4, 1280, 1280, 1, False),
     (2, 6, 10, 64, 68, 1, False),
 ])
-@pytest.mark.parametrize("tile", [0, 7, 9, 12, 13, 14, 15])
+@pytest.mark.parametrize("tile", [0, 7, 9, 12, 13, 14, 15, 16, 17, 18])
 def test_conv3x3(device, n_img, H, W, Ci, Co, stride, up, tile):
     from seervideoldm_amd import ops
     from seervideoldm_amd.weights import pack_conv3x3
