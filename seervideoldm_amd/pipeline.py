@@ -49,3 +49,31 @@ def generate_clips(sunet, fstext_model, vae, sampler, x0_image: torch.Tensor, te
         clips.append(ddim_sample(sampler, sunet, vae, shape=(b, c_l, f2, h_l, w_l), c=c, start_code=noise, x0_emb=x0_emb,
                                  ddim_steps=ddim_steps, scale=scale, uc=uc))
     return clips
+
+
+def concat_all_gather(t: torch.Tensor, process_group=None) -> torch.Tensor:
+    """eval.py's `concat_all_gather(accelerator, t)` (= accelerator.gather): the per-rank batches stacked in rank order"""
+    import torch.distributed as dist
+    if process_group is None or not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+        return t
+    t = t.contiguous()
+    parts = [torch.empty_like(t) for _ in range(dist.get_world_size(process_group))]
+    dist.all_gather(parts, t, group=process_group)
+    return torch.cat(parts, 0)
+
+
+@torch.no_grad()
+def evaluate_batch(sunet, fstext_model, vae, sampler, video: torch.Tensor, text_emb: torch.Tensor, empty_emb: torch.Tensor, *,
+                   cond_frames: int, ddim_steps: int = 30, scale: float = 7.5, process_group=None,
+                   noise_generator: Optional[torch.Generator] = None, latent_generator: Optional[torch.Generator] = None):
+    """The body of eval.py's validation loop (eval.py:186-231) for THIS rank's batch: the first `cond_frames` frames of
+    `video` [b, 3, F, H, W] in [-1, 1] condition the rest; returns (pred, gt) = ([conditioning frames | sampled frames],
+    ground truth), both [N*b, 3, F, H, W] in [0, 1] gathered over the ranks of `process_group` in rank order.  N GPUs evaluate
+    N batches with no communication until this final gather (the samples are the independent units of the path)."""
+    x0 = video[:, :, :cond_frames]
+    clip = generate_clips(sunet, fstext_model, vae, sampler, x0, text_emb, empty_emb, num_frames=video.shape[2],
+                          cond_frames=cond_frames, ddim_steps=ddim_steps, scale=scale, num_samples=1,
+                          noise_generator=noise_generator, latent_generator=latent_generator)[0]
+    pred = torch.cat([(x0.float() + 1.0) / 2.0, clip], dim=2)
+    gt = (video.float() + 1.0) / 2.0
+    return concat_all_gather(pred, process_group), concat_all_gather(gt, process_group)

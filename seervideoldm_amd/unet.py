@@ -174,7 +174,8 @@ class SeerUNet(nn.Module):
         (b0, b1), (f0, f1) = sh.plan(B, Fr)
         key = (context.data_ptr(), context._version, tuple(context.shape), b0, b1, f0, f1)
         if self._ctx_slice is None or self._ctx_slice[0] != key:
-            self._ctx_slice = (key, context[b0:b1, f0:f1].contiguous())
+            # the keyed tensor is kept alive with the slice: a recycled address must not look like the same context
+            self._ctx_slice = (key, context[b0:b1, f0:f1].contiguous(), context)
         local = self._engine.run(sample[b0:b1, :, f0:f1].float().contiguous(), t[b0:b1].contiguous(),
                                  self._ctx_slice[1], int(cond_frame), use_graph=self.use_graph)
         return sh.gather_output(local, B, Fr).to(sample.dtype)
@@ -433,11 +434,14 @@ class _Engine:
     # ---- entry ---------------------------------------------------------------------------------------------------------
     def _context(self, context: torch.Tensor):
         """context [B, F, L, Dc] fp32 -> bf16 [B*F*L, Dc]; the cross-attention K/V cache is keyed on the tensor's identity
-        and version, so the 16 K/V projections run once per sample instead of once per DDIM step."""
+        and version, so the 16 K/V projections run once per sample instead of once per DDIM step.  The engine keeps the keyed
+        tensor alive: a freed context's address can be handed to the next prompt's context (same shape, version 0), which
+        would otherwise look like a cache hit."""
         key = (context.data_ptr(), context._version, tuple(context.shape), context.dtype)
         if key != self._kv_key:
             self._kv_cache = {}
             self._kv_key = key
+            self._kv_ctx_ref = context
             c = context.reshape(-1, context.shape[-1])
             self._ctx_bf16 = self.ops.cast_bf16(c.float()) if c.dtype != bf16 else c.contiguous()
         return self._ctx_bf16, context.shape[-2]

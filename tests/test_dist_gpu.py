@@ -136,3 +136,54 @@ def test_data_parallel_train_step_on_hip_kernels(tmp_path):
     losses = [(a["loss"], b["loss"]) for a, b in zip(r0["res"], r1["res"])]
     print("[ddp] losses per step (rank0, rank1):", losses)
     assert sum(losses[-1]) < sum(losses[0]), losses
+
+
+# ---- sample-parallel evaluation (eval.py:186-231): every rank its own batch, one gather of the decoded clips at the end ------
+def _eval_worker(rank, world, port, out_path):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from seervideoldm_amd import AutoencoderKL, DDIMSampler, FSTextTransformer, SeerUNet, synth
+        from seervideoldm_amd.pipeline import evaluate_batch
+        from seervideoldm_amd.vae import ldm_to_diffusers_vae
+        _host_staged_gathers()
+        dev = torch.device("cuda:0")
+        ucfg = dict(block_out_channels=(320, 320, 320, 320), layers_per_block=1, cross_attention_dim=192, attention_head_dim=8)
+        vcfg = dict(ch=128, ch_mult=(1, 1, 2, 2), num_res_blocks=1)
+        unet = SeerUNet(**ucfg)
+        unet.load_state_dict(synth.synth_state_dict(synth.unet_param_shapes(ucfg)), strict=True)
+        fst = FSTextTransformer(num_frames=6, in_channels=192, out_channels=192, n_heads=2, num_layers=1, cross_attention_dim=192)
+        fst.load_state_dict(synth.synth_state_dict(synth.fstext_param_shapes(num_frames=6, num_layers=1, channels=192, n_heads=2,
+                                                                              cross_attention_dim=192)), strict=True)
+        vsd = {**synth.synth_state_dict(synth.vae_param_shapes(**vcfg)),
+               **synth.synth_state_dict(synth.vae_encoder_param_shapes(**vcfg, z_channels=4))}
+        vae = AutoencoderKL(block_out_channels=(128, 128, 256, 256), layers_per_block=1)
+        vae.load_state_dict(ldm_to_diffusers_vae(vsd, 4), strict=True)
+        unet, fst, vae = unet.to(dev).eval(), fst.to(dev).eval(), vae.to(dev)
+
+        def run(r, pg):
+            g = torch.Generator().manual_seed(50 + r)                 # rank r's batch
+            video = torch.tanh(torch.randn((1, 3, 3, 64, 64), generator=g)).to(dev)
+            text, empty = torch.randn((1, 77, 192), generator=g).to(dev), torch.randn((1, 77, 192), generator=g).to(dev)
+            return evaluate_batch(unet, fst, vae, DDIMSampler(dev), video, text, empty, cond_frames=1, ddim_steps=2, scale=7.5,
+                                  process_group=pg, noise_generator=torch.Generator().manual_seed(7 + r),
+                                  latent_generator=torch.Generator(device=dev).manual_seed(9 + r))
+        pred, gt = run(rank, dist.group.WORLD)
+        if rank == 0:
+            solo = [run(r, None) for r in range(world)]               # the same batches without a process group
+            torch.save(dict(pred=pred.cpu(), gt=gt.cpu(), solo_pred=torch.cat([s[0] for s in solo]).cpu(),
+                            solo_gt=torch.cat([s[1] for s in solo]).cpu()), out_path)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sample_parallel_evaluation_gathers_in_rank_order(tmp_path):
+    out = tmp_path / "ev.pt"
+    mp.spawn(_eval_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
+    r = torch.load(out)
+    assert r["pred"].shape == (2, 3, 3, 64, 64) and r["gt"].shape == (2, 3, 3, 64, 64)
+    assert torch.equal(r["gt"], r["solo_gt"])
+    d = (r["pred"] - r["solo_pred"]).abs().amax(dim=(1, 2, 3, 4))
+    assert torch.equal(r["pred"], r["solo_pred"]), f"per-rank max |gathered - solo| = {d.tolist()}"
+    assert float(r["pred"].min()) >= 0.0 and float(r["pred"].max()) <= 1.0

@@ -211,3 +211,26 @@ def test_full_size_step_properties(device):
     c2 = torch.cat([c1, _randn((1, 12, 77, 768), 3).to(device)])
     y2 = m(x, torch.tensor([981, 981], device=device), c2)
     assert (y2[1] - y[1]).abs().max() > 1e-3 and (y2[0] - y[0]).abs().max() <= 1e-3 * y.abs().max().item()
+
+
+def test_new_prompt_at_a_recycled_address_is_not_a_cache_hit(device):
+    """the cross-attention K/V cache is keyed on the context tensor: a freed context's address (same shape, version 0) handed to
+    the next prompt must not look like the same tensor"""
+    cfg, sd, m = _model("mini", device)
+    x, t = _randn((1, 4, 2, 8, 8), 1).to(device), torch.tensor([300], device=device)
+    vals_a, vals_b = _randn((1, 2, 77, 256), 2), _randn((1, 2, 77, 256), 3)
+    hits = 0
+    for _ in range(4):                                    # the allocator usually recycles the block at once; try a few times
+        ctx = vals_a.to(device)
+        ptr = ctx.data_ptr()
+        y_a = m(x, t, ctx, cond_frame=0).clone()
+        del ctx
+        ctx = vals_b.to(device)
+        hits += int(ctx.data_ptr() == ptr)
+        y_b = m(x, t, ctx, cond_frame=0).clone()
+        m._engine = None                                  # no cache at all: the reference for prompt b
+        y_b_ref = m(x, t, ctx, cond_frame=0)
+        assert torch.equal(y_b, y_b_ref)
+        assert not torch.equal(y_a, y_b)
+        del ctx
+    print(f"[kv cache] recycled context address in {hits}/4 rounds")
