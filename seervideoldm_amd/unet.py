@@ -442,6 +442,7 @@ class _Engine:
             self._kv_cache = {}
             self._kv_key = key
             self._kv_ctx_ref = context
+            self._graphs.clear()        # captured steps read the cached K/V tensors by address: they die with the cache
             c = context.reshape(-1, context.shape[-1])
             self._ctx_bf16 = self.ops.cast_bf16(c.float()) if c.dtype != bf16 else c.contiguous()
         return self._ctx_bf16, context.shape[-2]

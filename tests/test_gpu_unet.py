@@ -234,3 +234,23 @@ def test_new_prompt_at_a_recycled_address_is_not_a_cache_hit(device):
         assert not torch.equal(y_a, y_b)
         del ctx
     print(f"[kv cache] recycled context address in {hits}/4 rounds")
+
+
+def test_graph_replay_across_alternating_prompts(device):
+    """hipGraph replay bakes the addresses of the cached cross-attention K/V: prompts A, B, A, B (the same two tensors) must
+    each give the eager result every time"""
+    cfg, sd, m = _model("mini", device)
+    x, t = _randn((2, 4, 2, 8, 8), 1).to(device), torch.tensor([300, 300], device=device)
+    ctxs = [_randn((2, 2, 77, 256), 20 + i).to(device) for i in range(2)]
+    m.use_graph = False
+    m._engine = None
+    eager = [m(x, t, c, cond_frame=0).clone() for c in ctxs]
+    assert not torch.equal(eager[0], eager[1])
+    m.use_graph = True
+    try:
+        for rnd in range(3):
+            for i, c in enumerate(ctxs):
+                for _ in range(2):                      # capture (or recapture) + a pure replay
+                    assert torch.equal(m(x, t, c, cond_frame=0), eager[i]), (rnd, i)
+    finally:
+        m.use_graph = False
