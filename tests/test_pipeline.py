@@ -61,3 +61,39 @@ def test_generate_clips_matches_oracle_chain():
         print(f"[parity] pipeline clip: mean abs err {err.mean():.4g}, max {err.max():.4g}")
         # bf16 kernels through encode + text transformer + 4 CFG steps (scale 7.5) + decode vs fp32: stated tolerance
         assert err.mean() < 1.5e-2 and err.max() < 0.2
+
+
+@pytest.mark.gpu
+def test_prompt_after_prompt_with_graph_replay_equals_eager():
+    """an eval-style loop (eval.py:174-231): one sampler, one set of models, a NEW prompt / conditioning image every iteration,
+    old tensors dropped as the loop goes.  hipGraph replay must give the eager clips bit for bit for every prompt."""
+    dev = torch.device("cuda:0")
+    unet = SeerUNet(**UNET)
+    unet.load_state_dict(synth.synth_state_dict(synth.unet_param_shapes(UNET)), strict=True)
+    fst = FSTextTransformer(num_frames=6, in_channels=192, out_channels=192, n_heads=2, num_layers=2, cross_attention_dim=192)
+    fst.load_state_dict(synth.synth_state_dict(synth.fstext_param_shapes(**FST)), strict=True)
+    vsd = {**synth.synth_state_dict(synth.vae_param_shapes(**VAE)),
+           **synth.synth_state_dict(synth.vae_encoder_param_shapes(**VAE, z_channels=4))}
+    vae = AutoencoderKL(block_out_channels=(128, 128, 256, 256), layers_per_block=1)
+    vae.load_state_dict(ldm_to_diffusers_vae(vsd, 4), strict=True)
+    unet, fst, vae = unet.to(dev).eval(), fst.to(dev).eval(), vae.to(dev)
+
+    def loop(use_graph):
+        unet.use_graph = use_graph
+        unet._engine = None
+        smp = DDIMSampler(dev)
+        outs = []
+        for i in range(4):
+            img = torch.tanh(_randn((1, 3, 1, 64, 64), 100 + i)).to(dev)
+            text, empty = _randn((1, 77, 192), 200 + i).to(dev), _randn((1, 77, 192), 300).to(dev)
+            clip = generate_clips(unet, fst, vae, smp, img, text, empty, num_frames=3, cond_frames=1, ddim_steps=4, scale=7.5,
+                                  noise_generator=torch.Generator().manual_seed(400 + i),
+                                  latent_generator=torch.Generator(device=dev).manual_seed(500 + i))[0]
+            outs.append(clip.clone())
+            del img, text, empty, clip
+        return outs
+    eager, replay = loop(False), loop(True)
+    unet.use_graph = False
+    for i, (a, b) in enumerate(zip(eager, replay)):
+        assert torch.equal(a, b), f"prompt {i}: max diff {(a - b).abs().max().item():.4g}"
+    assert not torch.equal(eager[0], eager[1])
