@@ -254,3 +254,27 @@ def test_graph_replay_across_alternating_prompts(device):
                     assert torch.equal(m(x, t, c, cond_frame=0), eager[i]), (rnd, i)
     finally:
         m.use_graph = False
+
+
+def test_unbatched_cfg_branch(device):
+    """ddim_video.py:205-207: an unconditional embedding WITHOUT the frame axis ([b, 77, D], shape[2] != c.shape[2]) takes the
+    two-call branch; it must agree with the batched branch fed the same embedding expanded over the frames"""
+    cfg, sd, m = _model("mini", device)
+    b, f1, Fp, H = 1, 1, 2, 16
+    D = cfg["cross_attention_dim"]
+    x0_emb, x = (_randn((b, 4, f1, H, H), 1) * 0.9).to(device), _randn((b, 4, Fp, H, H), 4).to(device)
+    c = _randn((b, f1 + Fp, 77, D), 2).to(device)
+    uc3 = _randn((b, 77, D), 3).to(device)
+    uc4 = uc3.unsqueeze(1).expand(-1, f1 + Fp, -1, -1).contiguous()
+    smp = DDIMSampler(device)
+    smp.make_schedule(4, verbose=False)
+    t = torch.full((b,), 751, dtype=torch.long, device=device)
+    kw = dict(index=3, x0_emb=x0_emb, cond_frames=f1, unconditional_guidance_scale=7.5)
+    xa, pa = smp.p_sample_ddim(m, x, c, t, unconditional_conditioning=uc4, **kw)
+    xb, pb = smp.p_sample_ddim(m, x, c, t, unconditional_conditioning=uc3, **kw)
+    assert _rel(xb, xa.cpu()) < 3e-2 and _rel(pb, pa.cpu()) < 3e-2
+    # and without guidance the unconditional embedding is not used at all (ddim_video.py:192-199)
+    xc, _ = smp.p_sample_ddim(m, x, c, t, index=3, x0_emb=x0_emb, cond_frames=f1, unconditional_guidance_scale=1.0,
+                              unconditional_conditioning=uc4)
+    xd, _ = smp.p_sample_ddim(m, x, c, t, index=3, x0_emb=x0_emb, cond_frames=f1)
+    assert torch.equal(xc, xd)
