@@ -106,9 +106,9 @@ def _train_worker(rank, world, port, out_path):
         cfg = dict(block_out_channels=(320, 320, 320, 320), layers_per_block=1, cross_attention_dim=192, attention_head_dim=8)
         fs = dict(num_frames=16, num_layers=1, channels=192, n_heads=2, cross_attention_dim=192)
         unet = SeerUNet(**cfg)
-        unet.load_state_dict(synth.synth_state_dict(synth.unet_param_shapes(cfg)), strict=True)
+        unet.load_state_dict(synth.synth_state_dict(synth.unet_param_shapes(cfg), device=dev), strict=True)
         fst = FSTextTransformer(num_frames=16, in_channels=192, out_channels=192, n_heads=2, num_layers=1, cross_attention_dim=192)
-        fst.load_state_dict(synth.synth_state_dict(synth.fstext_param_shapes(**fs)), strict=True)
+        fst.load_state_dict(synth.synth_state_dict(synth.fstext_param_shapes(**fs), device=dev), strict=True)
         fst.set_numframe(3)
         tr = SeerTrainer(unet.to(dev), fst.to(dev), lr=2e-5, max_grad_norm=1.0, process_group=dist.group.WORLD)
         g = torch.Generator().manual_seed(100 + rank)                    # every rank its own micro-batch
@@ -152,12 +152,12 @@ def _eval_worker(rank, world, port, out_path):
         ucfg = dict(block_out_channels=(320, 320, 320, 320), layers_per_block=1, cross_attention_dim=192, attention_head_dim=8)
         vcfg = dict(ch=128, ch_mult=(1, 1, 2, 2), num_res_blocks=1)
         unet = SeerUNet(**ucfg)
-        unet.load_state_dict(synth.synth_state_dict(synth.unet_param_shapes(ucfg)), strict=True)
+        unet.load_state_dict(synth.synth_state_dict(synth.unet_param_shapes(ucfg), device=dev), strict=True)
         fst = FSTextTransformer(num_frames=6, in_channels=192, out_channels=192, n_heads=2, num_layers=1, cross_attention_dim=192)
         fst.load_state_dict(synth.synth_state_dict(synth.fstext_param_shapes(num_frames=6, num_layers=1, channels=192, n_heads=2,
-                                                                              cross_attention_dim=192)), strict=True)
-        vsd = {**synth.synth_state_dict(synth.vae_param_shapes(**vcfg)),
-               **synth.synth_state_dict(synth.vae_encoder_param_shapes(**vcfg, z_channels=4))}
+                                                                              cross_attention_dim=192), device=dev), strict=True)
+        vsd = {**synth.synth_state_dict(synth.vae_param_shapes(**vcfg), device=dev),
+               **synth.synth_state_dict(synth.vae_encoder_param_shapes(**vcfg, z_channels=4), device=dev)}
         vae = AutoencoderKL(block_out_channels=(128, 128, 256, 256), layers_per_block=1)
         vae.load_state_dict(ldm_to_diffusers_vae(vsd, 4), strict=True)
         unet, fst, vae = unet.to(dev).eval(), fst.to(dev).eval(), vae.to(dev)
