@@ -39,7 +39,8 @@ def time_train(device, steps=5, warmup=2, Fr=12, cond=2, lat=32, b=1, use_graph=
         torch.cuda.synchronize()
         h0 = time.perf_counter()
         ev[0].record()
-        loss = tr.forward_backward(x, noise, t, text, cond, use_graph=use_graph)
+        loss = tr.forward_backward(x, noise, t, text, cond, use_graph=use_graph,
+                                   on_unet_grads=tr.start_unet_allreduce if process_group is not None else None)
         ev[1].record()
         host.append((time.perf_counter() - h0) * 1e3)
         tr.optimizer_step()

@@ -160,6 +160,7 @@ class SeerTrainer:
         self._pos_src: Dict[int, torch.Tensor] = {}     # F -> source frame of pos_embed per output frame (device)
         self._graphs: Dict[Tuple, Tuple] = {}           # captured forward+backward, keyed on the input shapes
         self._graph_broken = False
+        self._early_hu = None                           # handle of a UNet-segment all-reduce started inside the step
 
     # ================================================================================================ helpers
     def _frozenT(self, key: str) -> torch.Tensor:
@@ -639,18 +640,25 @@ class SeerTrainer:
 
     # ================================================================================================ the step
     def forward_backward(self, model_input: torch.Tensor, target: torch.Tensor, timesteps: torch.Tensor,
-                         text_cond_emb: torch.Tensor, cond_frames: int, use_graph: bool = False) -> torch.Tensor:
+                         text_cond_emb: torch.Tensor, cond_frames: int, use_graph: bool = False,
+                         on_unet_grads=None) -> torch.Tensor:
         """model_input [b, 4, F, h, w] fp32 = cat[latents_x0, noisy_latents] (train.py:364-365); target = the noise
         [b, 4, F - cond, h, w]; text_cond_emb [b, 77, 768] (CLIP last hidden state).  Fills the gradient buffers and returns
-        the loss (1-element device tensor).  use_graph: replay the whole forward + backward (~2.5k launches, shape-static) as
-        one hipGraph -- eager, the step is bound by the host's launch rate, not by the GPU."""
+        the loss (1-element device tensor).  use_graph: replay the forward + backward (~2.5k launches, shape-static) as
+        hipGraphs -- eager, the step is bound by the host's launch rate, not by the GPU.
+        The step has two phases: (A) FSTextTransformer forward, UNet forward, loss, UNet backward -- after it the UNet's
+        gradient segment is final -- and (B) the FSTextTransformer backward.  `on_unet_grads()` is called between them: data
+        parallel training starts the all-reduce of the UNet segment there, so it travels under phase B."""
         if not model_input.is_cuda and self.ops is hip_ops:
             raise hip_ops._lib.SeerHipError("SeerTrainer needs ROCm tensors: the HIP kernels are the only compute path")
         if use_graph and not self._graph_broken:
-            return self._forward_backward_graph(model_input, target, timesteps, text_cond_emb, cond_frames)
-        return self._forward_backward(model_input, target, timesteps, text_cond_emb, cond_frames)
+            return self._forward_backward_graph(model_input, target, timesteps, text_cond_emb, cond_frames, on_unet_grads)
+        st = self._phase_a(model_input, target, timesteps, text_cond_emb, cond_frames)
+        if on_unet_grads is not None:
+            on_unet_grads()
+        return self._phase_b(st)
 
-    def _forward_backward_graph(self, model_input, target, timesteps, text_cond_emb, cond_frames):
+    def _forward_backward_graph(self, model_input, target, timesteps, text_cond_emb, cond_frames, on_unet_grads=None):
         b = model_input.shape[0]
         t = timesteps if torch.is_tensor(timesteps) else torch.tensor([timesteps] * b)
         t = t.to(model_input.device, torch.int64).expand(b).contiguous()
@@ -658,27 +666,32 @@ class SeerTrainer:
         g = self._graphs.get(key)
         if g is None:
             bufs = [model_input.float().clone(), target.float().clone(), t.clone(), text_cond_emb.float().clone()]
-            self._forward_backward(*bufs, cond_frames)            # eager warm-up: builds the transposed frozen weights, tables
+            self._phase_b(self._phase_a(*bufs, cond_frames))       # eager warm-up: builds the transposed frozen weights, tables
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
+            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             try:
-                with torch.cuda.graph(graph):
-                    loss = self._forward_backward(*bufs, cond_frames)
+                with torch.cuda.graph(ga):
+                    st = self._phase_a(*bufs, cond_frames)
+                with torch.cuda.graph(gb, pool=ga.pool()):         # phase B reads what phase A kept: one memory pool
+                    loss = self._phase_b(st)
             except Exception as e:                                 # capture refused: stay correct, run eagerly
                 self._graph_broken = True
                 import warnings
                 warnings.warn(f"hipGraph capture of the training step failed ({type(e).__name__}: {e}); running eagerly")
-                return self._forward_backward(model_input, target, timesteps, text_cond_emb, cond_frames)
-            g = (graph, bufs, loss, self.last_pred)
+                return self.forward_backward(model_input, target, timesteps, text_cond_emb, cond_frames, False, on_unet_grads)
+            g = (ga, gb, bufs, loss, self.last_pred, st)
             self._graphs = {key: g}
-        graph, bufs, loss, pred = g
+        ga, gb, bufs, loss, pred, _ = g
         for dst, src in zip(bufs, (model_input, target, t, text_cond_emb)):
             dst.copy_(src)
-        graph.replay()
+        ga.replay()
+        if on_unet_grads is not None:
+            on_unet_grads()
+        gb.replay()
         self.last_pred = pred
         return loss
 
-    def _forward_backward(self, model_input, target, timesteps, text_cond_emb, cond_frames):
+    def _phase_a(self, model_input, target, timesteps, text_cond_emb, cond_frames):
         b, _, Fr, _, _ = model_input.shape
         assert self.fstext.num_frames == Fr, "fstext.set_numframe(F) first (train.py:187)"
         y, fs_saved = self._fstext_fwd(text_cond_emb)                     # [b*F*l, Dc] bf16, rows (b, f, l)
@@ -691,8 +704,12 @@ class SeerTrainer:
             lt = self.tops.text_loss_grad(y, text_cond_emb.float().contiguous(), b, Fr, dctx)
             self.last_text_loss = lt
             loss = loss + lt
-        self._fstext_bwd(fs_saved, dctx)
         self.last_pred = pred
+        return fs_saved, dctx, loss
+
+    def _phase_b(self, st):
+        fs_saved, dctx, loss = st
+        self._fstext_bwd(fs_saved, dctx)
         return loss
 
     def accumulate(self) -> bool:
@@ -706,6 +723,13 @@ class SeerTrainer:
                 self.tops.axpby(P.acc, P.g, 1.0 / self.accum, 0.0 if first else 1.0)
         return self._micro % self.accum == 0
 
+    def start_unet_allreduce(self) -> None:
+        """the `on_unet_grads` hook of data-parallel training without gradient accumulation: the UNet segment (0.9 GB at full
+        size) starts its all-reduce as soon as the UNet backward has finished and travels under the FSTextTransformer backward"""
+        if self.pg is not None and self.accum == 1:
+            import torch.distributed as dist
+            self._early_hu = dist.all_reduce(self.pu.g, group=self.pg, async_op=True)
+
     def optimizer_step(self, lr: Optional[float] = None) -> None:
         lr = self.lr if lr is None else lr
         gu = self.pu.acc if self.accum > 1 else self.pu.g
@@ -714,7 +738,9 @@ class SeerTrainer:
         if self.pg is not None:              # DDP: average the flat gradient buffers; both all-reduces are in flight at once and
             import torch.distributed as dist  # the UNet segment's clip + AdamW run under the FSTextTransformer segment's
             ws = dist.get_world_size(self.pg)
-            hu = dist.all_reduce(gu, group=self.pg, async_op=True)
+            hu, self._early_hu = self._early_hu, None          # already travelling since the end of the UNet backward?
+            if hu is None:
+                hu = dist.all_reduce(gu, group=self.pg, async_op=True)
             hf = dist.all_reduce(gf, group=self.pg, async_op=True)
         self.step_count += 1
         kw = dict(lr=lr, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay, step=self.step_count)
@@ -738,7 +764,8 @@ class SeerTrainer:
         a = alphas_cumprod.to(latents.device, f32)[timesteps].reshape(-1, 1, 1, 1, 1)
         noisy = a.sqrt() * latents + (1 - a).sqrt() * noise               # DDPMScheduler.add_noise (input preparation)
         x = torch.cat([latents_x0, noisy], 2)
-        loss = self.forward_backward(x, noise, timesteps, text_cond_emb, latents_x0.shape[2], use_graph=use_graph)
+        loss = self.forward_backward(x, noise, timesteps, text_cond_emb, latents_x0.shape[2], use_graph=use_graph,
+                                     on_unet_grads=self.start_unet_allreduce if self.pg is not None else None)
         if self.accumulate():
             self.optimizer_step(lr)
         return loss

@@ -114,8 +114,10 @@ def _train_worker(rank, world, port, out_path):
         unet, fst = _train_models()
         tr = SeerTrainer(unet, fst, lr=1e-3, max_grad_norm=0.3, ops=tob, tops=ttob, process_group=dist.group.WORLD)
         x, noise, t, text = _train_batch(rank)                    # every rank its own micro-batch
-        loss = tr.forward_backward(x, noise, t, text, 1)
+        seen = []
+        loss = tr.forward_backward(x, noise, t, text, 1, on_unet_grads=lambda: seen.append(tr.pu.g.clone()))
         local = (tr.pu.g.clone(), tr.pf.g.clone())
+        assert len(seen) == 1 and torch.equal(seen[0], local[0])      # the UNet segment was final when the hook ran
         tr.optimizer_step()
         torch.save(dict(loss=loss, gu=local[0], gf=local[1], pu=tr.pu.p.clone(), pf=tr.pf.p.clone()), f"{out_path}.{rank}")
     finally:

@@ -116,8 +116,12 @@ def _train_worker(rank, world, port, out_path):
         text, t = torch.randn((1, 77, 192), generator=g).to(dev), torch.tensor([400 + rank], device=dev)
         res = []
         for step in range(4):
-            loss = tr.forward_backward(x, noise, t, text, 1, use_graph=True)
-            local = (tr.pu.g.clone().cpu(), tr.pf.g.clone().cpu())
+            pre = []
+            def hook():
+                pre.append(tr.pu.g.clone().cpu())                 # local UNet gradients, final at the hook ...
+                tr.start_unet_allreduce()                         # ... and on their way while the FSText backward runs
+            loss = tr.forward_backward(x, noise, t, text, 1, use_graph=True, on_unet_grads=hook)
+            local = (pre[0], tr.pf.g.clone().cpu())
             tr.optimizer_step()
             res.append(dict(loss=float(loss), gu=local[0], gf=local[1], pu=tr.pu.p.clone().cpu(), pf=tr.pf.p.clone().cpu()))
         torch.save(dict(res=res, broken=bool(getattr(tr, "_graph_broken", False))), f"{out_path}.{rank}")
