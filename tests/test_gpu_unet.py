@@ -278,3 +278,15 @@ def test_unbatched_cfg_branch(device):
                               unconditional_conditioning=uc4)
     xd, _ = smp.p_sample_ddim(m, x, c, t, index=3, x0_emb=x0_emb, cond_frames=f1)
     assert torch.equal(xc, xd)
+
+
+@pytest.mark.parametrize("H,W", [(16, 32), (32, 16), (8, 24)])
+def test_non_square_latents(device, H, W):
+    """the datasets are not all square (bridge data is 4:3): window geometry, convs and the frame-coupled GroupNorm at H != W"""
+    cfg, sd, m = _model("mini", device)
+    x = _randn((1, 4, 2, H, W), 1)
+    ctx = _randn((1, 2, 77, cfg["cross_attention_dim"]), 2)
+    t = torch.tensor([501])
+    y = m(x.to(device), t.to(device), ctx.to(device), cond_frame=1)
+    ref = O.unet_forward(sd, cfg, x, t, ctx, cond_frame=1)
+    _check(y, ref, f"non-square {H}x{W}")
