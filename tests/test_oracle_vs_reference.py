@@ -41,6 +41,20 @@ def test_unet_forward(ref, cond_frame, Fr, H):
     torch.testing.assert_close(O.unet_forward(sd, cfg, x, t, ctx, cond_frame=cond_frame), unet(x, t, ctx, cond_frame=cond_frame), **TOL)
 
 
+@pytest.mark.parametrize("H,W", [(16, 32), (32, 16), (8, 24)])
+@torch.no_grad()
+def test_unet_forward_non_square(ref, H, W):
+    """window geometry (8x8 / 4x4 windows, un-windowed levels) and frame-coupled GroupNorm at H != W"""
+    cfg = dict(sample_size=16, in_channels=4, out_channels=4, block_out_channels=(32, 64, 64, 64), cross_attention_dim=64,
+               attention_head_dim=8, layers_per_block=2)
+    unet = ref.unet.SeerUNet(**cfg).eval()
+    ref_import.enable_xformers_path(unet)
+    sd = synth.synth_state_dict(synth.unet_param_shapes(cfg))
+    unet.load_state_dict(sd, strict=True)
+    x, ctx, t = _randn((1, 4, 3, H, W), 7), _randn((1, 3, 77, 64), 8), torch.tensor([501])
+    torch.testing.assert_close(O.unet_forward(sd, cfg, x, t, ctx, cond_frame=1), unet(x, t, ctx, 1), **TOL)
+
+
 @torch.no_grad()
 def test_sampler_step_and_schedule(ref):
     smp = ref.ddim.DDIMSampler("cpu")
