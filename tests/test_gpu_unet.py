@@ -290,3 +290,13 @@ def test_non_square_latents(device, H, W):
     y = m(x.to(device), t.to(device), ctx.to(device), cond_frame=1)
     ref = O.unet_forward(sd, cfg, x, t, ctx, cond_frame=1)
     _check(y, ref, f"non-square {H}x{W}")
+
+
+@pytest.mark.parametrize("Fr,cond", [(2, 2), (1, 0), (1, 1), (5, 4)])
+def test_frame_count_edge_cases(device, Fr, cond):
+    """a single frame; every frame a conditioning frame (the temporal feed-forward then touches no row, attention.py:241-246);
+    all but one"""
+    cfg, sd, m = _model("mini", device)
+    x, ctx, t = _randn((1, 4, Fr, 8, 8), 1), _randn((1, Fr, 77, cfg["cross_attention_dim"]), 2), torch.tensor([77])
+    y = m(x.to(device), t.to(device), ctx.to(device), cond_frame=cond)
+    _check(y, O.unet_forward(sd, cfg, x, t, ctx, cond_frame=cond), f"F={Fr} cond={cond}")
