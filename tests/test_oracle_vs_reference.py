@@ -23,7 +23,7 @@ def ref():
     return ref_import.load_reference()
 
 
-@pytest.mark.parametrize("cond_frame,Fr,H", [(0, 3, 8), (1, 2, 16)])
+@pytest.mark.parametrize("cond_frame,Fr,H", [(0, 3, 8), (1, 2, 16), (2, 2, 8), (5, 3, 8), (1, 1, 8)])
 @torch.no_grad()
 def test_unet_forward(ref, cond_frame, Fr, H):
     # layers_per_block >= 2: with one layer the reference builds Downsample3D(in_channels, ...) from the block's INPUT width
