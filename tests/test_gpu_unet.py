@@ -300,3 +300,14 @@ def test_frame_count_edge_cases(device, Fr, cond):
     x, ctx, t = _randn((1, 4, Fr, 8, 8), 1), _randn((1, Fr, 77, cfg["cross_attention_dim"]), 2), torch.tensor([77])
     y = m(x.to(device), t.to(device), ctx.to(device), cond_frame=cond)
     _check(y, O.unet_forward(sd, cfg, x, t, ctx, cond_frame=cond), f"F={Fr} cond={cond}")
+
+
+@pytest.mark.parametrize("B,L", [(1, 40), (1, 128), (4, 77), (3, 8)])
+def test_context_length_and_batch(device, B, L):
+    """text sequences shorter / longer than CLIP's 77 tokens (the key tail of the cross attention is masked in-kernel) and
+    batches beyond the CFG pair, with a different timestep per batch element"""
+    cfg, sd, m = _model("mini", device)
+    x, ctx = _randn((B, 4, 2, 8, 8), 1), _randn((B, 2, L, cfg["cross_attention_dim"]), 2)
+    t = torch.tensor([3 + 331 * i for i in range(B)])
+    y = m(x.to(device), t.to(device), ctx.to(device), cond_frame=1)
+    _check(y, O.unet_forward(sd, cfg, x, t, ctx, cond_frame=1), f"B={B} L={L}")
