@@ -50,7 +50,7 @@ def test_train_step_matches_oracle(device, cfg, B, Fr, cond, H):
     fst.set_numframe(Fr)
     tr = SeerTrainer(unet, fst, **HP)
     x, noise = _randn((B, 4, Fr, H, H), 1), _randn((B, 4, Fr - cond, H, H), 2)
-    text, t = _randn((B, 77, 192), 3), torch.tensor([417] * B)
+    text, t = _randn((B, 77, 192), 3), torch.tensor([417, 93, 800, 5][:B])
     loss = tr.forward_backward(x.to(device), noise.to(device), t.to(device), text.to(device), cond)
     ref_loss, gu, gf, pred = O.train_loss_and_grads(usd, {**O.DEFAULT_CFG, **cfg}, fsd, x, noise, t, text, cond, fstext_heads=2)
     assert abs(float(loss) - float(ref_loss)) < 2e-2 * float(ref_loss), (float(loss), float(ref_loss))

@@ -40,7 +40,7 @@ def test_trainer_schedule_matches_oracle_autograd(setup, B, Fr, cond, H):
     x = _randn((B, 4, Fr, H, H), 1)
     noise = _randn((B, 4, Fr - cond, H, H), 2)
     text = _randn((B, 77, 192), 3)
-    t = torch.tensor([417] * B)
+    t = torch.tensor([417, 93, 800, 5][:B])          # a different timestep per batch element
     loss = tr.forward_backward(x, noise, t, text, cond)
     ref_loss, gu, gf, pred = O.train_loss_and_grads(usd, {**O.DEFAULT_CFG, **CFG}, fsd, x, noise, t, text, cond, fstext_heads=2)
     assert abs(float(loss) - float(ref_loss)) < 2e-2 * float(ref_loss)
