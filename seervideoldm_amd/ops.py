@@ -281,8 +281,10 @@ def softmax_rows(x: torch.Tensor, scale: float, out: Optional[torch.Tensor] = No
     assert x2.is_contiguous()
     if out is None:
         out = torch.empty(x.shape, device=x.device, dtype=bf16)
+    ldy = out.reshape(-1, out.shape[-1]).stride(0)        # `out` may be wider than x (zero-padded contraction of the next GEMM)
+    assert out.dtype == bf16 and out.shape[-1] >= x2.shape[1] and out.numel() // out.shape[-1] == x2.shape[0]
     check(_lib.load().seer_softmax_rows(_p(x2), int(x.dtype == torch.float32), x2.shape[0], x2.shape[1], x2.stride(0),
-                                        float(scale), _p(out), x2.shape[1], _stream()), "seer_softmax_rows")
+                                        float(scale), _p(out), ldy, _stream()), "seer_softmax_rows")
     return out
 
 

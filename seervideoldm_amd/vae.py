@@ -271,7 +271,15 @@ class AutoencoderKL(nn.Module):
         k = ops.gemm(h, w[p + ".key.weight"], bias=w[p + ".key.bias"]).reshape(N, HW, C)
         vt = ops.gemm_batched(h.reshape(N, HW, C), w[p + ".value.weight"], bias=w[p + ".value.bias"], trans_out=True)
         s = ops.gemm_batched(q, k, out_f32=True)                       # [N, HW, HW] fp32 scores
-        pr = ops.softmax_rows(s, float(C) ** -0.5)                     # bf16 probabilities
+        if HW % 64 == 0:
+            pr = ops.softmax_rows(s, float(C) ** -0.5)                 # bf16 probabilities
+        else:       # small / odd latents (e.g. 8x12): the p @ v contraction needs a multiple of 64 -> zero-padded keys
+            HWp = (HW + 63) // 64 * 64
+            pr = torch.zeros((N, HW, HWp), device=x.device, dtype=bf16)
+            ops.softmax_rows(s, float(C) ** -0.5, out=pr)
+            vp = torch.zeros((N, C, HWp), device=x.device, dtype=bf16)
+            vp[:, :, :HW] = vt
+            vt = vp
         o = ops.gemm_batched(pr, vt).reshape(N * HW, C)                # p @ v
         return ops.gemm(o, w[p + ".proj_attn.weight"], bias=w[p + ".proj_attn.bias"], residual=x)
 

@@ -66,7 +66,7 @@ def test_from_pretrained_layout(tmp_path):
 
 # ---------------------------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,H,W", [(2, 64, 64), (1, 64, 128)])     # (H/8)*(W/8) % 64 == 0: K of the mid attention's p @ v GEMM
+@pytest.mark.parametrize("N,H,W", [(2, 64, 64), (1, 64, 128), (1, 64, 96), (2, 32, 96)])   # the last two: 96 and 48 mid-attention tokens (zero-padded keys)
 def test_hip_encode_matches_oracle(N, H, W):
     dev = torch.device("cuda:0")
     kw = dict(ch=128, ch_mult=(1, 1, 2, 2), num_res_blocks=1, z_channels=4)       # >= 4 channels per GroupNorm group
