@@ -59,15 +59,23 @@ def _worker(rank, world, port, batch_groups, B, Fr, H, cond_frame, out_path):
         ctx = torch.randn((B, Fr, 77, 256), generator=g).to(dev)
         t = torch.tensor([501] * B, device=dev)
         ref = m(x, t, ctx, cond_frame=cond_frame).cpu()
+        ctx2 = torch.randn((B, Fr, 77, 256), generator=g).to(dev)          # a second prompt, used after the capture
+        ref2 = m(x, t, ctx2, cond_frame=cond_frame).cpu()
         shard = parallel.attach(m, world, rank, batch_groups=batch_groups)
         eager = m(x, t, ctx, cond_frame=cond_frame).cpu()
         m.use_graph = True
         rep1 = m(x, t, ctx, cond_frame=cond_frame).cpu()        # warm-up + segmented capture + first replay
         rep2 = m(x, t, ctx, cond_frame=cond_frame).cpu()        # pure replay
+        m.use_graph = False
+        eager2 = m(x, t, ctx2, cond_frame=cond_frame).cpu()
+        m.use_graph = True
+        m(x, t, ctx, cond_frame=cond_frame)
+        rep_new_prompt = m(x, t, ctx2, cond_frame=cond_frame).cpu()   # replay of the captured segments on a NEW prompt
         eng = m._engine
         nseg = max((g_[0].n_segments for g_ in eng._graphs.values()), default=0)
         if rank == 0:
-            torch.save(dict(ref=ref, eager=eager, rep1=rep1, rep2=rep2, desc=shard.describe(), nseg=nseg,
+            torch.save(dict(ref=ref, eager=eager, rep1=rep1, rep2=rep2, ref2=ref2, eager2=eager2, rep_new_prompt=rep_new_prompt,
+                            desc=shard.describe(), nseg=nseg,
                             broken=bool(getattr(eng, "_graph_broken", False))), out_path)
     finally:
         dist.destroy_process_group()
@@ -90,6 +98,8 @@ def test_sharded_step_on_hip_kernels(tmp_path, batch_groups, B, Fr, cond_frame):
     assert rel < 3e-2, rel
     assert not r["broken"], "segmented hipGraph capture fell back to eager"
     assert torch.equal(r["rep1"], r["eager"]) and torch.equal(r["rep2"], r["eager"])      # replay == eager, bit for bit
+    assert torch.equal(r["rep_new_prompt"], r["eager2"])                                   # ... also on the next prompt
+    assert ((r["eager2"] - r["ref2"]).norm() / r["ref2"].norm()).item() < 3e-2
     if batch_groups == 1:
         assert r["nseg"] > 10        # one segment per stretch between two exchanges
 
