@@ -50,10 +50,9 @@ def _worker(rank, world, port, batch_groups, B, Fr, H, cond_frame, out_path):
         from seervideoldm_amd import SeerUNet, parallel, synth
         _host_staged_gathers()
         dev = torch.device("cuda:0")
-        sd = synth.synth_state_dict(synth.unet_param_shapes(CFG_MINI))
-        m = SeerUNet(**CFG_MINI)
-        m.load_state_dict(sd, strict=True)
-        m = m.to(dev).eval()
+        m = SeerUNet(**CFG_MINI).to(dev)
+        m.load_state_dict(synth.synth_state_dict(synth.unet_param_shapes(CFG_MINI), device=dev), strict=True)
+        m.eval()
         g = torch.Generator().manual_seed(7)
         x = torch.randn((B, 4, Fr, H, H), generator=g).to(dev)
         ctx = torch.randn((B, Fr, 77, 256), generator=g).to(dev)
