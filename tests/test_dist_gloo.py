@@ -22,6 +22,20 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _spawn(worker, world, *args):
+    """mp.spawn(worker, (world, port, *args)); one retry on a rendezvous failure (the probed port can be taken in between)"""
+    for attempt in range(2):
+        try:
+            mp.spawn(worker, args=(world, _free_port(), *args), nprocs=world, join=True)
+            return
+        except Exception as e:      # noqa: BLE001
+            msg = str(e)
+            if attempt == 0 and any(k in msg for k in ("Address already in use", "Connection refused", "connect() timed out",
+                                                       "Connection reset", "Socket Timeout")):
+                continue
+            raise
+
+
 def _worker(rank, world, port, batch_groups, B, Fr, H, cond_frame, out_path):
     sys.path.insert(0, str(ROOT))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -55,8 +69,7 @@ def _worker(rank, world, port, batch_groups, B, Fr, H, cond_frame, out_path):
 ])
 def test_sharded_step_matches_unsharded(tmp_path, batch_groups, B, Fr, cond_frame):
     out = tmp_path / "res.pt"
-    port = _free_port()
-    mp.spawn(_worker, args=(2, port, batch_groups, B, Fr, 8, cond_frame, str(out)), nprocs=2, join=True)
+    _spawn(_worker, 2, batch_groups, B, Fr, 8, cond_frame, str(out))
     r = torch.load(out)
     assert r["desc"] == f"batch_groups{batch_groups}xframe_shards{2 // batch_groups}"
     rel = ((r["got"] - r["ref"]).norm() / r["ref"].norm()).item()
@@ -128,7 +141,7 @@ def test_data_parallel_train_step(tmp_path):
     """2 ranks, one micro-batch each: after the step both hold the SAME parameters, equal to a single process stepping on the
     mean of the two gradients (DDP semantics of accelerate, train.py:265-266,382)."""
     out = tmp_path / "tr"
-    mp.spawn(_train_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
+    _spawn(_train_worker, 2, str(out))
     r0, r1 = torch.load(f"{out}.0"), torch.load(f"{out}.1")
     assert torch.equal(r0["pu"], r1["pu"]) and torch.equal(r0["pf"], r1["pf"])
     assert not torch.equal(r0["gu"], r1["gu"])

@@ -25,6 +25,20 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _spawn(worker, world, *args):
+    """mp.spawn(worker, (world, port, *args)); one retry on a rendezvous failure (the probed port can be taken in between)"""
+    for attempt in range(2):
+        try:
+            mp.spawn(worker, args=(world, _free_port(), *args), nprocs=world, join=True)
+            return
+        except Exception as e:      # noqa: BLE001
+            msg = str(e)
+            if attempt == 0 and any(k in msg for k in ("Address already in use", "Connection refused", "connect() timed out",
+                                                       "Connection reset", "Socket Timeout")):
+                continue
+            raise
+
+
 def _host_staged_gathers():
     ag, agt = dist.all_gather, dist.all_gather_into_tensor
 
@@ -87,7 +101,7 @@ def _worker(rank, world, port, batch_groups, B, Fr, H, cond_frame, out_path):
 ])
 def test_sharded_step_on_hip_kernels(tmp_path, batch_groups, B, Fr, cond_frame):
     out = tmp_path / "res.pt"
-    mp.spawn(_worker, args=(2, _free_port(), batch_groups, B, Fr, 16, cond_frame, str(out)), nprocs=2, join=True)
+    _spawn(_worker, 2, batch_groups, B, Fr, 16, cond_frame, str(out))
     r = torch.load(out)
     assert r["desc"] == f"batch_groups{batch_groups}xframe_shards{2 // batch_groups}"
     rel = ((r["eager"] - r["ref"]).norm() / r["ref"].norm()).item()
@@ -140,7 +154,7 @@ def _train_worker(rank, world, port, out_path):
 
 def test_data_parallel_train_step_on_hip_kernels(tmp_path):
     out = tmp_path / "tr"
-    mp.spawn(_train_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
+    _spawn(_train_worker, 2, str(out))
     r0, r1 = torch.load(f"{out}.0"), torch.load(f"{out}.1")
     assert not r0["broken"] and not r1["broken"]
     for a, b in zip(r0["res"], r1["res"]):
@@ -193,7 +207,7 @@ def _eval_worker(rank, world, port, out_path):
 
 def test_sample_parallel_evaluation_gathers_in_rank_order(tmp_path):
     out = tmp_path / "ev.pt"
-    mp.spawn(_eval_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
+    _spawn(_eval_worker, 2, str(out))
     r = torch.load(out)
     assert r["pred"].shape == (2, 3, 3, 64, 64) and r["gt"].shape == (2, 3, 3, 64, 64)
     assert torch.equal(r["gt"], r["solo_gt"])
