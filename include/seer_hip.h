@@ -54,6 +54,9 @@ const char* seer_build_arch(void);          /* "gfx950" */
 #define SEER_EPI_SILU 4u       /* C = silu(acc + bias) (time_embedding.linear_1) */
 #define SEER_EPI_TRANS_OUT 8u  /* store C transposed: Ct[n*ldc + m] (used for V^T in the VAE attention) */
 #define SEER_EPI_ROTARY 16u    /* rotate the q|k columns (n < rot_cols) of a fused q|k|v projection (attention.py:649-651) */
+#define SEER_EPI_COLSCALE 32u  /* multiply the output columns n < col_scale_cols by col_scale (after bias / rotary): the q columns
+                                * of a projection leave the GEMM as q * scale * log2(e), rounded to bf16 ONCE, for
+                                * SEER_ATTN_Q_PRESCALED (attention.py:622-630 applies the scale inside the attention op) */
 
 typedef struct seer_gemm_desc {
     const void* A;          /* bf16 */
@@ -90,6 +93,9 @@ typedef struct seer_gemm_desc {
      * and column, X[img, oy*stride+ky, ox*stride+kx, ci] -- the VAE encoder's Downsample, F.pad(x, (0,1,0,1)) + conv(stride 2,
      * padding 0) (ldm/modules/diffusionmodules/model.py:60-78) */
     int32_t pad_after_only;
+    /* SEER_EPI_COLSCALE */
+    int32_t col_scale_cols;
+    float col_scale;
 } seer_gemm_desc;
 
 #define SEER_TILE_AUTO 0
@@ -148,7 +154,18 @@ typedef struct seer_attn_desc {
     /* optional (training): fp32 [batch' * heads][Sq] with batch' = batch (x windows); receives log2(sum_j 2^(scale*log2(e)*s_ij))
      * per query, the statistic seer_attn_bwd needs to rebuild the probabilities.  NULL at inference. */
     float* lse;
+    /* SEER_ATTN_* flags */
+    uint32_t flags;
+    /* kernel selection, a descriptor field so that A/B runs need no global state: 0 = auto; 1 = generic kernel, one K|V LDS
+     * buffer; 6 = generic kernel, ping-pong buffers; head_dim 40 only: 3 = the d = 40 kernel (fast path with the in-launch
+     * fallback), 5 = the same kernel running its tracked-reference form directly (what lse != NULL selects) */
+    int32_t variant;
 } seer_attn_desc;
+
+/* Q already holds q * scale * log2(e) (the producing GEMM's epilogue multiplied it in, SEER_EPI_COLSCALE): the kernel takes
+ * exp2 of the raw dot products and ignores `scale`.  Without the flag the d = 40 kernel multiplies Q itself (one more
+ * bf16 rounding of q) and the generic kernel scales the fp32 scores. */
+#define SEER_ATTN_Q_PRESCALED 1u
 
 int seer_attn_fwd(const seer_attn_desc* desc /* host */, void* stream);
 

@@ -13,7 +13,7 @@ _PKG = Path(__file__).resolve().parent
 _LIB_PATH = _PKG / "lib" / "libseer_hip.so"
 _lib = None
 
-ABI_VERSION = 11
+ABI_VERSION = 13
 
 SEER_GEMM_PLAIN = 0
 SEER_GEMM_CONV3X3 = 1
@@ -22,6 +22,8 @@ SEER_EPI_OUT_F32 = 2
 SEER_EPI_SILU = 4
 SEER_EPI_TRANS_OUT = 8
 SEER_EPI_ROTARY = 16
+SEER_EPI_COLSCALE = 32
+SEER_ATTN_Q_PRESCALED = 1
 SEER_TILE_AUTO, SEER_TILE_128x128, SEER_TILE_64x64, SEER_TILE_128x64 = 0, 1, 2, 3
 
 
@@ -45,6 +47,7 @@ class GemmDesc(C.Structure):
         ("rot_table", C.c_void_p), ("rot_tokens_per_batch", C.c_int32), ("rot_pos_offset", C.c_int32),
         ("rot_head_dim", C.c_int32), ("rot_dim", C.c_int32), ("rot_cols", C.c_int32),
         ("pad_after_only", C.c_int32),
+        ("col_scale_cols", C.c_int32), ("col_scale", C.c_float),
     ]
 
 
@@ -58,6 +61,7 @@ class AttnDesc(C.Structure):
         ("window_ws", C.c_int32), ("F", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
         ("Fq", C.c_int32), ("causal_offset", C.c_int32),
         ("lse", C.c_void_p),
+        ("flags", C.c_uint32), ("variant", C.c_int32),
     ]
 
 

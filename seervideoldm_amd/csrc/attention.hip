@@ -16,7 +16,8 @@
 // LDS images: K rows padded to an odd number of 16-byte chunks (conflict-free ds_read_b128 by key row);
 //             V row stride == 64 or 192 (mod 256) bytes (conflict-free transposed reads of 4 key rows).
 #include "seer_common.h"
-#include <cstdlib>
+
+int seer_attn40_launch(const seer_attn_desc& d, int ws_log2, hipStream_t st);   // attention40.hip
 
 namespace {
 
@@ -50,16 +51,21 @@ struct AttnCfg {
     static constexpr size_t LDS_BYTES = (size_t)2 * BUF * 2;
 };
 
-// v_permlane32_swap: (a, b) -> a = [a.lo | b.lo], b = [a.hi | b.hi]; with a = b = v every lane sees both halves' values
+// v_permlane32_swap a, b:  a' = [a.lo | b.lo], b' = [a.hi | b.hi]; with a = b = v every lane sees both halves' values.
+// Inline asm, not __builtin_amdgcn_permlane32_swap: hipcc (ROCm 7.2) returns the builtin's FIRST result for both elements of
+// its result pair (scripts/lab_probe3.cpp prints it), so max(r[0], r[1]) silently dropped the other half's 16 keys from the
+// running maximum.  Mild scores hide that (any reference near the maximum is fine); scores 130+ log2 units apart
+// overflowed exp2 and gave NaN rows -- found by the sharp-softmax cases of scripts/lab_attn.cpp / tests/test_gpu_kernels.py.
+// The s_nop pair covers the VALU-write -> permlane-read hazard, which nobody pads inside an asm statement.
 __device__ __forceinline__ float xhalf_max(float v) {
-    const unsigned u = __builtin_bit_cast(unsigned, v);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
 }
 __device__ __forceinline__ float lower_half_value(float v) {      // value of lane (l & 31) in every lane l
-    const unsigned u = __builtin_bit_cast(unsigned, v);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __builtin_bit_cast(float, r[0]);
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a;
 }
 
 struct TokMap {
@@ -158,7 +164,8 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
         for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
     float m_run = kNegInf;      // running max (log2 domain, already scaled)
     float l_run = 0.f;          // partial row sum over this lane-half's keys
-    const float cscale = p.scale * 1.4426950408889634f;
+    // SEER_ATTN_Q_PRESCALED: q already carries scale * log2(e)
+    const float cscale = (p.flags & SEER_ATTN_Q_PRESCALED) ? 1.0f : p.scale * 1.4426950408889634f;
 
     // keys this block needs: causal -> up to the last query of the block
     // causal: key j is visible to query i iff j <= i + q_off (q_off = sequence position of this shard's first query)
@@ -385,27 +392,21 @@ int launch_attn2(const seer_attn_desc& d, int ws_log2, float thr, hipStream_t st
     if (ws_log2 >= 0) nbatch *= (d.H >> ws_log2) * (d.W >> ws_log2);
     dim3 grid((d.Sq + 127) / 128, nbatch * d.heads, 1);
     constexpr size_t lds = AttnCfg<D>::LDS_BYTES / (DBUF ? 1 : 2);
-    if (lds > 64 * 1024) {
-        static bool done = false;      // opt in to > 64 KiB dynamic LDS once per instantiation
-        if (!done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_attn_kernel<D, DBUF>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            done = true;
-        }
-    }
+    static_assert(lds <= 64 * 1024, "above the default dynamic-LDS limit: would need a hipFuncSetAttribute opt-in");
     hipLaunchKernelGGL((seer_attn_kernel<D, DBUF>), grid, dim3(256), lds, st, d, ws_log2, thr);
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }
 
-// tuning knobs (A/B on one device): SEER_ATTN_DBUF=0|1, SEER_ATTN_DEFER=<log2 threshold>
+// measured on one MI355X (profiles/r01_attention_ab.log): deferred max +7-8 %; ping-pong LDS within noise -> the single
+// buffer (half the LDS) and a threshold of 4 are the defaults; desc.variant = 6 selects the ping-pong form for A/B runs
 template <int D>
 int launch_attn(const seer_attn_desc& d, int ws_log2, hipStream_t st) {
-    // measured on one MI355X (profiles/r01_attention_ab.log): deferred max +7-8 %; ping-pong LDS within noise (the kernel is
-    // VALU-bound at d=40, not barrier-bound) -> single buffer (half the LDS), threshold 4
-    static const int dbuf = [] { const char* e = getenv("SEER_ATTN_DBUF"); return e ? atoi(e) : 0; }();
-    static const float thr = [] { const char* e = getenv("SEER_ATTN_DEFER"); return e ? (float)atof(e) : 4.0f; }();
-    return dbuf ? launch_attn2<D, true>(d, ws_log2, thr, st) : launch_attn2<D, false>(d, ws_log2, thr, st);
+    constexpr float thr = 4.0f;
+    if constexpr (AttnCfg<D>::LDS_BYTES <= 64 * 1024) {
+        if (d.variant == 6) return launch_attn2<D, true>(d, ws_log2, thr, st);
+    }
+    return launch_attn2<D, false>(d, ws_log2, thr, st);
 }
 
 }  // namespace
@@ -425,9 +426,15 @@ extern "C" int seer_attn_fwd(const seer_attn_desc* desc, void* stream) {
         if (d.H % d.window_ws || d.W % d.window_ws) return SEER_EINVAL;
         if (d.Fq <= 0 || d.Sq != d.Fq * d.window_ws * d.window_ws || d.Sk != d.F * d.window_ws * d.window_ws) return SEER_EINVAL;
     }
+    if (d.variant < 0 || d.variant > 6 || d.variant == 2 || d.variant == 4) return SEER_EINVAL;
+    if ((d.variant == 3 || d.variant == 5) && d.head_dim != 40) return SEER_EINVAL;
     if (d.causal_offset < 0 || (d.causal && d.Sq + d.causal_offset > d.Sk)) return SEER_EINVAL;
     switch (d.head_dim) {
-        case 40: return launch_attn<40>(d, ws_log2, st);
+        case 40:
+            // the d = 40 kernel pays ~3 us of set-up (constant region, LDS-DMA plan, reference pre-pass) that short key
+            // sequences do not earn back (text cross-attention, Sk = 77: 18.7 vs 16.6 us, profiles/r02_attn40_variants.log)
+            if (d.variant == 1 || d.variant == 6 || (d.variant == 0 && d.Sk < 256)) return launch_attn<40>(d, ws_log2, st);
+            return seer_attn40_launch(d, ws_log2, st);
         case 80: return launch_attn<80>(d, ws_log2, st);
         case 96: return launch_attn<96>(d, ws_log2, st);      // FSTextTransformer (768 channels, 8 heads)
         case 160: return launch_attn<160>(d, ws_log2, st);

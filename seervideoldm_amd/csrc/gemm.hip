@@ -484,6 +484,10 @@ __global__ void __launch_bounds__(128 * WM) seer_gemm_kernel(const seer_gemm_des
                     v[3] = b1 * cs[2] + a1 * cs[3];
                 }
             }
+            if ((p.epilogue & SEER_EPI_COLSCALE) && n < p.col_scale_cols) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= p.col_scale;
+            }
             if (R) {
                 u32x2 rv;
                 if constexpr (!GEGLU) rv = rpre[i][j];
@@ -559,6 +563,10 @@ __global__ void __launch_bounds__(256) seer_splitk_reduce_kernel(const seer_gemm
     if (p.epilogue & SEER_EPI_SILU) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+    }
+    if ((p.epilogue & SEER_EPI_COLSCALE) && n < p.col_scale_cols) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= p.col_scale;
     }
     if (p.residual) {
         const u32x2 rv = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16*>(p.residual) + (int64_t)m * p.ldr + n);
@@ -664,6 +672,9 @@ int prepare(seer_gemm_desc& d, int* splits) {
         if (!d.rot_table || d.rot_head_dim <= 0 || d.rot_head_dim % 4 || d.rot_dim <= 0 || d.rot_dim % 4 ||
             d.rot_dim > d.rot_head_dim || d.rot_tokens_per_batch <= 0 || d.rot_cols % d.rot_head_dim || geglu)
             return SEER_EINVAL;
+    }
+    if (d.epilogue & SEER_EPI_COLSCALE) {
+        if (geglu || d.col_scale_cols <= 0 || d.col_scale_cols % 4 || d.col_scale_cols > d.N) return SEER_EINVAL;
     }
     if (d.batch <= 1) d.batch = 1;
 

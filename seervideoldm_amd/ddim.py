@@ -112,6 +112,11 @@ class DDIMSampler(object):
         device = self.device
         b = shape[0]
         img = torch.randn(shape, device=device) if x_T is None else x_T.to(device=device, dtype=torch.float32)
+        # one clip sharded over several ranks (parallel.attach): every rank must denoise the SAME latent.  The start code,
+        # the conditioning latents (a per-rank posterior sample) and any per-step noise come from rank 0.
+        img = _from_rank0(unet, img)
+        if x0_emb is not None:
+            x0_emb = _from_rank0(unet, x0_emb.to(device))
         timesteps = self.ddim_timesteps
         intermediates = {"x_inter": [img], "pred_x0": [img]}
         total_steps = timesteps.shape[0]
@@ -169,9 +174,22 @@ class DDIMSampler(object):
         noise = None
         if sigma != 0. or self.consume_rng_when_deterministic:
             noise = torch.randn(x.shape, device=x.device) * temperature
+            if sigma != 0.:
+                noise = _from_rank0(unet, noise)
         x_prev, pred_x0 = ops.cfg_ddim_step(eps.float().contiguous(), x, self.ddim_coef, index, cfg=cfg, scale=scale,
                                             cond_f=cond_f, noise=noise if sigma != 0. else None)
         return x_prev, pred_x0
+
+
+def _from_rank0(unet, t: torch.Tensor) -> torch.Tensor:
+    """broadcast `t` from rank 0 when `unet` runs one clip sharded over several ranks; identity otherwise"""
+    shard = getattr(unet, "_shard", None)
+    if shard is None or shard.world <= 1:
+        return t
+    import torch.distributed as dist
+    t = t.contiguous()
+    dist.broadcast(t, src=0)
+    return t
 
 
 @torch.no_grad()

@@ -38,9 +38,11 @@ def _req(t: torch.Tensor, dtype, name: str):
 # ------------------------------------------------------------------------------------------------------------
 def gemm(a: torch.Tensor, w: torch.Tensor, *, bias=None, residual=None, rowvec=None, rows_per_batch=0,
          a2: Optional[torch.Tensor] = None, geglu=False, silu=False, out_f32=False, out: Optional[torch.Tensor] = None,
-         tile=0, splits=0, rotary=None) -> torch.Tensor:
+         tile=0, splits=0, rotary=None, col_scale=None) -> torch.Tensor:
     """out[M,N] = epi(a[M,K1] | a2[M,K-K1]) @ w[N,K]^T ; a/a2 may be row-strided views (last dim contiguous).
-    rotary = (cos_sin table, tokens_per_batch, pos_offset, head_dim, rot_dim, cols): rotate columns < cols in the epilogue."""
+    rotary = (cos_sin table, tokens_per_batch, pos_offset, head_dim, rot_dim, cols): rotate columns < cols in the epilogue.
+    col_scale = (factor, cols): multiply output columns < cols by factor (the q columns of a projection carry the softmax
+    scale * log2(e) for attention(..., q_prescaled=True))."""
     _req(a, bf16, "a"); _req(w, bf16, "w")
     assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.is_contiguous()
     M, K1 = a.shape
@@ -80,6 +82,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias=None, residual=None, rowvec=N
         d.epilogue |= _lib.SEER_EPI_ROTARY
         d.rot_table, d.rot_tokens_per_batch, d.rot_pos_offset = _p(table), tpb, pos_off
         d.rot_head_dim, d.rot_dim, d.rot_cols = hd, rd, cols
+    if col_scale is not None:
+        d.epilogue |= _lib.SEER_EPI_COLSCALE
+        d.col_scale, d.col_scale_cols = float(col_scale[0]), int(col_scale[1])
     d.batch = 1
     d.tile = tile
     d.splits = splits
@@ -171,13 +176,16 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
               head_dim: int, Sq: int, Sk: int, causal=False, scale: Optional[float] = None,
               window=None, Fq: Optional[int] = None, causal_offset: int = 0,
               seq_stride_rows: int = 1, batch_stride_rows: Optional[int] = None,
-              lse: Optional[torch.Tensor] = None, _desc_only: bool = False) -> torch.Tensor:
+              lse: Optional[torch.Tensor] = None, q_prescaled: bool = False, variant: int = 0,
+              _desc_only: bool = False) -> torch.Tensor:
     """q/k/v/out are 2-D token-major views [batch*S, >=heads*head_dim] (row stride = token stride, e.g. column slices
     of a fused qkv buffer).  window = (ws, F, H, W) selects the temporal window form (K/V: F*H*W tokens per batch
     element in memory, Sk = F*ws*ws per window; Q/O hold Fq frames, Fq = F unless frame-sharded).  causal_offset is the
     sequence position of query 0 in the key sequence (frame shards).  seq_stride_rows / batch_stride_rows: token s of
     sequence b sits in row b*batch_stride_rows + s*seq_stride_rows (default: sequences stored one after the other) --
-    FSTextTransformer's attention over frames reads rows ordered (frame, token) with seq stride = tokens per frame."""
+    FSTextTransformer's attention over frames reads rows ordered (frame, token) with seq stride = tokens per frame.
+    q_prescaled: q already holds q * scale * log2(e) (gemm(..., col_scale=(qk_prescale(head_dim), cols))).
+    variant: kernel selection for A/B runs (include/seer_hip.h, seer_attn_desc.variant); 0 = auto."""
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (out, "out")):
         _req(t, bf16, n)
         assert t.dim() == 2 and t.stride(1) == 1
@@ -202,6 +210,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     d.batch, d.heads, d.head_dim, d.Sq, d.Sk = batch, heads, head_dim, Sq, Sk
     d.causal = int(causal)
     d.scale = float(scale if scale is not None else head_dim ** -0.5)
+    d.flags = _lib.SEER_ATTN_Q_PRESCALED if q_prescaled else 0
+    d.variant = variant
     if lse is not None:         # training: keep the softmax statistics for seer_attn_bwd
         _req(lse, torch.float32, "lse")
         nb = batch if window is None else batch * (window[2] // window[0]) * (window[3] // window[0])
@@ -211,6 +221,14 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
         return d
     check(_lib.load().seer_attn_fwd(C.byref(d), _stream()), "seer_attn_fwd")
     return out
+
+
+LOG2E = 1.4426950408889634
+
+
+def qk_prescale(head_dim: int, scale: Optional[float] = None) -> float:
+    """the factor a projection's q columns are multiplied by for attention(..., q_prescaled=True)"""
+    return (head_dim ** -0.5 if scale is None else scale) * LOG2E
 
 
 def rotary_table(freqs: torch.Tensor, T: int) -> torch.Tensor:

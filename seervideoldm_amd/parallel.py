@@ -125,7 +125,8 @@ class FrameShard:
 
     def temporal_attention(self, ops, qkv: torch.Tensor, out: torch.Tensor, B: int, heads: int, d: int, H: int, W: int,
                            sync=None):
-        """causal (window) attention of the local frames' queries over the gathered K|V of frames [0, F_total)."""
+        """causal (window) attention of the local frames' queries over the gathered K|V of frames [0, F_total).
+        The q columns of `qkv` carry scale * log2(e) (unet._temporal_transformer)."""
         C = heads * d
         HW = H * W
         Fl, Ft, f0 = self.local_frames, self.total_frames, self.frame_offset
@@ -133,10 +134,11 @@ class FrameShard:
         if H > MIN_WIN_SIZE:
             ws = MAX_WIN_SIZE if (H // MAX_WIN_SIZE) >= MAX_RATIO else MIN_WIN_SIZE
             ops.attention(qkv[:, :C], kv[:, :C], kv[:, C:], out, batch=B, heads=heads, head_dim=d, Sq=Fl * ws * ws,
-                          Sk=Ft * ws * ws, causal=True, window=(ws, Ft, H, W), Fq=Fl, causal_offset=f0 * ws * ws)
+                          Sk=Ft * ws * ws, causal=True, window=(ws, Ft, H, W), Fq=Fl, causal_offset=f0 * ws * ws,
+                          q_prescaled=True)
         else:
             ops.attention(qkv[:, :C], kv[:, :C], kv[:, C:], out, batch=B, heads=heads, head_dim=d, Sq=Fl * HW,
-                          Sk=Ft * HW, causal=True, causal_offset=f0 * HW)
+                          Sk=Ft * HW, causal=True, causal_offset=f0 * HW, q_prescaled=True)
 
     # ---- whole-step plumbing --------------------------------------------------------------------------------------
     def gather_output(self, local: torch.Tensor, B: int, F: int) -> torch.Tensor:

@@ -54,7 +54,8 @@ def generate_clips(sunet, fstext_model, vae, sampler, x0_image: torch.Tensor, te
 def concat_all_gather(t: torch.Tensor, process_group=None) -> torch.Tensor:
     """eval.py's `concat_all_gather(accelerator, t)` (= accelerator.gather): the per-rank batches stacked in rank order"""
     import torch.distributed as dist
-    if process_group is None or not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+    # None = the default (WORLD) group, as accelerator.gather always gathers over WORLD (eval.py:226-231)
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(process_group) == 1:
         return t
     t = t.contiguous()
     parts = [torch.empty_like(t) for _ in range(dist.get_world_size(process_group))]
@@ -64,16 +65,19 @@ def concat_all_gather(t: torch.Tensor, process_group=None) -> torch.Tensor:
 
 @torch.no_grad()
 def evaluate_batch(sunet, fstext_model, vae, sampler, video: torch.Tensor, text_emb: torch.Tensor, empty_emb: torch.Tensor, *,
-                   cond_frames: int, ddim_steps: int = 30, scale: float = 7.5, process_group=None,
+                   cond_frames: int, ddim_steps: int = 30, scale: float = 7.5, process_group=None, gather: bool = True,
                    noise_generator: Optional[torch.Generator] = None, latent_generator: Optional[torch.Generator] = None):
     """The body of eval.py's validation loop (eval.py:186-231) for THIS rank's batch: the first `cond_frames` frames of
     `video` [b, 3, F, H, W] in [-1, 1] condition the rest; returns (pred, gt) = ([conditioning frames | sampled frames],
-    ground truth), both [N*b, 3, F, H, W] in [0, 1] gathered over the ranks of `process_group` in rank order.  N GPUs evaluate
-    N batches with no communication until this final gather (the samples are the independent units of the path)."""
+    ground truth), both [N*b, 3, F, H, W] in [0, 1] gathered over the ranks of `process_group` (None = every rank, as
+    accelerator.gather does) in rank order.  N GPUs evaluate N batches with no communication until this final gather (the
+    samples are the independent units of the path); gather=False returns this rank's batch only."""
     x0 = video[:, :, :cond_frames]
     clip = generate_clips(sunet, fstext_model, vae, sampler, x0, text_emb, empty_emb, num_frames=video.shape[2],
                           cond_frames=cond_frames, ddim_steps=ddim_steps, scale=scale, num_samples=1,
                           noise_generator=noise_generator, latent_generator=latent_generator)[0]
     pred = torch.cat([(x0.float() + 1.0) / 2.0, clip], dim=2)
     gt = (video.float() + 1.0) / 2.0
+    if not gather:
+        return pred, gt
     return concat_all_gather(pred, process_group), concat_all_gather(gt, process_group)

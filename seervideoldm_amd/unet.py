@@ -309,20 +309,23 @@ class _Engine:
         h = ops.gemm(hn, w[p + ".proj_in.weight"], bias=w[p + ".proj_in.bias"])
         # self attention per frame
         n1 = ops.layernorm(h, w[tb + ".norm1.weight"], w[tb + ".norm1.bias"])
-        qkv = ops.gemm(n1, w[tb + ".attn1.qkv"])
+        # the q columns leave the projection as q * scale * log2(e) (one bf16 rounding): the attention kernels exponentiate
+        # the raw dot products
+        qs = ops.qk_prescale(d)
+        qkv = ops.gemm(n1, w[tb + ".attn1.qkv"], col_scale=(qs, C))
         a = torch.empty_like(h)
         ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], a, batch=B * Fr, heads=heads, head_dim=d,
-                      Sq=HW, Sk=HW)
+                      Sq=HW, Sk=HW, q_prescaled=True)
         ops.gemm(a, w[tb + ".attn1.to_out.0.weight"], bias=w[tb + ".attn1.to_out.0.bias"], residual=h, out=h)
         # text cross attention per frame (K/V depend on the context only: cached across DDIM steps)
         n2 = ops.layernorm(h, w[tb + ".norm2.weight"], w[tb + ".norm2.bias"])
-        q = ops.gemm(n2, w[tb + ".attn2.q"])
+        q = ops.gemm(n2, w[tb + ".attn2.q"], col_scale=(qs, C))
         kv = self._kv_cache.get(tb)
         if kv is None:
             kv = ops.gemm(self._ctx, w[tb + ".attn2.kv"])
             self._kv_cache[tb] = kv
         L = self._ctx_len
-        ops.attention(q, kv[:, :C], kv[:, C:], a, batch=B * Fr, heads=heads, head_dim=d, Sq=HW, Sk=L)
+        ops.attention(q, kv[:, :C], kv[:, C:], a, batch=B * Fr, heads=heads, head_dim=d, Sq=HW, Sk=L, q_prescaled=True)
         ops.gemm(a, w[tb + ".attn2.to_out.0.weight"], bias=w[tb + ".attn2.to_out.0.bias"], residual=h, out=h)
         self._ff(tb, h)
         return ops.gemm(h, w[p + ".proj_out.weight"], bias=w[p + ".proj_out.bias"], residual=x)
@@ -357,7 +360,8 @@ class _Engine:
         rot_dim = min(32, d)
         cs = self._rotary_table(tb, F_all * HW)
         # q|k|v projection with the rotary embedding applied to the q and k columns in the GEMM epilogue
-        qkv = ops.gemm(n1, w[tb + ".attn1.qkv"], rotary=(cs, Fr * HW, f_off * HW, d, rot_dim, 2 * C))
+        qkv = ops.gemm(n1, w[tb + ".attn1.qkv"], rotary=(cs, Fr * HW, f_off * HW, d, rot_dim, 2 * C),
+                       col_scale=(ops.qk_prescale(d), C))
         a = torch.empty_like(h)
         if self.shard is not None:
             self.shard.temporal_attention(ops, qkv, a, B, heads, d, H, W, sync=self.sync_point)
@@ -365,10 +369,10 @@ class _Engine:
             if H > MIN_WIN_SIZE:
                 ws = MAX_WIN_SIZE if (H // MAX_WIN_SIZE) >= MAX_RATIO else MIN_WIN_SIZE
                 ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], a, batch=B, heads=heads, head_dim=d,
-                              Sq=Fr * ws * ws, Sk=Fr * ws * ws, causal=True, window=(ws, Fr, H, W))
+                              Sq=Fr * ws * ws, Sk=Fr * ws * ws, causal=True, window=(ws, Fr, H, W), q_prescaled=True)
             else:
                 ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], a, batch=B, heads=heads, head_dim=d,
-                              Sq=Fr * HW, Sk=Fr * HW, causal=True)
+                              Sq=Fr * HW, Sk=Fr * HW, causal=True, q_prescaled=True)
         ops.gemm(a, w[tb + ".attn1.to_out.0.weight"], bias=w[tb + ".attn1.to_out.0.bias"], residual=h, out=h)
         # FF skips the conditioning frames (attention.py:241-246); frames are the slow index inside a batch element
         skip_f = cond_frame if self.shard is None else self.shard.local_cond_frames(cond_frame)
@@ -502,6 +506,10 @@ class _Engine:
             except Exception as e:                       # capture refused (driver / RCCL state): stay correct, run eagerly
                 rec.abort()
                 self._rec = None
+                if self.shard is not None and self.shard.world > 1:
+                    # this rank has already issued some of the step's collectives: an eager re-run here would put the ranks
+                    # out of step with each other -- surface the failure instead of hanging the group
+                    raise
                 self._graph_broken = True
                 import warnings
                 warnings.warn(f"hipGraph capture of the denoising step failed ({type(e).__name__}: {e}); running eagerly")
@@ -517,7 +525,9 @@ class _Engine:
         t_in.copy_(t)
         for step in rec.steps:
             step()
-        return out
+        # `out` is the graph's static output buffer: the caller gets its own copy (eps is only [B,4,F,h,w]); two replays of
+        # one graph -- the unbatched CFG branch of p_sample_ddim calls uc then c -- must not alias each other's result
+        return out.clone()
 
 
 class _SegmentRecorder:

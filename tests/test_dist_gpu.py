@@ -189,16 +189,16 @@ def _eval_worker(rank, world, port, out_path):
         vae.load_state_dict(ldm_to_diffusers_vae(vsd, 4), strict=True)
         unet, fst, vae = unet.to(dev).eval(), fst.to(dev).eval(), vae.to(dev)
 
-        def run(r, pg):
+        def run(r, pg, gather=True):
             g = torch.Generator().manual_seed(50 + r)                 # rank r's batch
             video = torch.tanh(torch.randn((1, 3, 3, 64, 64), generator=g)).to(dev)
             text, empty = torch.randn((1, 77, 192), generator=g).to(dev), torch.randn((1, 77, 192), generator=g).to(dev)
             return evaluate_batch(unet, fst, vae, DDIMSampler(dev), video, text, empty, cond_frames=1, ddim_steps=2, scale=7.5,
-                                  process_group=pg, noise_generator=torch.Generator().manual_seed(7 + r),
+                                  process_group=pg, gather=gather, noise_generator=torch.Generator().manual_seed(7 + r),
                                   latent_generator=torch.Generator(device=dev).manual_seed(9 + r))
         pred, gt = run(rank, dist.group.WORLD)
         if rank == 0:
-            solo = [run(r, None) for r in range(world)]               # the same batches without a process group
+            solo = [run(r, None, gather=False) for r in range(world)]   # the same batches, no gather
             torch.save(dict(pred=pred.cpu(), gt=gt.cpu(), solo_pred=torch.cat([s[0] for s in solo]).cpu(),
                             solo_gt=torch.cat([s[1] for s in solo]).cpu()), out_path)
     finally:

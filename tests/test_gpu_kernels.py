@@ -373,6 +373,105 @@ def test_attention_softmax_spike(device):
     _close(out, ref.permute(0, 2, 1, 3).reshape(S, C), rtol=2e-2, atol=1e-2, what="spiked softmax")
 
 
+def _rel_l2(got, ref):
+    got, ref = got.float(), ref.float()
+    return ((got - ref).norm() / ref.norm().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("variant", [1, 3, 5])
+@pytest.mark.parametrize("Sq,Sk,causal", [(1024, 1024, False), (768, 768, True), (1000, 930, False), (333, 333, True),
+                                           (130, 2049, False), (64, 256, False)])
+def test_attention_d40_kernels(device, variant, Sq, Sk, causal):
+    """head_dim 40: the generic kernel (variant 1), the d = 40 kernel's fast path (3) and its tracked form (5) against the
+    fp32 formula (xformers MEA as called at attention.py:622-630)"""
+    from seervideoldm_amd import ops
+    B, Hh, d = 2, 8, 40
+    C = Hh * d
+    q = _rand((B, Sq, Hh, d), device, 1).to(bf16)
+    k = _rand((B, Sk, Hh, d), device, 2).to(bf16)
+    v = _rand((B, Sk, Hh, d), device, 3).to(bf16)
+    out = torch.zeros((B * Sq, C), device=device, dtype=bf16)
+    ops.attention(q.reshape(B * Sq, C), k.reshape(B * Sk, C), v.reshape(B * Sk, C), out, batch=B, heads=Hh,
+                  head_dim=d, Sq=Sq, Sk=Sk, causal=causal, causal_offset=(Sk - Sq if causal else 0), variant=variant)
+    qq, kk, vv = [t.permute(0, 2, 1, 3).float() for t in (q, k, v)]
+    s = torch.einsum("bhqd,bhkd->bhqk", qq, kk) * d ** -0.5
+    if causal:
+        i = torch.arange(Sq, device=device)[:, None] + (Sk - Sq)
+        s = s.masked_fill(~(torch.arange(Sk, device=device)[None, :] <= i), float("-inf"))
+    ref = torch.einsum("bhqk,bhkd->bhqd", s.softmax(-1), vv).permute(0, 2, 1, 3).reshape(B * Sq, C)
+    _close(out, ref, rtol=2e-2, atol=1e-2, what=f"d40 variant {variant} {Sq}x{Sk} causal={causal}")
+
+
+@pytest.mark.parametrize("d,variant", [(40, 1), (40, 3), (40, 5), (80, 0), (96, 0), (160, 0)])
+@pytest.mark.parametrize("amp", [3.0, 6.0])
+def test_attention_sharp_softmax(device, d, variant, amp):
+    """scores hundreds of log2 units apart (cdna guide, rule 26: the rare branch needs its own test).  This is the case that
+    exposed the dropped half of the running maximum (the second result of the permlane32_swap builtin) as NaN rows, and it
+    drives the d = 40 fast path into its overflow fallback."""
+    from seervideoldm_amd import ops
+    B, S, Hh = 2, 1024, 8
+    C = Hh * d
+    q = _rand((B, S, Hh, d), device, 31, amp).to(bf16)
+    k = _rand((B, S, Hh, d), device, 32, amp).to(bf16)
+    v = _rand((B, S, Hh, d), device, 33, amp).to(bf16)
+    out = torch.zeros((B * S, C), device=device, dtype=bf16)
+    ops.attention(q.reshape(B * S, C), k.reshape(B * S, C), v.reshape(B * S, C), out, batch=B, heads=Hh, head_dim=d,
+                  Sq=S, Sk=S, variant=variant)
+    assert torch.isfinite(out.float()).all(), "non-finite attention output"
+    ref = _attn_ref(q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3), False)
+    ref = ref.permute(0, 2, 1, 3).reshape(B * S, C)
+    # scores of magnitude ~amp^2 * sqrt(d): one ulp of a bf16 operand moves a score by ~2^-9 * |s|, and the softmax is
+    # nearly one-hot, so single rows can flip between two keys; the L2 norm is the meaningful measure.  The d = 40 kernel
+    # multiplies q by scale * log2(e) before the MFMA (one more rounding of q when the caller did not prescale it).
+    assert _rel_l2(out, ref) < (3e-2 if (d == 40 and variant != 1) else 1e-2)
+
+
+@pytest.mark.parametrize("d,S", [(40, 1024), (40, 77), (80, 256), (160, 64)])
+def test_attention_q_prescaled(device, d, S):
+    """q handed over as q * scale * log2(e) (SEER_ATTN_Q_PRESCALED): the kernels exponentiate the raw dot products"""
+    from seervideoldm_amd import ops
+    B, Hh = 3, 8
+    C = Hh * d
+    q = (_rand((B, S, Hh, d), device, 41) * ops.qk_prescale(d)).to(bf16)
+    k = _rand((B, S, Hh, d), device, 42).to(bf16)
+    v = _rand((B, S, Hh, d), device, 43).to(bf16)
+    out = torch.zeros((B * S, C), device=device, dtype=bf16)
+    ops.attention(q.reshape(B * S, C), k.reshape(B * S, C), v.reshape(B * S, C), out, batch=B, heads=Hh, head_dim=d,
+                  Sq=S, Sk=S, q_prescaled=True)
+    s = torch.einsum("bhqd,bhkd->bhqk", q.permute(0, 2, 1, 3).float(), k.permute(0, 2, 1, 3).float()) * math.log(2.0)
+    ref = torch.einsum("bhqk,bhkd->bhqd", s.softmax(-1), v.permute(0, 2, 1, 3).float()).permute(0, 2, 1, 3).reshape(B * S, C)
+    _close(out, ref, rtol=2e-2, atol=1e-2, what=f"prescaled q d{d}")
+
+
+def test_attention_d40_lse(device):
+    """the log-sum-exp the training step asks for comes from the tracked form of the d = 40 kernel (rounded P)"""
+    from seervideoldm_amd import ops
+    B, S, Hh, d = 2, 512, 8, 40
+    C = Hh * d
+    q = _rand((B, S, Hh, d), device, 51).to(bf16)
+    k = _rand((B, S, Hh, d), device, 52).to(bf16)
+    v = _rand((B, S, Hh, d), device, 53).to(bf16)
+    out = torch.zeros((B * S, C), device=device, dtype=bf16)
+    lse = torch.zeros((B * Hh, S), device=device, dtype=torch.float32)
+    ops.attention(q.reshape(B * S, C), k.reshape(B * S, C), v.reshape(B * S, C), out, batch=B, heads=Hh, head_dim=d,
+                  Sq=S, Sk=S, lse=lse)
+    s = torch.einsum("bhqd,bhkd->bhqk", q.permute(0, 2, 1, 3).float(), k.permute(0, 2, 1, 3).float()) * d ** -0.5
+    ref = torch.logsumexp(s, -1) / math.log(2.0)            # log2 domain
+    assert (lse.reshape(B, Hh, S) - ref).abs().max().item() < 2e-2
+
+
+def test_gemm_col_scale(device):
+    """SEER_EPI_COLSCALE: the first columns of a projection scaled in the epilogue, also through split-K"""
+    from seervideoldm_amd import ops
+    for M, N, K, cols, splits in ((512, 960, 320, 320, 1), (384, 1280, 2560, 1280, 4), (200, 384, 128, 128, 1)):
+        a = _rand((M, K), device, 61).to(bf16)
+        w = (_rand((N, K), device, 62) * K ** -0.5).to(bf16)
+        out = ops.gemm(a, w, col_scale=(0.228, cols), splits=splits)
+        ref = a.float() @ w.float().t()
+        ref[:, :cols] *= 0.228
+        _close(out, ref, what=f"col_scale {M}x{N}x{K}")
+
+
 @pytest.mark.parametrize("d,Fr,H,W,ws", [(40, 4, 32, 32, 8), (80, 12, 16, 16, 4), (160, 3, 8, 8, 4)])
 def test_window_attention(device, d, Fr, H, W, ws):
     """temporal window attention == window_partition -> causal attention -> window_reverse (attention.py:42-69,661-703)."""

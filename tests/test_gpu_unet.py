@@ -280,6 +280,35 @@ def test_unbatched_cfg_branch(device):
     assert torch.equal(xc, xd)
 
 
+def test_unbatched_cfg_branch_under_graph_replay(device):
+    """the two-call CFG branch replays ONE captured graph twice (uc, then c: same shapes): the two results must be distinct
+    tensors -- a replay that hands out its static output buffer returns eps_c twice and silently drops the guidance"""
+    cfg, sd, m = _model("mini", device)
+    b, f1, Fp, H = 1, 1, 2, 16
+    D = cfg["cross_attention_dim"]
+    x0_emb, x = (_randn((b, 4, f1, H, H), 1) * 0.9).to(device), _randn((b, 4, Fp, H, H), 4).to(device)
+    c = _randn((b, f1 + Fp, 77, D), 2).to(device)
+    uc3 = _randn((b, 77, D), 3).to(device)
+    smp = DDIMSampler(device)
+    smp.make_schedule(4, verbose=False)
+    t = torch.full((b,), 751, dtype=torch.long, device=device)
+    kw = dict(index=3, x0_emb=x0_emb, cond_frames=f1, unconditional_guidance_scale=7.5, unconditional_conditioning=uc3)
+    x_eager, p_eager = smp.p_sample_ddim(m, x, c, t, **kw)
+    m.use_graph = True
+    try:
+        for _ in range(2):      # capture, then pure replay
+            x_graph, p_graph = smp.p_sample_ddim(m, x, c, t, **kw)
+            assert torch.equal(x_graph, x_eager) and torch.equal(p_graph, p_eager)
+        xa = torch.cat([x0_emb, x], dim=2)
+        ctx_c = c
+        ctx_uc = uc3[:, None].expand(-1, f1 + Fp, -1, -1).contiguous()
+        e_uc = m(xa, t, ctx_uc, cond_frame=f1)
+        e_c = m(xa, t, ctx_c, cond_frame=f1)
+        assert e_uc.data_ptr() != e_c.data_ptr() and not torch.equal(e_uc, e_c)
+    finally:
+        m.use_graph = False
+
+
 @pytest.mark.parametrize("H,W", [(16, 32), (32, 16), (8, 24)])
 def test_non_square_latents(device, H, W):
     """the datasets are not all square (bridge data is 4:3): window geometry, convs and the frame-coupled GroupNorm at H != W"""

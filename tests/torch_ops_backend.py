@@ -42,7 +42,7 @@ def _epilogue(acc, bias, geglu, rowvec, rows_per_batch, silu, residual, out_f32,
 
 
 def gemm(a, w, *, bias=None, residual=None, rowvec=None, rows_per_batch=0, a2=None, geglu=False, silu=False,
-         out_f32=False, out=None, tile=0, splits=0, rotary=None):
+         out_f32=False, out=None, tile=0, splits=0, rotary=None, col_scale=None):
     A = a.float() if a2 is None else torch.cat([a.float(), a2.float()], 1)
     assert A.shape[1] % 64 == 0 and w.dtype == bf16 and a.dtype == bf16
     acc = A @ w.float().t()
@@ -56,6 +56,9 @@ def gemm(a, w, *, bias=None, residual=None, rowvec=None, rows_per_batch=0, a2=No
         x0, x1 = t[..., :rd:2], t[..., 1:rd:2]
         rot = torch.stack([x0 * c[:, None] - x1 * s[:, None], x1 * c[:, None] + x0 * s[:, None]], -1).flatten(-2)
         acc = torch.cat([torch.cat([rot, t[..., rd:]], -1).reshape(rows, cols), acc[:, cols:]], 1)
+    if col_scale is not None:
+        assert bias is None and residual is None and not geglu
+        acc = torch.cat([acc[:, :col_scale[1]] * col_scale[0], acc[:, col_scale[1]:]], 1)
     return _epilogue(acc, bias, geglu, rowvec, rows_per_batch, silu, residual, out_f32, out)
 
 
@@ -80,6 +83,13 @@ def conv3x3(x, w, n_img, Hin, Win, *, stride=1, upsample=False, bias=None, resid
     return _epilogue(y, bias, False, rowvec, rows_per_batch, False, residual, False, out)
 
 
+LOG2E = 1.4426950408889634
+
+
+def qk_prescale(head_dim, scale=None):
+    return (head_dim ** -0.5 if scale is None else scale) * LOG2E
+
+
 def _tok_index(batch, ws, Fr, H, W):
     """token index [nW, Fr*ws*ws] of every window position, order (f, wy, wx); windows ordered (wy_blk, wx_blk)"""
     f = torch.arange(Fr)[:, None, None]
@@ -93,10 +103,12 @@ def _tok_index(batch, ws, Fr, H, W):
 
 
 def attention(q, k, v, out, *, batch, heads, head_dim, Sq, Sk, causal=False, scale=None, window=None, Fq=None,
-              causal_offset=0, seq_stride_rows=1, batch_stride_rows=None, lse=None):
+              causal_offset=0, seq_stride_rows=1, batch_stride_rows=None, lse=None, q_prescaled=False, variant=0):
     assert head_dim in (40, 80, 96, 160), "the flash kernels are built for head_dim 40/80/96/160"
     C = heads * head_dim
     scale = head_dim ** -0.5 if scale is None else scale
+    if q_prescaled:         # q carries scale * log2(e): softmax_e(scale * qk) == softmax_2(q'k)
+        scale = 0.6931471805599453
     if batch_stride_rows is not None:
         # row(b, s) = b*batch_stride_rows + s*seq_stride_rows: gather to the contiguous form, run, scatter back
         assert window is None
