@@ -78,5 +78,23 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     return LIB
 
 
+def build_c_caller() -> Path:
+    """tests/abi_caller.c -> build/abi_caller: a plain C99 host of the ABI, compiled with gcc against include/seer_hip.h and
+    the HIP runtime's C API (git-ignored; travels to the GPU box with the gpurun snapshot)."""
+    out = ROOT / "build" / "abi_caller"
+    src = ROOT / "tests" / "abi_caller.c"
+    out.parent.mkdir(exist_ok=True)
+    if out.exists() and out.stat().st_mtime >= max(src.stat().st_mtime, LIB.stat().st_mtime):
+        return out
+    rocm = Path(os.environ.get("ROCM_PATH", "/opt/rocm"))
+    cmd = ["gcc", "-std=c99", "-O1", "-D__HIP_PLATFORM_AMD__", f"-I{ROOT / 'include'}", f"-I{rocm / 'include'}", str(src),
+           "-o", str(out), f"-L{LIBDIR}", "-lseer_hip", f"-L{rocm / 'lib'}", "-lamdhip64", "-lm",
+           "-Wl,-rpath,$ORIGIN/../seervideoldm_amd/lib", f"-Wl,-rpath,{rocm / 'lib'}"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"gcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+    return out
+
+
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv, verbose=True))

@@ -1,6 +1,7 @@
 // Small / boundary kernels of the Seer hot path on gfx950: rotary embedding, timestep embedding, small-M linear,
 // conv_in / conv_out (layout change fused), casts, CFG + DDIM update.
 #include "seer_common.h"
+#include <atomic>
 
 namespace {
 
@@ -385,12 +386,12 @@ extern "C" int seer_timestep_embedding(const int64_t* t, int32_t B, int32_t dim,
 
 // kernels whose dynamic LDS may exceed the 64 KiB default: opt in once per kernel (160 KiB per CU on gfx950)
 template <typename K>
-int ensure_lds(K kernel, size_t bytes, bool* done) {
+int ensure_lds(K kernel, size_t bytes, std::atomic<bool>* done) {      // setting the attribute twice is harmless: the flag only has to be race-free
     if (bytes > 160 * 1024) return SEER_EINVAL;
-    if (bytes > 64 * 1024 && !*done) {
+    if (bytes > 64 * 1024 && !done->load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return SEER_ELAUNCH;
-        *done = true;
+        done->store(true, std::memory_order_release);
     }
     return SEER_OK;
 }
@@ -401,13 +402,13 @@ extern "C" int seer_linear_smallm(const float* x, int32_t B, int32_t K, const vo
     const size_t lds = (size_t)B * K * sizeof(float);
     const bf16* Wb = reinterpret_cast<const bf16*>(W);
     if (B <= 2) {
-        static bool done = false;
+        static std::atomic<bool> done{false};
         const int rc = ensure_lds(linear_smallm_kernel<2, 4>, lds, &done);
         if (rc != SEER_OK) return rc;
         hipLaunchKernelGGL((linear_smallm_kernel<2, 4>), dim3((N + 15) / 16), dim3(256), lds, S(stream), x, B, K, Wb, bias, N,
                            silu_in, silu_out, y);
     } else {
-        static bool done = false;
+        static std::atomic<bool> done{false};
         const int rc = ensure_lds(linear_smallm_kernel<8, 2>, lds, &done);
         if (rc != SEER_OK) return rc;
         hipLaunchKernelGGL((linear_smallm_kernel<8, 2>), dim3((N + 7) / 8), dim3(256), lds, S(stream), x, B, K, Wb, bias, N,
@@ -423,7 +424,7 @@ extern "C" int seer_conv_in(const float* x, int32_t B, int32_t Cin, int32_t F, i
         return SEER_EINVAL;
     const int ppb = 32;
     const size_t lds = ((size_t)9 * Cin * Cout + (size_t)ppb * 9 * Cin) * sizeof(float);
-    static bool done = false;
+    static std::atomic<bool> done{false};
     const int rc = ensure_lds(conv_in_kernel, lds, &done);
     if (rc != SEER_OK) return rc;
     const int64_t npix = (int64_t)B * F * H * W_;
@@ -442,12 +443,12 @@ extern "C" int seer_conv_out(const void* x, int32_t B, int32_t C0, int32_t F, in
     const size_t lds = (size_t)Cout * 9 * C0 * sizeof(float);
     const bf16* xb = reinterpret_cast<const bf16*>(x);
     if (Cout == 4) {
-        static bool done = false;
+        static std::atomic<bool> done{false};
         const int rc = ensure_lds(conv_out_kernel<4>, lds, &done);
         if (rc != SEER_OK) return rc;
         hipLaunchKernelGGL(conv_out_kernel<4>, grid, dim3(256), lds, S(stream), xb, B, C0, F, H, W_, Wt, bias, y, ppb);
     } else if (Cout == 3) {
-        static bool done = false;
+        static std::atomic<bool> done{false};
         const int rc = ensure_lds(conv_out_kernel<3>, lds, &done);
         if (rc != SEER_OK) return rc;
         hipLaunchKernelGGL(conv_out_kernel<3>, grid, dim3(256), lds, S(stream), xb, B, C0, F, H, W_, Wt, bias, y, ppb);

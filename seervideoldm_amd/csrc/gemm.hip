@@ -13,6 +13,7 @@
 // Implicit GEMM conv: k = (ky, kx, ci); Cin % 64 == 0 so a 64-wide K tile never straddles a filter tap; the
 // tap -> pixel offset is wave-uniform scalar work, the per-row pixel decode is hoisted out of the K loop.
 #include "seer_common.h"
+#include <mutex>
 
 namespace {
 
@@ -592,9 +593,10 @@ int launch_tile(const seer_gemm_desc& d, hipStream_t st) {
     const size_t lds = (size_t)(NS == 0 ? 2 : NS) * (BM + BN) * BK * sizeof(bf16);
     constexpr bool GEGLU_OK = ((BN / 32) % 2) == 0;      // value / gate n-tile pairs must sit in one wave
     if (lds > 64 * 1024) {
-        // above the default dynamic-LDS limit: opt in once per instantiation (160 KiB per CU on gfx950)
-        static bool done = false;
-        if (!done) {
+        // above the default dynamic-LDS limit: opt in once per instantiation (160 KiB per CU on gfx950); std::call_once keeps
+        // concurrent first calls from different host threads safe (the header promises thread safety)
+        static std::once_flag once;
+        std::call_once(once, [lds] {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, true, false, false, NS, WM>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if constexpr (GEGLU_OK)
@@ -602,8 +604,7 @@ int launch_tile(const seer_gemm_desc& d, hipStream_t st) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, false, false, false, NS, WM>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            done = true;
-        }
+        });
     }
     const bool conv = d.mode == SEER_GEMM_CONV3X3;
     const bool geglu = (d.epilogue & SEER_EPI_GEGLU) != 0;

@@ -4,6 +4,7 @@
 // All reductions are two-stage (per-block partials in a caller workspace, added in block order): no float atomics, so a
 // step is bit-reproducible.
 #include "seer_common.h"
+#include <mutex>
 
 namespace {
 
@@ -901,12 +902,11 @@ extern "C" int seer_conv_out_bwd(const float* dpred, int32_t B, int32_t C0, int3
     const size_t lds = ((size_t)Cout * 9 * C0 + (size_t)Cout * 3 * (W_ + 2)) * sizeof(float);
     if (lds > 160 * 1024) return SEER_ENOSYS;
     if (lds > 64 * 1024) {
-        static bool done = false;
-        if (!done) {
+        static std::once_flag once;
+        std::call_once(once, [] {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_out_bwd_kernel<4>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            done = true;
-        }
+        });
     }
     hipLaunchKernelGGL(conv_out_bwd_kernel<4>, dim3((unsigned)(B * F * H)), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
                        dpred, B, C0, F, H, W_, Wt, reinterpret_cast<bf16*>(dx));

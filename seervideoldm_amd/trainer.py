@@ -787,6 +787,20 @@ class SeerTrainer:
             if hasattr(mod, "_invalidate"):
                 mod._invalidate()
 
+    @torch.no_grad()
+    def reload_from_modules(self) -> None:
+        """re-read the trainable tensors from the modules (after a `load_state_dict`: resume, train.py:268-272) into the flat
+        master buffers IN PLACE: the working weights and the captured graphs are views of / read those buffers by address"""
+        packed_u = _pack_temporal_fp32(dict(self.unet.state_dict()))
+        packed_f = _pack_fstext_fp32(dict(self.fstext.state_dict()), self.fstext.num_layers)
+        for P, packed in ((self.pu, packed_u), (self.pf, packed_f)):
+            for k in P.names:
+                P.view(P.p, k).copy_(packed[k].to(self.device, f32).reshape(P.shapes[k]))
+            P.pb.copy_(P.p)
+        for k in list(self._wT):                      # transposed copies of trainable matrices are stale now
+            if k in self.trainable_u or k in self.wf:
+                del self._wT[k]
+
     def save_state(self, save_path: str, global_step: Optional[int] = None, epoch: int = 0) -> str:
         """the files of `accelerator.save_state(save_path)` that inference reads back (inference_img.py:98-104):
         `pytorch_model.bin` (SeerUNet) and `pytorch_model_1.bin` (FSTextTransformer), plus the Adam state of this trainer

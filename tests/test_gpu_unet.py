@@ -2,12 +2,18 @@
 (oracle/seer_oracle.py, itself pinned to the reference by tests/golden) on identical closed-form weights and seeded
 inputs.
 
-Tolerance (stated, bf16 storage + fp32 accumulation against an fp32 oracle through ~100 dependent layers):
-    relative L2 error  ||hip - oracle|| / ||oracle||  <= 3e-2   and   max |hip - oracle| <= 0.08 * max |oracle|
-An fp16-autocast run of the reference itself sits at the same order (it rounds every Linear/conv output to 11 bits;
-bf16 keeps 8).  Structural bugs (wrong window order, wrong rotary position, missing GroupNorm coupling) show up as
-relative errors of 0.3 - 1.4, an order of magnitude above the bound.
+Tolerance (bf16 storage + fp32 accumulation against an fp32 oracle through ~100 dependent layers), set from a MEASURED
+number: the reference itself, run under CPU bf16 autocast (accelerate's mixed precision) against its own fp32 run on the
+width-320 network, differs by rel-L2 1.8e-2 (tests/golden/calibration_bf16.json, written by oracle/make_goldens_w320.py;
+tests/test_calibration.py re-measures it with the oracle on every box).  The HIP path also keeps its activations in bf16
+between layers, so its bound is 1.65 x that number:
+    relative L2 error  ||hip - oracle|| / ||oracle||  <= 1.65 * 1.82e-2 = 3.0e-2   and   max |hip - oracle| <= 0.08 * max |oracle|
+Structural bugs (wrong window order, wrong rotary position, missing GroupNorm coupling) show up as relative errors of
+0.3 - 1.4, an order of magnitude above the bound.
 """
+import json
+from pathlib import Path
+
 import numpy as np
 import pytest
 import torch
@@ -18,7 +24,9 @@ from seervideoldm_amd.vae import ldm_to_diffusers_vae
 
 pytestmark = pytest.mark.gpu
 
-REL_L2, REL_MAX = 3e-2, 0.08
+_CALIB = json.loads((Path(__file__).resolve().parent / "golden" / "calibration_bf16.json").read_text())
+REL_L2 = 1.65 * _CALIB["unet_w320_bf16_autocast_vs_fp32"]["rel_l2"]
+REL_MAX = 0.08
 
 # head dims must be in {40, 80, 160} for the flash kernels: channel widths are the real ones, depth/size are reduced
 CFG_MINI = dict(block_out_channels=(320, 320, 320, 320), layers_per_block=1, cross_attention_dim=256, attention_head_dim=8)
@@ -211,6 +219,56 @@ def test_full_size_step_properties(device):
     c2 = torch.cat([c1, _randn((1, 12, 77, 768), 3).to(device)])
     y2 = m(x, torch.tensor([981, 981], device=device), c2)
     assert (y2[1] - y[1]).abs().max() > 1e-3 and (y2[0] - y[0]).abs().max() <= 1e-3 * y.abs().max().item()
+
+
+def test_full_size_step_matches_oracle(device):
+    """BASELINE config 2 end to end against the oracle: CFG batch 2 x 12 frames (2 conditioning) x 32^2, the full-width
+    two-layers-per-block UNet (1.08 G parameters) -- the exact shape bench.py times (windows 8 / 4 / 4 / none, head dims
+    40 / 80 / 160, 768 causal keys per window at the top level).  The fp32 oracle forward takes ~10 s on the box's host cores."""
+    cfg = dict(synth.SD15_UNET_CFG)
+    sd = synth.synth_state_dict(synth.unet_param_shapes(cfg), device=device)
+    m = SeerUNet(**cfg).to(device)
+    m.load_state_dict(sd, strict=True)
+    sd_cpu = {k: v.cpu() for k, v in sd.items()}
+    del sd
+    x = _randn((2, 4, 12, 32, 32), 11)
+    ctx = _randn((2, 12, 77, 768), 12)
+    t = torch.tensor([981, 981])
+    got = m(x.to(device), t.to(device), ctx.to(device), cond_frame=2)
+    ref = O.unet_forward(sd_cpu, cfg, x, t, ctx, cond_frame=2)
+    _check(got, ref, "config 2 full size (B2 F12 32x32, cond 2)")
+    del m, sd_cpu
+    torch.cuda.empty_cache()
+
+
+def test_bridge_config_single_gpu(device):
+    """BASELINE config 3 on one GPU: CFG batch 8 (4 samples x [uc, c]) x 16 frames (1 conditioning) x 32^2, full-width UNet.
+    (a) finite, right shape; (b) a sample's result does not depend on its batch slot or on its neighbours: rows 0 and 4 of
+    the B = 8 step equal the B = 2 step of that sample to rounding (tile / split-K choices differ with M, the arithmetic
+    per element does not); (c) hipGraph replay is bit-equal to the eager step."""
+    cfg = dict(synth.SD15_UNET_CFG)
+    m = SeerUNet(**cfg).to(device)
+    m.load_state_dict(synth.synth_state_dict(synth.unet_param_shapes(cfg), device=device), strict=True)
+    xs = _randn((4, 4, 16, 32, 32), 21).to(device)
+    cs, ucs = _randn((4, 16, 77, 768), 22).to(device), _randn((4, 16, 77, 768), 23).to(device)
+    x8, c8 = torch.cat([xs, xs]), torch.cat([ucs, cs])
+    t8 = torch.full((8,), 621, dtype=torch.long, device=device)
+    y8 = m(x8, t8, c8, cond_frame=1)
+    assert y8.shape == (8, 4, 16, 32, 32) and torch.isfinite(y8).all()
+    y2 = m(torch.cat([xs[:1], xs[:1]]), t8[:2], torch.cat([ucs[:1], cs[:1]]), cond_frame=1)
+    for a, b in ((y8[0], y2[0]), (y8[4], y2[1])):
+        rel = ((a - b).norm() / b.norm()).item()
+        print(f"[property] sample 0 inside the B=8 step vs alone: rel_l2 {rel:.3g}")
+        assert rel < 1e-2
+    m.use_graph = True
+    try:
+        g1 = m(x8, t8, c8, cond_frame=1)
+        g2 = m(x8, t8, c8, cond_frame=1)
+        assert torch.equal(g1, y8) and torch.equal(g2, y8)
+    finally:
+        m.use_graph = False
+    del m
+    torch.cuda.empty_cache()
 
 
 def test_new_prompt_at_a_recycled_address_is_not_a_cache_hit(device):
