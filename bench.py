@@ -9,10 +9,10 @@ A "step" is one `DDIMSampler.p_sample_ddim`: one CFG-batched SeerUNet forward (B
 update, on synthetic latents that are already resident in HBM.  Workload = BASELINE config 2 (Sthv2): b=1 (CFG batch 2),
 12 frames total (2 conditioning + 10 predicted), 32x32 latent (256^2 pixels), full-width SD-v1-5-shaped SeerUNet
 (1.08 G parameters, closed-form synthetic weights: there is no network for checkpoints), bf16 storage / fp32 accumulate.
-N > 1: the units of the path are independent samples, so N GPUs denoise N samples (one CFG-batched sample per GPU, no data-path
-collective): `value` = whole-job steps/s, "scaling": "weak".  The north star's partition of ONE sample (CFG halves, then frame
-shards with their GroupNorm / K|V exchanges: seervideoldm_amd/parallel.py) is timed in the same run and reported as
-`frame_sharded` (strong scaling of the per-sample latency).
+N > 1: the headline `value` is the north star's partition of ONE step over all GPUs (seervideoldm_amd/parallel.py: batch x CFG
+groups first -- no communication -- then frame shards inside a group, with their GroupNorm-statistics all-reduces and K|V
+all-gathers over RCCL), "scaling": "strong": the same work, N GPUs.  N GPUs denoising N independent samples (the path's natural
+units, no data-path collective; linear by construction) is timed in the same run and reported as `weak_scaling`.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel class (the MFMA GEMM / implicit-GEMM conv template,
 93 % of the step's FLOPs) from HIP-event timings taken inside this process; `cpu_baseline` times the CPU oracle
@@ -34,6 +34,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import torch  # noqa: E402
 
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16
+PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"
 WORKLOAD = dict(b=1, cond_frames=2, frames=12, latent=32, ddim_steps=50, scale=7.5)
 # BASELINE.json configs: [1] is the bench line (default); the others are parity-test cases that can be timed on request
 WORKLOADS = {
@@ -79,6 +80,30 @@ def gpu_busy(ms: float, device):
         ops.gemm(a, a, out=out, tile=1)
 
 
+def time_attention_block(device):
+    """the north star's named kernel target: spatial self-attention of the 32x32 level, [B*F*heads = 192, 1024 tokens, d = 40]
+    out of the fused q|k|v projection; back-to-back launches between two HIP events on the launch stream"""
+    from seervideoldm_amd import ops
+    B, S, H, d = 24, 1024, 8, 40
+    C = H * d
+    qkv = torch.randn((B * S, 3 * C), device=device).to(torch.bfloat16)
+    out = torch.empty((B * S, C), device=device, dtype=torch.bfloat16)
+    run = lambda: ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, batch=B, heads=H, head_dim=d, Sq=S, Sk=S)
+    for _ in range(5):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 50
+    e0.record()
+    for _ in range(n):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / n * 1e3
+    tf = 4.0 * B * H * S * S * d / us * 1e-6
+    return dict(shape="[192, 1024, 40] bf16, non-causal", us_per_launch=round(us, 2), achieved=round(tf, 1), unit="TFLOP/s",
+                frac=round(tf / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), flops="4*BH*Sq*Sk*d")
+
+
 def host_threads() -> int:
     """threads for the CPU baseline: the CPUs this process may actually use (affinity and cgroup quota), then the count
     that runs a probe matmul fastest (256 logical CPUs oversubscribed by a small quota run an order of magnitude slower)."""
@@ -122,13 +147,14 @@ def cpu_baseline(sd_cpu, cfg, budget_s):
             O.unet_forward(sd_cpu, cfg, x, torch.tensor([981, 981]), c, 0)
         return time.perf_counter() - t0
 
-    t1 = one(1)                                   # also the warm-up
-    F = int(max(1, min(w["frames"], budget_s / max(t1, 1e-3))))
-    tF = one(F) if F > 1 else t1
+    t1 = one(1)                                   # warm-up (1 warm-up + >= 3 timed)
+    F = int(max(1, min(w["frames"], budget_s / 3.0 / max(t1, 1e-3))))
+    ts = sorted(one(F) for _ in range(3))
+    tF = ts[1]                                    # median of 3
     est_full = tF * w["frames"] / F
     return dict(value=1.0 / est_full, unit="steps/s", cores=ncores, kind="port",
-                sample=f"1 CFG-batched UNet forward (B=2, 32x32 latent, fp32) at F={F} of {w['frames']} frames in "
-                       f"{tF:.1f}s, scaled linearly in F to the full step")
+                sample=f"CFG-batched UNet forward (B=2, 32x32 latent, fp32) at F={F} of {w['frames']} frames: 1 warm-up + 3 timed "
+                       f"({ts[0]:.1f} / {ts[1]:.1f} / {ts[2]:.1f} s, median used), scaled linearly in F to the full step")
 
 
 def main():
@@ -165,10 +191,8 @@ def main():
         sd_cpu = {k: v.cpu() for k, v in sd.items()}
     del sd
     model.eval()
-    # The units of this path are independent samples ("shards naturally on batch x CFG"): N GPUs denoise N samples,
-    # one CFG-batched sample per GPU, with no data-path collective -> `value` is whole-job steps/s, "scaling": "weak".
-    # The north star's partition of ONE sample (batch x frame shards, GroupNorm statistics all-reduce + K|V all-gather per
-    # temporal block) is measured after it in the same run and reported as `frame_sharded` (strong scaling of the latency).
+    # N > 1: first N independent samples (one per GPU, no collective: `weak_scaling`), then the headline: ONE step partitioned
+    # over all GPUs (batch x CFG groups, then frame shards with GroupNorm-statistics all-reduces + K|V all-gathers).
     model.use_graph = not args.no_graph
 
     x_T, x0_emb, c, uc = build_inputs(device)
@@ -210,20 +234,18 @@ def main():
         return dt / args.steps * 1e3
 
     ms_per_step = timed_steps()
+    graph_live = bool(model._engine is not None and model._engine._graphs and not getattr(model._engine, "_graph_broken", False))
 
-    # ---- N > 1 extra: ONE sample partitioned over all GPUs (the north star's batch x frame sharding)
-    sharded = None
+    # ---- N > 1: the headline is ONE step partitioned over all GPUs (the north star's batch x frame sharding)
+    weak, parallelism = None, "single"
     if world > 1:
-        try:
-            from seervideoldm_amd import parallel
-            shard = parallel.attach(model, world, rank)
-            ms_sh = timed_steps()
-            sharded = {"ms_per_step": round(ms_sh, 3), "steps_per_s": round(1e3 / ms_sh, 3), "parallelism": shard.describe(),
-                       "scaling": "strong", "speedup_vs_one_gpu_step": round(ms_per_step / ms_sh, 3),
-                       "what": "the same single sample (CFG batch 2 x 12 frames) on all GPUs: CFG halves x frame shards, 77 GroupNorm "
-                               "statistics all-reduces + 16 K|V all-gathers per step between hipGraph segments"}
-        except Exception as e:      # noqa: BLE001  (an extra must never cost the headline line)
-            sharded = {"error": f"{type(e).__name__}: {e}"[:300]}
+        from seervideoldm_amd import parallel
+        weak = {"value": round(world * 1e3 / ms_per_step, 3), "unit": "steps/s", "ms_per_step": round(ms_per_step, 3),
+                "scaling": "weak", "what": f"{world} independent samples, one CFG-batched sample per GPU, no data-path collective"}
+        shard = parallel.attach(model, world, rank)
+        ms_per_step = timed_steps()
+        parallelism = f"{shard.describe()} over {world} RCCL ranks"
+        graph_live = bool(model._engine._graphs and not getattr(model._engine, "_graph_broken", False))
         model._shard = None
         model._engine = None
 
@@ -250,14 +272,21 @@ def main():
         avg_launch_ms = gm["ms"] / gm["launches"]
         # HBM-side bytes per launch from the separate rocprofv3 --pmc passes of the same step (scripts/pmc_step.py ->
         # scripts/pmc_summary.py; PMC cannot be collected from inside this process)
-        traffic = None
+        # (scripts/pmc_step.py -> scripts/pmc_summary.py; PMC cannot be collected from inside this process).  The file carries
+        # the digest of the library build it was taken on: a stale file is refused, not quoted.
+        traffic, traffic_note = None, None
         try:
             if args.workload != "sthv2":
                 raise OSError("the PMC passes were taken on the default workload")
-            pmc = json.load(open(ROOT / "profiles" / "r01_pmc_traffic.json"))
+            pmc = json.load(open(ROOT / "profiles" / PMC_TRAFFIC_FILE))
+            built = (ROOT / "seervideoldm_amd" / "lib" / "build.sha256").read_text().strip()
+            if pmc.get("build_sha256") != built:
+                raise ValueError(f"{PMC_TRAFFIC_FILE} was taken on library build {str(pmc.get('build_sha256'))[:12]}, this is "
+                                 f"{built[:12]}")
             traffic = round(pmc["kernels"]["seer_gemm_kernel"]["hbm_bytes_per_launch"])
-        except (OSError, KeyError, ValueError):
-            pass
+        except (OSError, KeyError, ValueError) as e:
+            traffic_note = str(e)[:200]
+        attn_block = time_attention_block(device)
         roofline = dict(bound="mfma", kernel="seer_gemm_kernel (bf16 MFMA GEMM / implicit-GEMM conv3x3, all tiles)",
                         achieved=round(gm["tflops"], 2), peak=MFMA_BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=round(gm["tflops"] / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), traffic=traffic,
@@ -266,7 +295,10 @@ def main():
                         launches_per_step=gm["launches"] // reps, avg_launch_us=round(avg_launch_ms * 1e3, 2),
                         algorithmic_gflop_per_launch=round(per_launch_flops / 1e9, 3),
                         step_breakdown_ms={k: round(v["ms"] / reps, 3) for k, v in summ.items()},
-                        attention_tflops=round(summ.get("attention", {}).get("tflops", 0.0), 2))
+                        attention_tflops=round(summ.get("attention", {}).get("tflops", 0.0), 2),
+                        spatial_attention_block=attn_block)
+        if traffic_note:
+            roofline["traffic_note"] = traffic_note
 
     # ---- end-to-end clip latency: 50 DDIM steps + frozen VAE decode of the 10 predicted frames
     clip = None
@@ -352,21 +384,20 @@ def main():
         cpu = cpu_baseline(sd_cpu, cfg, args.cpu_budget_s)
 
     if rank == 0:
-        par = "single" if world == 1 else f"{world} independent samples, one per GPU (no data-path collective)"
         line = {
             "metric": "UNet denoising steps/sec (12-frame 256^2 latent, 50-step DDIM)" if args.workload == "sthv2"
                       else f"UNet denoising steps/sec ({args.workload} workload, 50-step DDIM)",
-            "value": round(world * 1e3 / ms_per_step, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "value": round(1e3 / ms_per_step, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload]["name"] + ", "
                                    "full-width SeerUNet 1.08G params, 50-step DDIM, scale 7.5",
-                       "global_batch": world * WORKLOADS[args.workload]["b"], "parallelism": par,
-                       "hip_graph": bool(not args.no_graph)},
+                       "global_batch": WORKLOADS[args.workload]["b"], "parallelism": parallelism,
+                       "hip_graph": graph_live},
             "roofline": roofline, "cpu_baseline": cpu, "end_to_end": clip, "train_step": train,
         }
-        if sharded is not None:
-            line["frame_sharded"] = sharded
+        if weak is not None:
+            line["weak_scaling"] = weak
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist

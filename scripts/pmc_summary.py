@@ -1,7 +1,7 @@
 """Per-launch HBM traffic of the GEMM template from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of scripts/pmc_step.py.
 
     python scripts/pmc_summary.py gpurun_out/pmc_step_fetch/*/*_counter_collection.csv \
-                                  gpurun_out/pmc_step_write/*/*_counter_collection.csv  > profiles/r01_pmc_traffic.json
+                                  gpurun_out/pmc_step_write/*/*_counter_collection.csv  > profiles/r02_pmc_traffic.json
 
 Units and the gfx950 correction follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are in KiB;
 FETCH_SIZE reports exactly half of the bytes of a wide (16 B/lane) coalesced read stream on gfx950 -> doubled; WRITE_SIZE is
@@ -19,7 +19,8 @@ def per_kernel(path, counter):
         if r["Counter_Name"] != counter:
             continue
         name = r["Kernel_Name"]
-        fam = "seer_gemm_kernel" if "seer_gemm_kernel" in name else ("seer_attn_kernel" if "seer_attn_kernel" in name else None)
+        fam = "seer_gemm_kernel" if "seer_gemm_kernel" in name else (
+            "seer_attn40_kernel" if "seer_attn40_kernel" in name else ("seer_attn_kernel" if "seer_attn_kernel" in name else None))
         if fam is None:
             for k in ("gn_stats", "gn_apply", "gn_finalize", "layernorm", "splitk_reduce"):
                 if k in name:
@@ -33,7 +34,10 @@ def per_kernel(path, counter):
 def main():
     fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
-    out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over scripts/pmc_step.py "
+    from pathlib import Path
+    sha = (Path(__file__).resolve().parents[1] / "seervideoldm_amd" / "lib" / "build.sha256").read_text().strip()
+    out = {"build_sha256": sha,      # bench.py refuses the file when the library has been rebuilt since
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over scripts/pmc_step.py "
                      "(2 eager full-size denoising steps, config 2)",
            "correction": "HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request)",
            "kernels": {}}

@@ -45,6 +45,17 @@ class FrameShard:
         self.G = self.P = None
         self.total_frames = self.frame_offset = self.local_frames = 0
         self.debug_boundaries = False   # tests: hit every sync point (with a no-op exchange) even when P == 1
+        # RCCL collectives can be captured into the step's hipGraph (scripts/exp_nccl_capture.py: capture + replay of
+        # all_reduce / all_gather_into_tensor verified on torch 2.10 + RCCL 2.26): the whole sharded step then replays as
+        # ONE graph instead of ~94 segments with an eager exchange and a host round trip between each pair.  gloo (CPU tests,
+        # several ranks on one device) cannot be captured and keeps the segmented replay.
+        self.capture_collectives = False
+        try:
+            import os
+            if dist.is_available() and dist.is_initialized() and os.environ.get("SEER_CAPTURE_COLLECTIVES", "1") != "0":
+                self.capture_collectives = dist.get_backend() == "nccl"
+        except Exception:       # noqa: BLE001  (no default group yet: decided again in plan())
+            pass
 
     # ---- geometry --------------------------------------------------------------------------------------------
     def plan(self, B: int, F: int):
@@ -74,7 +85,11 @@ class FrameShard:
         return self._pgs[key][self.g]
 
     def describe(self) -> str:
-        return f"batch_groups{self.G}xframe_shards{self.P}" if self.G else "unplanned"
+        if not self.G:
+            return "unplanned"
+        how = "" if self.P == 1 else (", collectives captured in the step graph" if self.capture_collectives
+                                      else ", eager collectives between graph segments")
+        return f"batch_groups{self.G}xframe_shards{self.P}{how}"
 
     # ---- hooks used by unet._Engine ----------------------------------------------------------------------------
     def reduce_gn_stats(self, stats: torch.Tensor, count_local: float, sync=None) -> float:

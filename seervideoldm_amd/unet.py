@@ -474,12 +474,13 @@ class _Engine:
         return self._run_graph(sample, t, ctx, L, cond_frame)
 
     def sync_point(self, fn):
-        """run `fn` -- an EAGER cross-rank exchange (RCCL all-reduce / all-gather on static buffers) -- at this point of the
-        schedule.  Under segmented capture it ends the current hipGraph segment, records `fn` as a replay step and opens
-        the next segment, so the collectives never have to be captured themselves."""
+        """run `fn` -- a cross-rank exchange (all-reduce / all-gather on static buffers) -- at this point of the schedule.
+        RCCL collectives are captured into the step's graph with everything else.  Backends that cannot be captured (gloo)
+        get a segmented capture: the current hipGraph segment ends, `fn` is recorded as an eager replay step and the next
+        segment opens."""
         rec = self._rec
-        if rec is None:
-            fn()
+        if rec is None or (self.shard is not None and self.shard.capture_collectives):
+            fn()            # eager step, or an RCCL collective recorded into the graph being captured
             return
         rec.end_segment()
         fn()
