@@ -120,6 +120,11 @@ typedef struct seer_gemm_desc {
 #define SEER_TILE_G96x160_2 16
 #define SEER_TILE_G96x160_3 17
 #define SEER_TILE_G96x128_2 18
+/* weight-stationary persistent kernel (gemm_ws.hip): one column panel of W resident in LDS per CU, A streamed through a ring;
+ * AUTO picks it for plain GEMMs with K <= 768 and M >= 1024, this value asks for it (falls back to AUTO when not eligible) */
+#define SEER_TILE_G256x256_2 21 /* 8 waves, 64x128 wave tiles, 2 x 64 KB stages: the only tile whose FLOPs per LDS-fill byte (128) reach the MFMA roof */
+#define SEER_TILE_WS 19
+#define SEER_TILE_AUTO_TILED 20   /* AUTO restricted to the tile kernel (A/B runs against the weight-stationary kernel) */
 
 int seer_gemm_bf16(const seer_gemm_desc* desc /* host */, void* stream);
 /* bytes of workspace the call would use for split-K with this descriptor (0: it will not split) */

@@ -1,0 +1,133 @@
+// Stand-alone timing harness for seer_gemm_bf16 on the GEMM / conv shapes of ONE config-2 denoising step (SURVEY Appendix C:
+// CFG batch 2 x 12 frames x 32^2), with the number of calls per step, through the C ABI only (no Python: starts in seconds).
+//   build: scripts/build_labs.sh lab_gemm     run: build/lab_gemm [iters] [tile-override...]
+// Prints per shape: us per call (back-to-back launches between two HIP events), TFLOP/s, ms per step = us * calls, and the
+// step total -- the quantity a kernel change has to move.  LAB_ONLY=<substring> restricts the shape list.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "seer_hip.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(2); } } while (0)
+
+struct Shape {
+    const char* name;
+    int calls;            // per denoising step
+    int conv;             // 0: plain GEMM, 1: conv3x3
+    int M, N, K;          // plain: as is; conv: n_img = M, H = N (square), Cin = K, with Cout, stride, up below
+    int geglu, res, bias;
+    int Cout, stride, up;
+    int K2;               // plain: second source columns (skip concat), 0 = none
+};
+
+static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
+
+int main(int argc, char** argv) {
+    const int iters = argc > 1 ? atoi(argv[1]) : 20;
+    const int tile_override = argc > 2 ? atoi(argv[2]) : 0;
+    const char* only = getenv("LAB_ONLY");
+    const Shape shapes[] = {
+        // transformer blocks (16 text + 16 temporal per step; the temporal feed-forward runs on 10 of 12 frames per sample)
+        {"ff1 geglu L0", 10, 0, 24576, 2560, 320, 1, 0, 1}, {"ff1 geglu L1", 10, 0, 6144, 5120, 640, 1, 0, 1},
+        {"ff1 geglu L2", 10, 0, 1536, 10240, 1280, 1, 0, 1}, {"ff1 geglu mid", 2, 0, 384, 10240, 1280, 1, 0, 1},
+        {"ff2 +res L0", 10, 0, 24576, 320, 1280, 0, 1, 1}, {"ff2 +res L1", 10, 0, 6144, 640, 2560, 0, 1, 1},
+        {"ff2 +res L2", 10, 0, 1536, 1280, 5120, 0, 1, 1}, {"ff2 +res mid", 2, 0, 384, 1280, 5120, 0, 1, 1},
+        {"qkv L0", 10, 0, 24576, 960, 320, 0, 0, 0}, {"qkv L1", 10, 0, 6144, 1920, 640, 0, 0, 0},
+        {"qkv L2", 10, 0, 1536, 3840, 1280, 0, 0, 0}, {"qkv mid", 2, 0, 384, 3840, 1280, 0, 0, 0},
+        {"proj/to_out +res L0", 25, 0, 24576, 320, 320, 0, 1, 1}, {"proj_in/q L0", 15, 0, 24576, 320, 320, 0, 0, 1},
+        {"proj/to_out +res L1", 25, 0, 6144, 640, 640, 0, 1, 1}, {"proj_in/q L1", 15, 0, 6144, 640, 640, 0, 0, 1},
+        {"proj/to_out +res L2", 25, 0, 1536, 1280, 1280, 0, 1, 1}, {"proj_in/q L2", 15, 0, 1536, 1280, 1280, 0, 0, 1},
+        {"proj/to_out +res mid", 5, 0, 384, 1280, 1280, 0, 1, 1}, {"proj_in/q mid", 3, 0, 384, 1280, 1280, 0, 0, 1},
+        // 1x1 shortcut convs over the skip concat (two sources)
+        {"shortcut L0 640->320", 2, 0, 24576, 320, 320, 0, 0, 1, 0, 0, 0, 320}, {"shortcut L0 960->320", 1, 0, 24576, 320, 640, 0, 0, 1, 0, 0, 0, 320},
+        {"shortcut L1 1280->640", 1, 0, 6144, 640, 640, 0, 0, 1, 0, 0, 0, 640}, {"shortcut L1 1920->640", 1, 0, 6144, 640, 1280, 0, 0, 1, 0, 0, 0, 640},
+        {"shortcut L1 960->640", 1, 0, 6144, 640, 640, 0, 0, 1, 0, 0, 0, 320}, {"shortcut L2 2560->1280", 2, 0, 1536, 1280, 1280, 0, 0, 1, 0, 0, 0, 1280},
+        {"shortcut L2 1920->1280", 1, 0, 1536, 1280, 1280, 0, 0, 1, 0, 0, 0, 640}, {"shortcut L3 2560->1280", 3, 0, 384, 1280, 1280, 0, 0, 1, 0, 0, 0, 1280},
+        // 3x3 convs (24 images per level)
+        {"conv 32x32 320->320", 7, 1, 24, 32, 320, 0, 1, 1, 320, 1, 0}, {"conv 16x16 640->640", 6, 1, 24, 16, 640, 0, 1, 1, 640, 1, 0},
+        {"conv 8x8 1280->1280", 6, 1, 24, 8, 1280, 0, 1, 1, 1280, 1, 0}, {"conv 4x4 1280->1280", 11, 1, 24, 4, 1280, 0, 1, 1, 1280, 1, 0},
+        {"conv 8x8 2560->1280", 2, 1, 24, 8, 2560, 0, 0, 1, 1280, 1, 0}, {"conv 4x4 2560->1280", 3, 1, 24, 4, 2560, 0, 0, 1, 1280, 1, 0},
+        {"conv 16x16 1920->640", 1, 1, 24, 16, 1920, 0, 0, 1, 640, 1, 0}, {"conv 16x16 1280->640", 1, 1, 24, 16, 1280, 0, 0, 1, 640, 1, 0},
+        {"conv 16x16 960->640", 1, 1, 24, 16, 960, 0, 0, 1, 640, 1, 0}, {"conv 8x8 1920->1280", 1, 1, 24, 8, 1920, 0, 0, 1, 1280, 1, 0},
+        {"conv 32x32 960->320", 1, 1, 24, 32, 960, 0, 0, 1, 320, 1, 0}, {"conv 32x32 640->320", 2, 1, 24, 32, 640, 0, 0, 1, 320, 1, 0},
+        {"conv 16x16 320->640", 1, 1, 24, 16, 320, 0, 0, 1, 640, 1, 0}, {"conv 8x8 640->1280", 1, 1, 24, 8, 640, 0, 0, 1, 1280, 1, 0},
+        {"conv up 16->32 640->640", 1, 1, 24, 16, 640, 0, 0, 1, 640, 1, 1}, {"conv up 8->16 1280->1280", 1, 1, 24, 8, 1280, 0, 0, 1, 1280, 1, 1},
+        {"conv up 4->8 1280->1280", 1, 1, 24, 4, 1280, 0, 0, 1, 1280, 1, 1},
+        {"conv s2 32x32 320->320", 1, 1, 24, 32, 320, 0, 0, 1, 320, 2, 0}, {"conv s2 16x16 640->640", 1, 1, 24, 16, 640, 0, 0, 1, 640, 2, 0},
+        {"conv s2 8x8 1280->1280", 1, 1, 24, 8, 1280, 0, 0, 1, 1280, 2, 0},
+    };
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    // one pool of random bf16 / fp32 data, big enough for every operand
+    const size_t pool_elems = (size_t)96 << 20;
+    std::vector<uint16_t> h(pool_elems);
+    uint32_t r = 7u;
+    for (size_t i = 0; i < pool_elems; ++i) { r = r * 1664525u + 1013904223u; h[i] = f2bf(((float)(r >> 8) / 8388608.0f - 1.0f) * 0.5f); }
+    uint16_t *dA, *dW, *dC, *dR; float *dB; void* dWs;
+    CK(hipMalloc(&dA, pool_elems * 2)); CK(hipMalloc(&dW, pool_elems * 2)); CK(hipMalloc(&dC, pool_elems * 2)); CK(hipMalloc(&dR, pool_elems * 2));
+    CK(hipMalloc(&dB, 65536 * 4)); CK(hipMalloc(&dWs, (size_t)512 << 20));
+    CK(hipMemcpy(dA, h.data(), pool_elems * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dW, h.data() + 12345, (pool_elems - 12345) * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dR, h.data() + 777, (pool_elems - 777) * 2, hipMemcpyHostToDevice)); CK(hipMemset(dB, 0, 65536 * 4));
+    printf("seer ABI %d, iters %d, tile override %d\n%-28s %5s %9s %8s %9s\n", seer_abi_version(), iters, tile_override, "shape", "calls", "us/call", "TF/s", "ms/step");
+    double total_ms = 0, total_flops = 0;
+    for (const Shape& s : shapes) {
+        if (only && !strstr(s.name, only)) continue;
+        seer_gemm_desc d;
+        memset(&d, 0, sizeof d);
+        double flops;
+        d.A = dA; d.W = dW; d.C = dC; d.batch = 1; d.tile = tile_override;
+        if (s.bias) d.bias = dB;
+        if (s.conv) {
+            const int Hs = s.up ? 2 * s.N : s.N, Ho = (Hs + 2 - 3) / s.stride + 1;
+            d.mode = SEER_GEMM_CONV3X3; d.M = s.M * Ho * Ho; d.N = s.Cout; d.K = 9 * s.K; d.K1 = d.K;
+            d.Hin = d.Win = s.N; d.Cin = s.K; d.Hout = d.Wout = Ho; d.stride = s.stride; d.upsample = s.up; d.ldc = s.Cout;
+            flops = 2.0 * d.M * d.N * d.K;
+        } else {
+            d.mode = SEER_GEMM_PLAIN; d.M = s.M; d.N = s.N; d.K = s.K + s.K2; d.K1 = s.K; d.lda = s.K; d.ldc = s.geglu ? s.N / 2 : s.N;
+            if (s.K2) { d.A2 = dR; d.lda2 = s.K2; }
+            if (s.geglu) d.epilogue |= SEER_EPI_GEGLU;
+            flops = 2.0 * d.M * d.N * d.K;
+        }
+        if (s.res) { d.residual = dR; d.ldr = d.ldc; }
+        int64_t ws = seer_gemm_workspace_bytes(&d);
+        if (ws < 0) { printf("%-28s workspace query failed: %s\n", s.name, seer_strerror((int)ws)); continue; }
+        if (ws > 0) { d.workspace = dWs; d.workspace_bytes = ws; }
+        const bool stamps = getenv("LAB_STAMPS") != nullptr;
+        if (stamps) { d.workspace = dWs; d.workspace_bytes = 777; CK(hipMemset(dWs, 0, 1 << 22)); }
+        int rc = 0;
+        for (int i = 0; i < 3 && rc == 0; ++i) rc = seer_gemm_bf16(&d, st);
+        if (rc != 0) { printf("%-28s rc %d (%s)\n", s.name, rc, seer_strerror(rc)); continue; }
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < iters; ++i) seer_gemm_bf16(&d, st);
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1e3 / iters;
+        printf("%-28s %5d %9.1f %8.0f %9.3f%s\n", s.name, s.calls, us, flops / us * 1e-6, us * s.calls * 1e-3, ws > 0 ? "  (split-K)" : "");
+        if (stamps) {
+            std::vector<long long> hs((1 << 22) / 8);
+            CK(hipMemcpy(hs.data(), dWs, 1 << 22, hipMemcpyDeviceToHost));
+            for (int b : {0, 9}) for (int w : {0, 1, 2, 3, 4, 5, 6, 7}) {
+                const long long* t = hs.data() + ((size_t)b * 8 + w) * 64;
+                printf("  block %d wave %d hw_id %llx (10 ns ticks since start):", b, w, (unsigned long long)t[63]);
+                for (int i = 1; i < 63 && t[i]; ++i) printf(" %lld", t[i] - t[0]);
+                printf("\n");
+            }
+        }
+        total_ms += us * s.calls * 1e-3;
+        total_flops += flops * s.calls;
+        fflush(stdout);
+    }
+    printf("%-28s %5s %9s %8.0f %9.3f   (%.2f TFLOP per step; %.3f of 2.5 PF)\n", "TOTAL", "", "", total_flops / total_ms * 1e-9, total_ms,
+           total_flops * 1e-12, total_flops / total_ms * 1e-9 / 2500.0);
+    return 0;
+}

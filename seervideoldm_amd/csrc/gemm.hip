@@ -15,6 +15,10 @@
 #include "seer_common.h"
 #include <mutex>
 
+bool seer_gemm_ws_eligible(const seer_gemm_desc& d);             // gemm_ws.hip: weight-stationary persistent kernel (short K)
+bool seer_gemm_ws_profitable(const seer_gemm_desc& d);
+int seer_gemm_ws_launch(const seer_gemm_desc& d, hipStream_t st);
+
 namespace {
 
 constexpr int BK = 64;
@@ -34,12 +38,15 @@ __device__ __attribute__((aligned(16))) unsigned int seer_zero_page[4] = {0u, 0u
 // NS == 0: register-staged double buffer (global_load -> VGPR -> ds_write), one barrier per K tile.
 // NS >= 2: NS-stage ring filled by global_load_lds (16 B per lane straight into LDS, no VGPR / ds_write), NS-1 tiles in
 //          flight across raw s_barriers behind counted s_waitcnt vmcnt(N).  Same LDS image either way.
-// WM: waves along M (the wave grid is WM x 2): 2 -> 256 threads, 4 -> 512 threads (256-row tiles, same 64x64 wave tile).
-template <int BM, int BN, bool CONV, bool GEGLU, bool SPLIT, int NS, int WM = 2>
-__global__ void __launch_bounds__(128 * WM) seer_gemm_kernel(const seer_gemm_desc p) {
-    constexpr int NT = 128 * WM;                   // threads per block
+// WM x WN: the wave grid.  WN = 2: WM = 2 -> 256 threads, 4 -> 512 threads (256-row tiles, same 64x64 wave tile).
+// WM = 2, WN = 4 with a 256 x 256 tile is the 8-phase ping-pong kernel (PP8 below): 128 x 64 wave tiles, its own main loop.
+template <int BM, int BN, bool CONV, bool GEGLU, bool SPLIT, int NS, int WM = 2, int WN = 2>
+__global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm_desc p) {
+    constexpr int NT = 64 * WM * WN;               // threads per block
     constexpr int RPP = NT / 8;                    // tile rows staged per pass (8 lanes x 16 B cover one 128-B row)
-    constexpr int WTM = BM / WM, WTN = BN / 2;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr bool PP8 = WM == 2 && WN == 4 && BM == 256 && BN == 256;
+    static_assert(WN == 2 || PP8, "wave grids other than WM x 2 exist only as the 256 x 256 ping-pong kernel");
     constexpr int TM = WTM / 16, TN = WTN / 16;
     constexpr int A_CH = BM / RPP, B_CH = BN / RPP;  // 16-byte chunks per thread per K tile
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the rows staged per pass");
@@ -52,7 +59,7 @@ __global__ void __launch_bounds__(128 * WM) seer_gemm_kernel(const seer_gemm_des
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
 
     // ---- block -> tile mapping: XCD-contiguous chunks (blocks b and b+8 share an XCD), grouped along M
     const int tiles_m = (p.M + BM - 1) / BM;
@@ -87,9 +94,16 @@ __global__ void __launch_bounds__(128 * WM) seer_gemm_kernel(const seer_gemm_des
     int64_t a_off[A_CH];              // plain: row offset into A ; conv: image base offset
     int64_t a_off2[A_CH];
     int a_oy[A_CH], a_ox[A_CH];
+    // PP8 stages half tiles: chunk c = 2 * half + i is one 8-row group of "half" (the rows of quadrant-row `half` of both wave
+    // rows: tile rows wm * 128 + half * 64 + [0, 64); 16 of them per wave), see the main loop
+    auto a_tile_row = [&](int c) { return PP8 ? (wave >> 2) * 128 + (c >> 1) * 64 + 16 * (wave & 3) + 8 * (c & 1) + (lane >> 3) : srow + RPP * c; };
+    auto b_tile_row = [&](int c) {
+        const int hn = 16 * wave + 8 * (c & 1) + (lane >> 3);
+        return PP8 ? (hn >> 5) * 64 + (c >> 1) * 32 + (hn & 31) : srow + RPP * c;
+    };
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
-        int gm = m0 + srow + RPP * i;
+        int gm = m0 + a_tile_row(i);
         gm = gm < p.M ? gm : p.M - 1;
         if constexpr (CONV) {
             const int hw = p.Hout * p.Wout;
@@ -110,7 +124,7 @@ __global__ void __launch_bounds__(128 * WM) seer_gemm_kernel(const seer_gemm_des
     int64_t b_off[B_CH];
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
-        int gn = n0 + srow + RPP * i;
+        int gn = n0 + b_tile_row(i);
         gn = gn < p.N ? gn : p.N - 1;
         b_off[i] = (int64_t)gn * p.K;
     }
@@ -170,8 +184,9 @@ __global__ void __launch_bounds__(128 * WM) seer_gemm_kernel(const seer_gemm_des
     // ---- residual tile prefetch: the epilogue's bf16 residual (8 B per accumulator quad) is requested before the K loop so
     // its HBM/L2 latency hides under the main loop instead of adding a dependent round trip to every block's tail
     const bf16* R = reinterpret_cast<const bf16*>(p.residual);
-    u32x2 rpre[TM][TN];
-    if constexpr (!GEGLU && !SPLIT) {
+    constexpr bool RES_PRE = !GEGLU && !SPLIT && TM * TN <= 16;     // the 256x256 tile has no registers to spare for it
+    u32x2 rpre[RES_PRE ? TM : 1][RES_PRE ? TN : 1];
+    if constexpr (RES_PRE) {
         if (R) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -188,7 +203,7 @@ __global__ void __launch_bounds__(128 * WM) seer_gemm_kernel(const seer_gemm_des
 
     // bias prefetch, same reason (a dependent L2 round trip at the head of every block's epilogue otherwise); the 160-wide
     // tiles have no registers to spare for it
-    constexpr bool BIAS_PRE = !SPLIT && TN <= 4;
+    constexpr bool BIAS_PRE = !SPLIT && TN <= 4 && !PP8;
     f32x4 bpre[TN];
     if constexpr (BIAS_PRE) {
         if (p.bias) {
@@ -202,7 +217,7 @@ __global__ void __launch_bounds__(128 * WM) seer_gemm_kernel(const seer_gemm_des
 
     // per-batch row vector (time embedding): one row serves the whole tile whenever the tile does not straddle two batch
     // elements -> prefetch it as well
-    constexpr bool RV_PRE = !SPLIT && !GEGLU && TN <= 4;
+    constexpr bool RV_PRE = !SPLIT && !GEGLU && TN <= 4 && !PP8;
     f32x4 rvpre[TN];
     bool rv_pre_ok = false;
     if constexpr (RV_PRE) {
@@ -250,7 +265,146 @@ __global__ void __launch_bounds__(128 * WM) seer_gemm_kernel(const seer_gemm_des
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
     };
 
-    if constexpr (NS == 0) {
+    if constexpr (PP8) {
+        // ---- 256 x 256 x 64 tile, 8 waves as 2 (M) x 4 (N), 128 x 64 wave tiles: the 8-phase ping-pong loop of the CDNA guide's
+        // "256^2 8-phase template" (cdna_hip_programming.md), built from its description.  Why: a 128 x 128 tile needs 1 byte of
+        // LDS fill per 64 FLOP and the fill path gives a CU ~50-70 GB/s (profiles/r02_lab_fill.log) -> at most ~1.1 PF; 256 x 256
+        // halves the bytes per FLOP, but a block-wide "all read, all multiply" loop leaves LDS and matrix pipe idle in turn
+        // (0.5-0.8 PF, profiles/r02_lab_gemm_t256.log).  Here:
+        //   * a K tile is four 16 KB HALF tiles  h0 = A rows of quadrant-row 0, h1 = W columns of quadrant-column 1,
+        //     h2 = A rows of quadrant-row 1, h3 = W columns of quadrant-column 0  (quadrant-row r of the block = rows
+        //     wm * 128 + r * 64 + [0, 64) of both wave rows; quadrant-column c = columns wn * 64 + c * 32 + [0, 32));
+        //   * a K tile is four PHASES, one 64 x 32 quadrant of the wave tile each (16 MFMAs over K = 64):
+        //       q0 = (r0, c0) reads h0, h3 | q1 = (r0, c1) reads h1 | q2 = (r1, c1) reads h2 | q3 = (r1, c0) reads h3
+        //     so every half tile has its LAST read one phase before the phase that restages it (tile u + 2 into the same buffer):
+        //       q1 stages h0, q2 stages h1, q3 stages h2, q0 of the next tile stages h3  -> 3-4 half tiles always in flight;
+        //   * every phase is  [fragment reads + 2 LDS-DMA + lgkmcnt(0)]  s_barrier  [16 MFMAs]  s_barrier,  and wave row 1 runs
+        //     ONE BARRIER behind wave row 0: while one wave of a SIMD multiplies, the other reads and stages;
+        //   * one counted wait per K tile (q3): vmcnt(6) leaves the three youngest half tiles in flight, never 0 in the loop.
+        // Ordering (guide, "Read a staged buffer one phase AFTER the wait that retires it"): the q3 wait sits before q3's first
+        // barrier and the first read of the tile it retires is in q0; fragment reads are retired (lgkmcnt(0)) BEFORE the phase's
+        // first barrier, which is what makes restaging one phase later safe with the two wave rows a barrier apart.
+        static_assert(NS == 2 && A_CH == 4 && B_CH == 4, "two 64 KB buffers of four half tiles");
+        constexpr int HALF = 128 * BK;                               // elements per half tile
+        const int T = nk - kt0;
+        const int schunk = ((tid & 7) ^ ((tid >> 3) & 7)) * 8;
+        // LDS: [buffer][h0 = A r0 | h2 = A r1 | h3 = W c0 | h1 = W c1], 16 KB each
+        auto half_base = [&](int u, int h) { return smem_b + ((u & 1) * 4 + (h == 0 ? 0 : h == 2 ? 1 : h == 3 ? 2 : 3)) * HALF; };
+        auto stage_half = [&](int u, int h) {                         // this wave's 2 x 1 KB of half tile h of K tile u
+            if (u >= T) return;
+            const int kbase = (kt0 + u) * BK;
+            bf16* dst = half_base(u, h) + (16 * wave) * BK;
+            if (h == 0 || h == 2) {
+                const int c0 = h == 0 ? 0 : 2;
+                if constexpr (CONV) {
+                    const int tap = kbase / p.Cin;
+                    const int ci0 = kbase - tap * p.Cin;
+                    const int ky = tap / 3, kx = tap - ky * 3;
+                    const int Hs = p.upsample ? p.Hin * 2 : p.Hin;
+                    const int Ws = p.upsample ? p.Win * 2 : p.Win;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int iy = a_oy[c0 + i] + ky, ix = a_ox[c0 + i] + kx;
+                        const bool ok = (iy >= 0) & (iy < Hs) & (ix >= 0) & (ix < Ws);
+                        const int sy = p.upsample ? (iy >> 1) : iy;
+                        const int sx = p.upsample ? (ix >> 1) : ix;
+                        const bf16* src = ok ? (A + a_off[c0 + i] + ((int64_t)sy * p.Win + sx) * p.Cin + ci0 + schunk)
+                                             : reinterpret_cast<const bf16*>(seer_zero_page);
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                         (__attribute__((address_space(3))) void*)(dst + 8 * i * BK), 16, 0, 0);
+                    }
+                } else {
+                    const bool second = kbase >= p.K1;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const bf16* src = second ? (A2 + a_off2[c0 + i] + (kbase - p.K1) + schunk) : (A + a_off[c0 + i] + kbase + schunk);
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                         (__attribute__((address_space(3))) void*)(dst + 8 * i * BK), 16, 0, 0);
+                    }
+                }
+            } else {
+                const int c0 = h == 3 ? 0 : 2;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const bf16* src = W + b_off[c0 + i] + kbase + schunk;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(dst + 8 * i * BK), 16, 0, 0);
+                }
+            }
+        };
+        bf16x8 fa[2][4], fb[2][2];
+        auto read_a = [&](int u, int r) {                             // 64 rows of this wave x K 64: 8 ds_read_b128
+            const bf16* as = half_base(u, r == 0 ? 0 : 2) + (wm * 64) * BK;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int sw = (((ks * 4 + fq) ^ (frow & 7)) * 8);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8*>(as + (i * 16 + frow) * BK + sw);
+            }
+        };
+        auto read_b = [&](int u, int c) {                             // 32 columns of this wave x K 64: 4 ds_read_b128
+            const bf16* bs = half_base(u, c == 0 ? 3 : 1) + (wn * 32) * BK;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int sw = (((ks * 4 + fq) ^ (frow & 7)) * 8);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[ks][j] = *reinterpret_cast<const bf16x8*>(bs + (j * 16 + frow) * BK + sw);
+            }
+        };
+        auto barrier = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // the MFMA half of a phase: quadrant (r, c) of the wave tile, between the phase's two barriers
+#define SEER_PP8_MMA(R, C)                                                                                                   \
+        do {                                                                                                                 \
+            barrier();                                                                                                       \
+            __builtin_amdgcn_s_setprio(1);                                                                                   \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                 \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                \
+                    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
+                        acc[4 * (R) + i][2 * (C) + j] =                                                                      \
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[4 * (R) + i][2 * (C) + j], 0, 0, 0); \
+            __builtin_amdgcn_s_setprio(0);                                                                                   \
+            barrier();                                                                                                       \
+        } while (0)
+
+        // prologue: K tile 0 whole, K tile 1 up to h2 (its h3 goes out in q0 of tile 0)
+        stage_half(0, 0); stage_half(0, 1); stage_half(0, 2); stage_half(0, 3);
+        stage_half(1, 0); stage_half(1, 1); stage_half(1, 2);
+        if (T > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        barrier();
+        if (wm == 1) barrier();                                       // wave row 1 runs one barrier behind from here on
+        for (int u = 0; u < T; ++u) {
+            // q0
+            read_b(u, 0);
+            read_a(u, 0);
+            stage_half(u + 1, 3);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            SEER_PP8_MMA(0, 0);
+            // q1
+            read_b(u, 1);
+            stage_half(u + 2, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            SEER_PP8_MMA(0, 1);
+            // q2
+            read_a(u, 1);
+            stage_half(u + 2, 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            SEER_PP8_MMA(1, 1);
+            // q3: the wait that retires K tile u + 1 (all but the halves h0..h2 of tile u + 2 staged in q1..q3)
+            read_b(u, 0);
+            stage_half(u + 2, 2);
+            if (u + 2 < T) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            SEER_PP8_MMA(1, 0);
+        }
+#undef SEER_PP8_MMA
+        if (wm == 0) barrier();                                       // re-align the two wave rows
+    } else if constexpr (NS == 0) {
         load_tile(kt0);
         store_tile(0);
         __syncthreads();
@@ -329,6 +483,7 @@ __global__ void __launch_bounds__(128 * WM) seer_gemm_kernel(const seer_gemm_des
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
         };
+        {
 #pragma unroll
         for (int s_ = 0; s_ < NS; ++s_)
             if (kt0 + s_ < nk) issue_tile(kt0 + s_, s_);
@@ -364,6 +519,7 @@ __global__ void __launch_bounds__(128 * WM) seer_gemm_kernel(const seer_gemm_des
             }
 #endif
             stage = (stage + 1 == NS) ? 0 : stage + 1;
+        }
         }
 #else
 #pragma unroll
@@ -419,7 +575,11 @@ __global__ void __launch_bounds__(128 * WM) seer_gemm_kernel(const seer_gemm_des
     // segments per wave instruction, measured ~1.5 TB/s); staged through the (now idle) K-loop LDS the block stores 16 B per
     // lane along whole output rows instead.
     constexpr int BNO = GEGLU ? BN / 2 : BN;            // output columns of the block tile
-    constexpr int CPITCH = BNO * 2 + 16;               // staged row pitch in bytes (16-B aligned rows)
+    // staged row pitch in bytes: 16 B of padding spreads the 16 rows a wave instruction writes over the banks; when the padded
+    // tile does not fit (256 x 256 bf16 = the whole 128 KB ring) the rows are dense and the 16-byte chunk index is XORed with
+    // the row instead
+    constexpr bool CSWZ = BM * (BNO * 2 + 16) > 2 * STAGE * (int)sizeof(bf16);
+    constexpr int CPITCH = BNO * 2 + (CSWZ ? 0 : 16);
     static_assert(BM * CPITCH <= 2 * STAGE * (int)sizeof(bf16), "staged C tile must fit in the K-loop LDS");
     const bool staged = !out_f32 && !trans && (p.ldc % 8 == 0) && (p.N % (GEGLU ? 16 : 8) == 0) &&
                         ((reinterpret_cast<uintptr_t>(Cb) & 15) == 0);
@@ -491,7 +651,7 @@ __global__ void __launch_bounds__(128 * WM) seer_gemm_kernel(const seer_gemm_des
             }
             if (R) {
                 u32x2 rv;
-                if constexpr (!GEGLU) rv = rpre[i][j];
+                if constexpr (RES_PRE) rv = rpre[i][j];
                 else rv = *reinterpret_cast<const u32x2*>(R + (int64_t)m * p.ldr + nc);
                 v[0] += __builtin_bit_cast(float, rv[0] << 16);
                 v[1] += __builtin_bit_cast(float, rv[0] & 0xffff0000u);
@@ -513,7 +673,8 @@ __global__ void __launch_bounds__(128 * WM) seer_gemm_kernel(const seer_gemm_des
                 if (staged) {
                     const int row_l = wm * WTM + i * 16 + frow;
                     const int col_l = nc - (GEGLU ? (n0 >> 1) : n0);
-                    *reinterpret_cast<u32x2*>(smem + row_l * CPITCH + col_l * 2) = o;
+                    const int cb = col_l * 2;
+                    *reinterpret_cast<u32x2*>(smem + row_l * CPITCH + (CSWZ ? (cb ^ ((row_l & 15) << 4)) : cb)) = o;
                 } else {
                     *reinterpret_cast<u32x2*>(Cb + (int64_t)m * p.ldc + nc) = o;
                 }
@@ -531,7 +692,8 @@ __global__ void __launch_bounds__(128 * WM) seer_gemm_kernel(const seer_gemm_des
             const int row = c / CPR, ch = c - row * CPR;
             const int m = m0 + row, n = n0o + ch * 8;
             if (((BM * CPR) % NT == 0 || c < BM * CPR) && m < p.M && n < n_out)
-                *reinterpret_cast<u32x4*>(Cb + (int64_t)m * p.ldc + n) = *reinterpret_cast<const u32x4*>(smem + row * CPITCH + ch * 16);
+                *reinterpret_cast<u32x4*>(Cb + (int64_t)m * p.ldc + n) =
+                    *reinterpret_cast<const u32x4*>(smem + row * CPITCH + (CSWZ ? (ch ^ (row & 15)) : ch) * 16);
         }
     }
 }
@@ -586,7 +748,7 @@ __global__ void __launch_bounds__(256) seer_splitk_reduce_kernel(const seer_gemm
     }
 }
 
-template <int BM, int BN, int NS, int WM = 2>
+template <int BM, int BN, int NS, int WM = 2, int WN = 2>
 int launch_tile(const seer_gemm_desc& d, hipStream_t st) {
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, 1, d.batch > 1 ? d.batch : 1);
@@ -597,12 +759,12 @@ int launch_tile(const seer_gemm_desc& d, hipStream_t st) {
         // concurrent first calls from different host threads safe (the header promises thread safety)
         static std::once_flag once;
         std::call_once(once, [lds] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, true, false, false, NS, WM>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, true, false, false, NS, WM, WN>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if constexpr (GEGLU_OK)
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, false, true, false, NS, WM>),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, false, true, false, NS, WM, WN>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, false, false, false, NS, WM>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, false, false, false, NS, WM, WN>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         });
     }
@@ -610,14 +772,14 @@ int launch_tile(const seer_gemm_desc& d, hipStream_t st) {
     const bool geglu = (d.epilogue & SEER_EPI_GEGLU) != 0;
     if (conv && geglu) return SEER_EINVAL;
     if (conv) {
-        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, true, false, false, NS, WM>), grid, dim3(128 * WM), lds, st, d);
+        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, true, false, false, NS, WM, WN>), grid, dim3(64 * WM * WN), lds, st, d);
     } else if (geglu) {
         if constexpr (GEGLU_OK)
-            hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, true, false, NS, WM>), grid, dim3(128 * WM), lds, st, d);
+            hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, true, false, NS, WM, WN>), grid, dim3(64 * WM * WN), lds, st, d);
         else
             return SEER_EINVAL;
     } else {
-        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, false, false, NS, WM>), grid, dim3(128 * WM), lds, st, d);
+        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, false, false, NS, WM, WN>), grid, dim3(64 * WM * WN), lds, st, d);
     }
     SEER_LAUNCH_CHECK();
     return SEER_OK;
@@ -720,6 +882,7 @@ int prepare(seer_gemm_desc& d, int* splits) {
 extern "C" int64_t seer_gemm_workspace_bytes(const seer_gemm_desc* desc) {
     if (!desc) return SEER_EINVAL;
     seer_gemm_desc d = *desc;
+    if (d.tile == SEER_TILE_WS || d.tile == SEER_TILE_AUTO_TILED) d.tile = SEER_TILE_AUTO;
     int s = 1;
     const int rc = prepare(d, &s);
     if (rc != SEER_OK) return rc;
@@ -730,6 +893,8 @@ extern "C" int seer_gemm_bf16(const seer_gemm_desc* desc, void* stream) {
     if (!desc) return SEER_EINVAL;
     seer_gemm_desc d = *desc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int requested = d.tile;       // WS / AUTO_TILED are AUTO as far as tile and split-K selection go
+    if (requested == SEER_TILE_WS || requested == SEER_TILE_AUTO_TILED) d.tile = SEER_TILE_AUTO;
     int s = 1;
     const int rc = prepare(d, &s);
     if (rc != SEER_OK) return rc;
@@ -739,6 +904,11 @@ extern "C" int seer_gemm_bf16(const seer_gemm_desc* desc, void* stream) {
     }
     d.splits = 1;
     d.tile = desc->tile;            // prepare() may have picked a split tile; unsplit launches choose their own below
+    if (seer_gemm_ws_eligible(d) && (requested == SEER_TILE_WS || (requested == SEER_TILE_AUTO && seer_gemm_ws_profitable(d)))) {
+        const int rc_ws = seer_gemm_ws_launch(d, st);
+        if (rc_ws != SEER_ENOSYS) return rc_ws;
+    }
+    if (requested == SEER_TILE_WS || requested == SEER_TILE_AUTO_TILED) d.tile = SEER_TILE_AUTO;   // the tile kernel picks its own
 
     int tile = d.tile;
     if (tile == SEER_TILE_AUTO) {
@@ -779,6 +949,7 @@ extern "C" int seer_gemm_bf16(const seer_gemm_desc* desc, void* stream) {
         case SEER_TILE_G64x160_3: return launch_tile<64, 160, 3>(d, st);
         case SEER_TILE_G256x128_2: return launch_tile<256, 128, 2, 4>(d, st);
         case SEER_TILE_G256x64_3: return launch_tile<256, 64, 3, 4>(d, st);
+        case SEER_TILE_G256x256_2: return launch_tile<256, 256, 2, 2, 4>(d, st);
         case SEER_TILE_G96x160_2: return launch_tile<96, 160, 2>(d, st);
         case SEER_TILE_G96x160_3: return launch_tile<96, 160, 3>(d, st);
         case SEER_TILE_G96x128_2: return launch_tile<96, 128, 2>(d, st);

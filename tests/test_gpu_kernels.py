@@ -48,6 +48,7 @@ def _close(got, ref, rtol=2e-2, atol=2e-2, what=""):
     (384, 320, 320, 12), (6144, 640, 640, 12), (130, 68, 192, 12), (384, 320, 2560, 13), (1000, 640, 128, 13),   # 160-wide
     (512, 256, 1280, 14), (300, 132, 192, 14), (6144, 640, 640, 14), (1000, 64, 320, 15), (24576, 320, 320, 15),   # 8 waves
     (24576, 320, 1280, 16), (1000, 320, 320, 16), (130, 68, 192, 17), (12288, 640, 640, 18), (100, 64, 128, 18),       # 96-row tiles
+    (512, 512, 64, 21), (512, 256, 1280, 21), (300, 132, 192, 21), (6144, 640, 640, 21), (1536, 1280, 128, 21),        # 256x256 ping-pong
 ])
 def test_gemm_plain(device, M, N, K, tile):
     from seervideoldm_amd import ops
@@ -60,6 +61,49 @@ def test_gemm_plain(device, M, N, K, tile):
     _close(out, ref, what=f"gemm {M}x{N}x{K} tile{tile}")
     out32 = ops.gemm(a, w, out_f32=True, tile=tile)
     _close(out32, a.float() @ w.float().t(), rtol=2e-3, atol=2e-3, what="gemm f32 out")
+
+
+@pytest.mark.parametrize("M,N,K,geglu,res,a2k,tile", [
+    (24576, 2560, 320, True, False, 0, 0), (24576, 960, 320, False, False, 0, 0),                  # AUTO routes these to it
+    (6144, 5120, 640, True, False, 0, 19), (6144, 1920, 640, False, False, 0, 19), (24576, 320, 320, False, False, 0, 19),
+    (24576, 320, 640, False, False, 320, 19), (6144, 640, 640, False, False, 320, 19),            # skip concat (two sources)
+    (1000, 320, 320, False, False, 0, 19), (1283, 192, 640, False, False, 0, 19), (2049, 128, 320, True, False, 0, 19),   # row tails
+    (4096, 136, 320, False, False, 0, 19), (1536, 200, 640, False, False, 0, 19), (1100, 1000, 320, False, False, 0, 19),  # column tails
+    (6144, 640, 640, False, True, 0, 19), (1536, 200, 192, False, False, 0, 19),                    # not eligible: the tile kernel answers
+])
+def test_gemm_weight_stationary(device, M, N, K, geglu, res, a2k, tile):
+    """the weight-stationary persistent kernel (gemm_ws.hip) on the short-K projections of the step and on ragged shapes,
+    against fp32; tile 19 asks for it explicitly (shapes it does not take fall through to the tile kernel), 0 checks that AUTO
+    routes the wide K = 320 projections to it and gets the same bits"""
+    from seervideoldm_amd import ops
+    from seervideoldm_amd.weights import geglu_row_order
+    K1 = K - a2k
+    a = _rand((M, K1), device, 1).to(bf16)
+    a2 = _rand((M, a2k), device, 4).to(bf16) if a2k else None
+    w = (_rand((N, K), device, 2) * K ** -0.5).to(bf16)
+    bias = _rand((N,), device, 3)
+    n_out = N // 2 if geglu else N
+    r = _rand((M, n_out), device, 5).to(bf16) if res else None
+    out = ops.gemm(a, w, a2=a2, bias=bias, residual=r, geglu=geglu, tile=tile, col_scale=None if geglu else (0.5, min(64, N)))
+    ws = ops.gemm(a, w, a2=a2, bias=bias, residual=r, geglu=geglu, tile=19, col_scale=None if geglu else (0.5, min(64, N)))
+    tiled = ops.gemm(a, w, a2=a2, bias=bias, residual=r, geglu=geglu, tile=20, col_scale=None if geglu else (0.5, min(64, N)))
+    if tile == 0:
+        assert torch.equal(out, ws), "AUTO must route this shape to the weight-stationary kernel"
+    A = a.float() if a2 is None else torch.cat([a.float(), a2.float()], 1)
+    acc = A @ w.float().t() + bias
+    if geglu:
+        # device layout: rows interleaved in groups of 16 (16 value rows, then their 16 gate rows)
+        acc = acc.reshape(M, N // 32, 2, 16)
+        ref = (acc[:, :, 0] * Fn.gelu(acc[:, :, 1])).reshape(M, N // 2)
+    else:
+        ref = acc
+        ref[:, :min(64, N)] *= 0.5
+    if res:
+        ref = ref + r.float()
+    _close(ws, ref, what=f"ws gemm {M}x{N}x{K}")
+    _close(tiled, ref, what=f"tile gemm {M}x{N}x{K}")
+    # same K order, same fp32 accumulation: the two kernels agree to the last bf16 rounding
+    assert (ws.float() - tiled.float()).abs().max().item() <= 2e-2 * ref.abs().max().item()
 
 
 @pytest.mark.parametrize("M,N,K,splits", [(384, 1280, 1280, 0), (384, 1280, 5120, 4), (200, 68, 1024, 3), (1536, 1280, 5120, 0)])
@@ -173,8 +217,9 @@ def test_gemm_dual_source_and_rowvec(device):
     _close(out, ref, what="dual-source gemm")
 
 
+@pytest.mark.parametrize("tile", [0, 21])
 @pytest.mark.parametrize("M,C", [(384, 1280), (1536, 320), (2048, 640)])
-def test_gemm_geglu(device, M, C):
+def test_gemm_geglu(device, M, C, tile):
     from seervideoldm_amd import ops
     from seervideoldm_amd.weights import interleave_geglu
     N = 8 * C
@@ -182,7 +227,7 @@ def test_gemm_geglu(device, M, C):
     w = _rand((N, C), device, 2, C ** -0.5).to(bf16)
     bias = _rand((N,), device, 3, 0.5)
     wi, bi = interleave_geglu(w, bias)
-    out = ops.gemm(a, wi, bias=bi, geglu=True)
+    out = ops.gemm(a, wi, bias=bi, geglu=True, tile=tile)
     h = a.float() @ w.float().t() + bias
     val, gate = h.chunk(2, dim=-1)
     ref = val * Fn.gelu(gate)
@@ -217,7 +262,7 @@ def test_gemm_batched_and_transposed(device):
     (2, 8, 8, 64, 64, 1, True), (24, 32, 32, 320, 320, 1, False), (4, 4, 4, 1280, 1280, 1, False),
     (2, 6, 10, 64, 68, 1, False),
 ])
-@pytest.mark.parametrize("tile", [0, 7, 9, 12, 13, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize("tile", [0, 7, 9, 12, 13, 14, 15, 16, 17, 18, 21])
 def test_conv3x3(device, n_img, H, W, Ci, Co, stride, up, tile):
     from seervideoldm_amd import ops
     from seervideoldm_amd.weights import pack_conv3x3

@@ -244,8 +244,10 @@ def test_full_size_step_matches_oracle(device):
 def test_bridge_config_single_gpu(device):
     """BASELINE config 3 on one GPU: CFG batch 8 (4 samples x [uc, c]) x 16 frames (1 conditioning) x 32^2, full-width UNet.
     (a) finite, right shape; (b) a sample's result does not depend on its batch slot or on its neighbours: rows 0 and 4 of
-    the B = 8 step equal the B = 2 step of that sample to rounding (tile / split-K choices differ with M, the arithmetic
-    per element does not); (c) hipGraph replay is bit-equal to the eager step."""
+    the B = 8 step equal the B = 2 step of that sample up to the path's own rounding noise (tile / split-K choices differ
+    with M, so fp32 sums are ordered differently and single bf16 roundings flip; through ~100 layers that is the same
+    1.7e-2 the path has against the fp32 oracle -- measured 1.66e-2 -- and far from the 0.3+ of a batch mix-up);
+    (c) hipGraph replay is bit-equal to the eager step."""
     cfg = dict(synth.SD15_UNET_CFG)
     m = SeerUNet(**cfg).to(device)
     m.load_state_dict(synth.synth_state_dict(synth.unet_param_shapes(cfg), device=device), strict=True)
@@ -259,7 +261,7 @@ def test_bridge_config_single_gpu(device):
     for a, b in ((y8[0], y2[0]), (y8[4], y2[1])):
         rel = ((a - b).norm() / b.norm()).item()
         print(f"[property] sample 0 inside the B=8 step vs alone: rel_l2 {rel:.3g}")
-        assert rel < 1e-2
+        assert rel < REL_L2
     m.use_graph = True
     try:
         g1 = m(x8, t8, c8, cond_frame=1)
