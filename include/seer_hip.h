@@ -41,7 +41,14 @@ const char* seer_build_arch(void);          /* "gfx950" */
  * A(m,k):  mode PLAIN  : A[m*lda + k] for k < K1, A2[m*lda2 + (k-K1)] for k >= K1 (channel concat of two
  *                        tensors: the skip concat of unet_3d_blocks.py:596,712 without materialising it)
  *          mode CONV3X3: m -> (img, oy, ox); k -> (ky, kx, ci);  X[img, oy*stride+ky-1, ox*stride+kx-1, ci]
- *                        (zero outside), read through a nearest 2x upsample when `upsample` != 0.
+ *                        (zero outside), read through a nearest 2x upsample when `upsample` == 1.
+ *                        `upsample` == 2: the same Upsample3D conv (resnet.py:52-57) as its four 2x2 PHASE convs -- output
+ *                        pixel (2y+a, 2x+b) only ever sees source rows y+a-1, y+a and columns x+b-1, x+b, so phase (a, b)
+ *                        is a 4-tap conv over the SOURCE grid with taps summed per source pixel (16 tap-products per
+ *                        source pixel instead of 36).  M = n_img*Hin*Win, K = 4*Cin with k -> (ty, tx, ci),
+ *                        W = [4 phases (a*2+b)][N][K] (seervideoldm_amd.weights.pack_conv3x3_up_phases), Hout = 2 Hin,
+ *                        Wout = 2 Win; the launch runs the four phases as its grid.z and scatters the rows into
+ *                        C [n_img*Hout*Wout, ldc].  bias and col_scale only (no residual / rowvec / fp32 / transposed out).
  * epilogue: + bias[n] ; + rowvec[(m / rows_per_batch), n] (the time-embedding add of resnet.py:191-193);
  *           + residual[m*ldr + n] ; GEGLU (attention.py:791-793): W rows are interleaved in groups of 16
  *           (16 value rows, then their 16 gate rows), output is N/2 wide: val * gelu_erf(gate).

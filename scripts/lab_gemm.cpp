@@ -59,6 +59,10 @@ int main(int argc, char** argv) {
         {"conv 16x16 320->640", 1, 1, 24, 16, 320, 0, 0, 1, 640, 1, 0}, {"conv 8x8 640->1280", 1, 1, 24, 8, 640, 0, 0, 1, 1280, 1, 0},
         {"conv up 16->32 640->640", 1, 1, 24, 16, 640, 0, 0, 1, 640, 1, 1}, {"conv up 8->16 1280->1280", 1, 1, 24, 8, 1280, 0, 0, 1, 1280, 1, 1},
         {"conv up 4->8 1280->1280", 1, 1, 24, 4, 1280, 0, 0, 1, 1280, 1, 1},
+        // the same three as four 2x2 phase convs (what the engine runs; not in the 9-tap total twice: calls = 0 above would
+        // hide them, so the TOTAL line counts the phase form and the 9-tap rows are printed with calls 0 when LAB_PHASES=1)
+        {"conv up4 16->32 640->640", 1, 1, 24, 16, 640, 0, 0, 1, 640, 1, 2}, {"conv up4 8->16 1280->1280", 1, 1, 24, 8, 1280, 0, 0, 1, 1280, 1, 2},
+        {"conv up4 4->8 1280->1280", 1, 1, 24, 4, 1280, 0, 0, 1, 1280, 1, 2},
         {"conv s2 32x32 320->320", 1, 1, 24, 32, 320, 0, 0, 1, 320, 2, 0}, {"conv s2 16x16 640->640", 1, 1, 24, 16, 640, 0, 0, 1, 640, 2, 0},
         {"conv s2 8x8 1280->1280", 1, 1, 24, 8, 1280, 0, 0, 1, 1280, 2, 0},
     };
@@ -78,7 +82,9 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dR, h.data() + 777, (pool_elems - 777) * 2, hipMemcpyHostToDevice)); CK(hipMemset(dB, 0, 65536 * 4));
     printf("seer ABI %d, iters %d, tile override %d\n%-28s %5s %9s %8s %9s\n", seer_abi_version(), iters, tile_override, "shape", "calls", "us/call", "TF/s", "ms/step");
     double total_ms = 0, total_flops = 0;
-    for (const Shape& s : shapes) {
+    for (const Shape& s0 : shapes) {
+        Shape s = s0;
+        if (s.conv && s.up == 1) s.calls = 0;     // the engine runs the phase form of the three upsampler convs
         if (only && !strstr(s.name, only)) continue;
         seer_gemm_desc d;
         memset(&d, 0, sizeof d);
@@ -89,7 +95,8 @@ int main(int argc, char** argv) {
             const int Hs = s.up ? 2 * s.N : s.N, Ho = (Hs + 2 - 3) / s.stride + 1;
             d.mode = SEER_GEMM_CONV3X3; d.M = s.M * Ho * Ho; d.N = s.Cout; d.K = 9 * s.K; d.K1 = d.K;
             d.Hin = d.Win = s.N; d.Cin = s.K; d.Hout = d.Wout = Ho; d.stride = s.stride; d.upsample = s.up; d.ldc = s.Cout;
-            flops = 2.0 * d.M * d.N * d.K;
+            flops = 2.0 * d.M * d.N * d.K;          // the 9-tap count: what the reference's conv costs
+            if (s.up == 2) { d.M = s.M * s.N * s.N; d.K = 4 * s.K; d.K1 = d.K; d.batch = 4; }
         } else {
             d.mode = SEER_GEMM_PLAIN; d.M = s.M; d.N = s.N; d.K = s.K + s.K2; d.K1 = s.K; d.lda = s.K; d.ldc = s.geglu ? s.N / 2 : s.N;
             if (s.K2) { d.A2 = dR; d.lda2 = s.K2; }

@@ -106,13 +106,17 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
         int gm = m0 + a_tile_row(i);
         gm = gm < p.M ? gm : p.M - 1;
         if constexpr (CONV) {
-            const int hw = p.Hout * p.Wout;
+            // upsample == 2: one of the four 2x2 phase convs of "nearest 2x + conv3x3" (seer_hip.h): rows index the SOURCE
+            // grid, output pixel (2 y + a, 2 x + b) of phase (a, b) = blockIdx.z reads source rows y + a - 1 + {0, 1}
+            const bool phase_mode = p.upsample == 2;
+            const int gw = phase_mode ? p.Win : p.Wout;
+            const int hw = phase_mode ? p.Hin * p.Win : p.Hout * p.Wout;
             const int img = gm / hw;
             const int rem = gm - img * hw;
-            const int oy = rem / p.Wout;
+            const int oy = rem / gw;
             const int pad0 = p.pad_after_only ? 0 : 1;     // rows / columns of padding before the image
-            a_oy[i] = oy * p.stride - pad0;
-            a_ox[i] = (rem - oy * p.Wout) * p.stride - pad0;
+            a_oy[i] = phase_mode ? oy + ((int)blockIdx.z >> 1) - 1 : oy * p.stride - pad0;
+            a_ox[i] = phase_mode ? (rem - oy * gw) + ((int)blockIdx.z & 1) - 1 : (rem - oy * gw) * p.stride - pad0;
             a_off[i] = (int64_t)img * p.Hin * p.Win * p.Cin;
             a_off2[i] = 0;
         } else {
@@ -136,15 +140,16 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
         if constexpr (CONV) {
             const int tap = kbase / p.Cin;
             const int ci0 = kbase - tap * p.Cin;
-            const int ky = tap / 3, kx = tap - ky * 3;
-            const int Hs = p.upsample ? p.Hin * 2 : p.Hin;
-            const int Ws = p.upsample ? p.Win * 2 : p.Win;
+            const int ksz = p.upsample == 2 ? 2 : 3;
+            const int ky = tap / ksz, kx = tap - ky * ksz;
+            const int Hs = p.upsample == 1 ? p.Hin * 2 : p.Hin;
+            const int Ws = p.upsample == 1 ? p.Win * 2 : p.Win;
 #pragma unroll
             for (int i = 0; i < A_CH; ++i) {
                 const int iy = a_oy[i] + ky, ix = a_ox[i] + kx;
                 const bool ok = (iy >= 0) & (iy < Hs) & (ix >= 0) & (ix < Ws);
-                const int sy = p.upsample ? (iy >> 1) : iy;
-                const int sx = p.upsample ? (ix >> 1) : ix;
+                const int sy = p.upsample == 1 ? (iy >> 1) : iy;
+                const int sx = p.upsample == 1 ? (ix >> 1) : ix;
                 u32x4 v = {0u, 0u, 0u, 0u};
                 if (ok) {
                     const bf16* src = A + a_off[i] + ((int64_t)sy * p.Win + sx) * p.Cin + ci0 + c8;
@@ -299,15 +304,16 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
                 if constexpr (CONV) {
                     const int tap = kbase / p.Cin;
                     const int ci0 = kbase - tap * p.Cin;
-                    const int ky = tap / 3, kx = tap - ky * 3;
-                    const int Hs = p.upsample ? p.Hin * 2 : p.Hin;
-                    const int Ws = p.upsample ? p.Win * 2 : p.Win;
+                    const int ksz = p.upsample == 2 ? 2 : 3;
+                    const int ky = tap / ksz, kx = tap - ky * ksz;
+                    const int Hs = p.upsample == 1 ? p.Hin * 2 : p.Hin;
+                    const int Ws = p.upsample == 1 ? p.Win * 2 : p.Win;
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         const int iy = a_oy[c0 + i] + ky, ix = a_ox[c0 + i] + kx;
                         const bool ok = (iy >= 0) & (iy < Hs) & (ix >= 0) & (ix < Ws);
-                        const int sy = p.upsample ? (iy >> 1) : iy;
-                        const int sx = p.upsample ? (ix >> 1) : ix;
+                        const int sy = p.upsample == 1 ? (iy >> 1) : iy;
+                        const int sx = p.upsample == 1 ? (ix >> 1) : ix;
                         const bf16* src = ok ? (A + a_off[c0 + i] + ((int64_t)sy * p.Win + sx) * p.Cin + ci0 + schunk)
                                              : reinterpret_cast<const bf16*>(seer_zero_page);
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -427,15 +433,16 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
             if constexpr (CONV) {
                 const int tap = kbase / p.Cin;
                 const int ci0 = kbase - tap * p.Cin;
-                const int ky = tap / 3, kx = tap - ky * 3;
-                const int Hs = p.upsample ? p.Hin * 2 : p.Hin;
-                const int Ws = p.upsample ? p.Win * 2 : p.Win;
+                const int ksz = p.upsample == 2 ? 2 : 3;
+                const int ky = tap / ksz, kx = tap - ky * ksz;
+                const int Hs = p.upsample == 1 ? p.Hin * 2 : p.Hin;
+                const int Ws = p.upsample == 1 ? p.Win * 2 : p.Win;
 #pragma unroll
                 for (int i = 0; i < A_CH; ++i) {
                     const int iy = a_oy[i] + ky, ix = a_ox[i] + kx;
                     const bool ok = (iy >= 0) & (iy < Hs) & (ix >= 0) & (ix < Ws);
-                    const int sy = p.upsample ? (iy >> 1) : iy;
-                    const int sx = p.upsample ? (ix >> 1) : ix;
+                    const int sy = p.upsample == 1 ? (iy >> 1) : iy;
+                    const int sx = p.upsample == 1 ? (ix >> 1) : ix;
                     const bf16* src = ok ? (A + a_off[i] + ((int64_t)sy * p.Win + sx) * p.Cin + ci0 + schunk)
                                          : reinterpret_cast<const bf16*>(seer_zero_page);
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -568,6 +575,18 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
     const bool do_silu = (p.epilogue & SEER_EPI_SILU) != 0;
     const bool trans = (p.epilogue & SEER_EPI_TRANS_OUT) != 0;
     bf16* Cb = reinterpret_cast<bf16*>(p.C) + (int64_t)z * p.strideC;
+    // output row of GEMM row m: the identity, except for the phase convs, whose row (img, y, x) is pixel (2 y + a, 2 x + b)
+    auto crow = [&](int m) -> int64_t {
+        if constexpr (CONV) {
+            if (p.upsample == 2) {
+                const int hw = p.Hin * p.Win;
+                const int img = m / hw, rem = m - img * hw;
+                const int y = rem / p.Win, x = rem - y * p.Win;
+                return ((int64_t)img * p.Hout + 2 * y + ((int)blockIdx.z >> 1)) * p.Wout + 2 * x + ((int)blockIdx.z & 1);
+            }
+        }
+        return m;
+    };
     float* Cf = reinterpret_cast<float*>(p.C) + (int64_t)z * p.strideC;
     const bool do_rot = (p.epilogue & SEER_EPI_ROTARY) != 0;
 
@@ -676,7 +695,7 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
                     const int cb = col_l * 2;
                     *reinterpret_cast<u32x2*>(smem + row_l * CPITCH + (CSWZ ? (cb ^ ((row_l & 15) << 4)) : cb)) = o;
                 } else {
-                    *reinterpret_cast<u32x2*>(Cb + (int64_t)m * p.ldc + nc) = o;
+                    *reinterpret_cast<u32x2*>(Cb + crow(m) * p.ldc + nc) = o;
                 }
             }
         }
@@ -692,7 +711,7 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
             const int row = c / CPR, ch = c - row * CPR;
             const int m = m0 + row, n = n0o + ch * 8;
             if (((BM * CPR) % NT == 0 || c < BM * CPR) && m < p.M && n < n_out)
-                *reinterpret_cast<u32x4*>(Cb + (int64_t)m * p.ldc + n) =
+                *reinterpret_cast<u32x4*>(Cb + crow(m) * p.ldc + n) =
                     *reinterpret_cast<const u32x4*>(smem + row * CPITCH + (CSWZ ? (ch ^ (row & 15)) : ch) * 16);
         }
     }
@@ -817,10 +836,22 @@ int prepare(seer_gemm_desc& d, int* splits) {
     const bool geglu = (d.epilogue & SEER_EPI_GEGLU) != 0;
     if (d.N % (geglu ? 32 : 4)) return SEER_EINVAL;
     if (d.mode == SEER_GEMM_CONV3X3) {
-        if (d.Cin <= 0 || d.Cin % BK || d.K != 9 * d.Cin) return SEER_EINVAL;
-        if (d.stride != 1 && d.stride != 2) return SEER_EINVAL;
+        if (d.Cin <= 0 || d.Cin % BK) return SEER_EINVAL;
         if (d.Hin <= 0 || d.Win <= 0 || d.Hout <= 0 || d.Wout <= 0) return SEER_EINVAL;
-        if (d.M % (d.Hout * d.Wout)) return SEER_EINVAL;
+        if (d.upsample == 2) {
+            // four 2x2 phase convs as the four batch elements of one launch: same input, W[phase][N][4 Cin], rows scattered
+            if (d.K != 4 * d.Cin || d.stride != 1 || d.pad_after_only || d.Hout != 2 * d.Hin || d.Wout != 2 * d.Win) return SEER_EINVAL;
+            if (d.M % (d.Hin * d.Win) || d.residual || d.rowvec) return SEER_EINVAL;
+            if (d.epilogue & (SEER_EPI_OUT_F32 | SEER_EPI_TRANS_OUT | SEER_EPI_ROTARY | SEER_EPI_GEGLU)) return SEER_EINVAL;
+            d.batch = 4;
+            d.strideA = 0;
+            d.strideW = (int64_t)d.N * d.K;
+            d.strideC = 0;
+        } else {
+            if (d.K != 9 * d.Cin) return SEER_EINVAL;
+            if (d.stride != 1 && d.stride != 2) return SEER_EINVAL;
+            if (d.M % (d.Hout * d.Wout)) return SEER_EINVAL;
+        }
         d.K1 = d.K;
     } else if (d.mode == SEER_GEMM_PLAIN) {
         if (!d.A2) { d.K1 = d.K; d.lda2 = 0; }

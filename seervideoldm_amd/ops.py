@@ -171,6 +171,33 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, n_img: int, Hin: int, Win: int, *,
     return out
 
 
+def conv_up2x(x: torch.Tensor, w4: torch.Tensor, n_img: int, Hin: int, Win: int, *, bias=None,
+              out: Optional[torch.Tensor] = None, tile=0) -> torch.Tensor:
+    """nearest-2x upsample + conv3x3 (Upsample3D, resnet.py:52-57) as four 2x2 phase convs in one launch.
+    x: channels-last [n_img*Hin*Win, Cin] bf16; w4: [4, Cout, 4*Cin] from weights.pack_conv3x3_up_phases.
+    Returns [n_img*2Hin*2Win, Cout]."""
+    _req(x, bf16, "x"); _req(w4, bf16, "w4")
+    assert x.is_contiguous() and w4.is_contiguous()
+    Cin = x.shape[1]
+    four, Cout, K = w4.shape
+    assert four == 4 and K == 4 * Cin and x.shape[0] == n_img * Hin * Win
+    d = GemmDesc()
+    d.A, d.W = _p(x), _p(w4)
+    d.M, d.N, d.K, d.K1 = n_img * Hin * Win, Cout, K, K
+    if out is None:
+        out = torch.empty((n_img * 4 * Hin * Win, Cout), device=x.device, dtype=bf16)
+    d.C, d.ldc = _p(out), out.stride(0)
+    if bias is not None:
+        _req(bias, torch.float32, "bias"); d.bias = _p(bias)
+    d.mode = _lib.SEER_GEMM_CONV3X3
+    d.Hin, d.Win, d.Cin, d.Hout, d.Wout, d.stride, d.upsample = Hin, Win, Cin, 2 * Hin, 2 * Win, 1, 2
+    d.batch = 4
+    d.tile = tile
+    d.splits = 1
+    _launch_gemm(d, x.device, "seer_gemm_bf16(conv_up2x)")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------------------
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *, batch: int, heads: int,
               head_dim: int, Sq: int, Sk: int, causal=False, scale: Optional[float] = None,

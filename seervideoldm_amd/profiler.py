@@ -46,6 +46,15 @@ class TimedOps:
         tag = f"conv n{n_img} {Hin}x{Win} {x.shape[1]}->{Co} s{stride} up{int(bool(up))}"
         return self._timed("gemm", 2.0 * M * Co * K, nbytes, self._base.conv3x3, x, w, n_img, Hin, Win, _tag=tag, **k)
 
+    def conv_up2x(self, x, w4, n_img, Hin, Win, **k):
+        # EXECUTED MACs of the four 2x2 phase convs (16 tap-products per source pixel and channel pair), not the 36 of the
+        # 9-tap conv over the upsampled grid that the reference runs: the roofline fraction prices what the MFMAs did
+        Co, K4 = w4.shape[1], w4.shape[2]
+        M = n_img * Hin * Win
+        nbytes = 2 * (x.numel() + w4.numel() + 4 * M * Co)
+        tag = f"conv_up2x n{n_img} {Hin}x{Win} {x.shape[1]}->{Co} (4 phases)"
+        return self._timed("gemm", 2.0 * 4 * M * Co * K4, nbytes, self._base.conv_up2x, x, w4, n_img, Hin, Win, _tag=tag, **k)
+
     def attention(self, q, k_, v, out, **k):
         nb = k["batch"]
         if k.get("window") is not None:

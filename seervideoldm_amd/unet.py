@@ -22,7 +22,7 @@ import torch.nn as nn
 
 from . import ops as hip_ops
 from . import synth
-from .weights import geglu_row_order, pack_conv1x1, pack_conv3x3
+from .weights import geglu_row_order, pack_conv1x1, pack_conv3x3, pack_conv3x3_up_phases
 
 bf16 = torch.bfloat16
 MAX_WIN_SIZE, MAX_RATIO, MIN_WIN_SIZE = 8, 4, 4      # seer/models/attention.py:31-33
@@ -237,6 +237,10 @@ class _Engine:
                     w[k] = f32(v.permute(0, 2, 3, 1))                   # [Cout,3,3,C0]: direct kernel
             elif k.endswith(".weight") and v.dim() == 4:
                 w[k] = b16(pack_conv3x3(v) if v.shape[-1] == 3 else pack_conv1x1(v))
+                if ".upsamplers." in k:
+                    # the conv behind the nearest-2x upsample as four 2x2 phase convs (16 instead of 36 tap-products per
+                    # source pixel); the 9-tap form stays for the fine-tuning backward (trainer.py)
+                    w[k + "_up4"] = b16(pack_conv3x3_up_phases(v.to(torch.float32)))
             elif k.endswith(".weight") and v.dim() == 2:
                 if k.endswith("ff.net.0.proj.weight"):
                     order = geglu_row_order(v.shape[0] // 2)
@@ -429,8 +433,8 @@ class _Engine:
                     x = self._text_transformer(f"{p}.attentions.{j}", x, geo)
                     x = self._temporal_transformer(f"{p}.temporal_attentions.{j}", x, geo, cond_frame)
             if i < n - 1:
-                x = ops.conv3x3(x, w[f"{p}.upsamplers.0.conv.weight"], B * Fr, geo[2], geo[3], upsample=True,
-                                bias=w[f"{p}.upsamplers.0.conv.bias"])
+                x = ops.conv_up2x(x, w[f"{p}.upsamplers.0.conv.weight_up4"], B * Fr, geo[2], geo[3],
+                                  bias=w[f"{p}.upsamplers.0.conv.bias"])
                 geo = (B, Fr, geo[2] * 2, geo[3] * 2)
         x = self._gn(x, None, B, Fr * geo[2] * geo[3], "conv_norm_out", self.eps, True)
         return ops.conv_out(x, w["conv_out.weight"], w["conv_out.bias"], B, Fr, geo[2], geo[3])

@@ -19,6 +19,28 @@ def pack_conv3x3(w: torch.Tensor) -> torch.Tensor:
     return w.permute(0, 2, 3, 1).reshape(Co, 9 * Ci).contiguous()
 
 
+def pack_conv3x3_up_phases(w: torch.Tensor) -> torch.Tensor:
+    """[Co, Ci, 3, 3] -> [4, Co, 4*Ci]: the conv behind a nearest-2x upsample (resnet.py:52-57) as four 2x2 convs over the
+    SOURCE grid.  Output pixel (2y+a, 2x+b) reads upsampled rows 2y+a-1 .. 2y+a+1 = source rows y+a-1 (ty = 0) and y+a
+    (ty = 1): for a = 0 the taps ky = 1, 2 fall on the same source row and are summed, for a = 1 the taps ky = 0, 1 (same in
+    x).  phase = a*2 + b, k = (ty*2 + tx)*Ci + ci.  Sums are taken in fp32 before the bf16 rounding."""
+    Co, Ci, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    wf = w.float()
+    sets = (((0,), (1, 2)), ((0, 1), (2,)))          # [a][ty] -> ky values
+    out = torch.empty((4, Co, 2, 2, Ci), dtype=torch.float32, device=w.device)
+    for a in range(2):
+        for b in range(2):
+            for ty in range(2):
+                for tx in range(2):
+                    acc = 0
+                    for ky in sets[a][ty]:
+                        for kx in sets[b][tx]:
+                            acc = acc + wf[:, :, ky, kx]
+                    out[a * 2 + b, :, ty, tx, :] = acc
+    return out.reshape(4, Co, 4 * Ci).to(w.dtype).contiguous()
+
+
 def pack_conv1x1(w: torch.Tensor) -> torch.Tensor:
     """[Co, Ci, 1, 1] -> [Co, Ci]."""
     return w.reshape(w.shape[0], w.shape[1]).contiguous()

@@ -71,7 +71,7 @@ def test_sharded_step_matches_unsharded(tmp_path, batch_groups, B, Fr, cond_fram
     out = tmp_path / "res.pt"
     _spawn(_worker, 2, batch_groups, B, Fr, 8, cond_frame, str(out))
     r = torch.load(out)
-    assert r["desc"] == f"batch_groups{batch_groups}xframe_shards{2 // batch_groups}"
+    assert r["desc"].startswith(f"batch_groups{batch_groups}xframe_shards{2 // batch_groups}")
     rel = ((r["got"] - r["ref"]).norm() / r["ref"].norm()).item()
     # same arithmetic, but a different GEMM blocking or statistics summation order flips bf16 roundings, and two bf16 runs
     # of this network sit ~1-2e-2 apart (the same distance either has from the fp32 oracle); structural errors

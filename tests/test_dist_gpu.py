@@ -103,7 +103,7 @@ def test_sharded_step_on_hip_kernels(tmp_path, batch_groups, B, Fr, cond_frame):
     out = tmp_path / "res.pt"
     _spawn(_worker, 2, batch_groups, B, Fr, 16, cond_frame, str(out))
     r = torch.load(out)
-    assert r["desc"] == f"batch_groups{batch_groups}xframe_shards{2 // batch_groups}"
+    assert r["desc"].startswith(f"batch_groups{batch_groups}xframe_shards{2 // batch_groups}")
     rel = ((r["eager"] - r["ref"]).norm() / r["ref"].norm()).item()
     print(f"[parity] sharded ({r['desc']}) vs unsharded on HIP: rel_l2={rel:.4g}, graph segments {r['nseg']}")
     # a different GEMM blocking / statistics summation order flips bf16 roundings (two bf16 runs of this network sit

@@ -279,6 +279,26 @@ def test_conv3x3(device, n_img, H, W, Ci, Co, stride, up, tile):
     _close(out, ref_cl, what=f"conv {Ci}->{Co} s{stride} up{up}")
 
 
+@pytest.mark.parametrize("n_img,H,W,Ci,Co", [(2, 8, 8, 64, 64), (3, 4, 4, 128, 192), (24, 16, 16, 640, 640), (2, 6, 10, 64, 68),
+                                             (24, 4, 4, 1280, 1280)])
+@pytest.mark.parametrize("tile", [0, 5, 7, 8, 12, 14, 21])
+def test_conv_up2x_phases(device, n_img, H, W, Ci, Co, tile):
+    """nearest-2x + conv3x3 (Upsample3D, resnet.py:52-57) as four 2x2 phase convs against F.interpolate + F.conv2d in fp32,
+    and against the 9-tap kernel on the same input (the two differ by the rounding of the summed taps only)"""
+    from seervideoldm_amd import ops
+    from seervideoldm_amd.weights import pack_conv3x3, pack_conv3x3_up_phases
+    x = _rand((n_img, Ci, H, W), device, 1).to(bf16)
+    w = _rand((Co, Ci, 3, 3), device, 2, (9 * Ci) ** -0.5)
+    bias = _rand((Co,), device, 3)
+    x_cl = x.permute(0, 2, 3, 1).reshape(-1, Ci).contiguous()
+    out = ops.conv_up2x(x_cl, pack_conv3x3_up_phases(w).to(bf16), n_img, H, W, bias=bias, tile=tile)
+    ref = Fn.conv2d(Fn.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w.to(bf16).float(), bias, padding=1)
+    ref_cl = ref.permute(0, 2, 3, 1).reshape(-1, Co)
+    _close(out, ref_cl, what=f"conv_up2x {Ci}->{Co} {H}x{W} tile{tile}")
+    nine = ops.conv3x3(x_cl, pack_conv3x3(w.to(bf16)), n_img, H, W, upsample=True, bias=bias, splits=1)
+    assert (out.float() - nine.float()).abs().max().item() <= 3e-2 * ref_cl.abs().max().item()
+
+
 @pytest.mark.parametrize("tile", [0, 2, 7, 8])
 def test_conv3x3_pad_after_only(device, tile):
     """the VAE encoder's Downsample: F.pad(x, (0,1,0,1)) + conv(stride 2, padding 0) (ldm .../model.py:60-78)"""

@@ -83,6 +83,23 @@ def conv3x3(x, w, n_img, Hin, Win, *, stride=1, upsample=False, bias=None, resid
     return _epilogue(y, bias, False, rowvec, rows_per_batch, False, residual, False, out)
 
 
+def conv_up2x(x, w4, n_img, Hin, Win, *, bias=None, out=None, tile=0):
+    """the four 2x2 phase convs of weights.pack_conv3x3_up_phases, written out: phase (a, b) reads source rows y+a-1, y+a"""
+    Ci, Co = x.shape[1], w4.shape[1]
+    xi = F.pad(x.float().reshape(n_img, Hin, Win, Ci), (0, 0, 1, 1, 1, 1))          # zero border of one source pixel
+    y = torch.zeros((n_img, 2 * Hin, 2 * Win, Co))
+    wf = w4.float().reshape(4, Co, 2, 2, Ci)
+    for a in range(2):
+        for b in range(2):
+            acc = 0
+            for ty in range(2):
+                for tx in range(2):
+                    src = xi[:, a + ty:a + ty + Hin, b + tx:b + tx + Win, :]        # source (y + a - 1 + ty, x + b - 1 + tx)
+                    acc = acc + src @ wf[a * 2 + b, :, ty, tx, :].t()
+            y[:, a::2, b::2, :] = acc
+    return _epilogue(y.reshape(-1, Co), bias, False, None, 0, False, None, False, out)
+
+
 LOG2E = 1.4426950408889634
 
 
