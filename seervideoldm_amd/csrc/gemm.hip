@@ -122,15 +122,21 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
         } else {
             a_off[i] = (int64_t)gm * p.lda;
             a_off2[i] = (int64_t)gm * p.lda2;
-            a_oy[i] = a_ox[i] = 0;
+            // the same row relative to the tile's first row, in ELEMENTS (32 bits): the LDS-direct fetches address
+            // "wave-uniform 64-bit base + one VGPR" (global_load_lds v, s[..]) instead of forming a 64-bit address per piece
+            a_oy[i] = (gm - m0) * p.lda;
+            a_ox[i] = (gm - m0) * p.lda2;
         }
     }
     int64_t b_off[B_CH];
+#pragma unroll
+    int b_rel[B_CH];                  // (gn - n0) * K: the W row relative to the tile's first, in elements
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
         int gn = n0 + b_tile_row(i);
         gn = gn < p.N ? gn : p.N - 1;
         b_off[i] = (int64_t)gn * p.K;
+        b_rel[i] = (gn - n0) * p.K;
     }
 
     u32x4 areg[A_CH], breg[B_CH];
@@ -450,17 +456,20 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
                 }
             } else {
                 const bool second = kbase >= p.K1;
+                const unsigned char* base = second ? reinterpret_cast<const unsigned char*>(A2 + (int64_t)m0 * p.lda2 + (kbase - p.K1))
+                                                   : reinterpret_cast<const unsigned char*>(A + (int64_t)m0 * p.lda + kbase);
 #pragma unroll
                 for (int i = 0; i < A_CH; ++i) {
-                    const bf16* src = second ? (A2 + a_off2[i] + (kbase - p.K1) + schunk) : (A + a_off[i] + kbase + schunk);
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                    const unsigned voff = (unsigned)((second ? a_ox[i] : a_oy[i]) + schunk) * 2u;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + voff),
                                                      (__attribute__((address_space(3))) void*)(as + RPP * i * BK), 16, 0, 0);
                 }
             }
+            const unsigned char* wbase = reinterpret_cast<const unsigned char*>(W + (int64_t)n0 * p.K + kbase);
 #pragma unroll
             for (int i = 0; i < B_CH; ++i) {
-                const bf16* src = W + b_off[i] + kbase + schunk;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                const unsigned voff = (unsigned)(b_rel[i] + schunk) * 2u;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbase + voff),
                                                  (__attribute__((address_space(3))) void*)(bs + RPP * i * BK), 16, 0, 0);
             }
         };
