@@ -11,7 +11,7 @@ for p in 1 2 4 6 8 9 15; do
 done
 wait
 for p in 1 2 4 6 8 9 15; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o lib/libseer_aprobe$p.so lib/obj/gemm.hip.o lib/obj/attn_probe$p.o \
-      lib/obj/norm.hip.o lib/obj/elementwise.hip.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o lib/libseer_aprobe$p.so lib/obj/attn_probe$p.o \
+      $(ls lib/obj/*.hip.o | grep -v "/attention.hip.o")   # every other object of the library: _lib.load() binds all symbols
 done
 ls lib/*.so
