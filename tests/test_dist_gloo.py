@@ -154,3 +154,20 @@ def test_data_parallel_train_step(tmp_path):
     tr.pf.g.copy_((r0["gf"] + r1["gf"]) * 0.5)
     tr.optimizer_step()
     assert torch.allclose(tr.pu.p, r0["pu"], atol=1e-7) and torch.allclose(tr.pf.p, r0["pf"], atol=1e-7)
+
+
+def test_partition_choice_per_config():
+    """the CFG-doubled batch splits first (no per-layer communication), frames only inside a batch group.
+    config 2 (b = 1 -> CFG batch 2) on 8 GPUs = 2 batch groups x 4 frame shards; config 3 (b = 4 -> CFG batch 8) on 8 GPUs = 8
+    batch groups and NO frame sharding (zero data-path collectives)."""
+    from seervideoldm_amd.parallel import FrameShard, choose_groups
+    assert choose_groups(8, 2) == (2, 4)
+    assert choose_groups(8, 8) == (8, 1)
+    assert choose_groups(4, 2) == (2, 2) and choose_groups(2, 2) == (2, 1) and choose_groups(2, 1) == (1, 2)
+    sh = FrameShard(8, 5)
+    assert sh.plan(8, 16) == ((5, 6), (0, 16)) and sh.P == 1
+    assert not sh.capture_collectives              # no RCCL process group here: collectives stay eager between graph segments
+    assert sh.describe() == "batch_groups8xframe_shards1"
+    sh = FrameShard(8, 5)
+    assert sh.plan(2, 12) == ((1, 2), (3, 6)) and (sh.G, sh.P) == (2, 4)
+    assert sh.describe().startswith("batch_groups2xframe_shards4, eager collectives")
