@@ -177,7 +177,23 @@ def main():
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
+            # rehearsal of the N > 1 control flow on a 1-GPU box (tests/test_bench_multi.py): gloo has no device all-gather,
+            # so the two gather flavours go through host memory; everything else is the code path the driver runs over RCCL
             dist.init_process_group(backend)
+            ag, agt = dist.all_gather, dist.all_gather_into_tensor
+
+            def all_gather(recv, send, group=None):
+                host = [torch.empty(r.shape, dtype=r.dtype) for r in recv]
+                ag(host, send.cpu(), group=group)
+                for r, h in zip(recv, host):
+                    r.copy_(h)
+
+            def all_gather_into_tensor(out, x, group=None):
+                host = torch.empty(out.shape, dtype=out.dtype)
+                agt(host, x.cpu(), group=group)
+                out.copy_(host)
+
+            dist.all_gather, dist.all_gather_into_tensor = all_gather, all_gather_into_tensor
 
     from seervideoldm_amd import DDIMSampler, SeerUNet, synth
     from seervideoldm_amd.profiler import TimedOps

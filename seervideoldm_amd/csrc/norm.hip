@@ -76,29 +76,22 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const bf16* __restrict__ 
     }
 }
 
-// stats[b][g][2] = sum over blocks (fixed order: 4 contiguous slices, then the 4 slice sums in order)
-__global__ void __launch_bounds__(1024) gn_finalize_kernel(const float* __restrict__ partials, int nblk, int groups,
-                                                           float* __restrict__ stats) {
-    __shared__ float part[8][128];
-    const int b = blockIdx.x;
-    const int n = groups * 2;                 // <= 128
-    const int s = threadIdx.x & 127, slice = threadIdx.x >> 7;    // 8 slices x 128 stats with 1024 threads
+// stats[b][g][2] = sum over blocks.  One WAVE per (b, statistic): lane l adds blocks l, l+64, ... in order, then the 64 lane
+// sums are added by a fixed butterfly -- the same order for every (b, statistic) and every run (deterministic, no atomics), and
+// 2 * batch * groups waves instead of `batch` blocks each walking a 64-deep dependent chain (4.7 -> ~2 us per launch: the
+// kernel is pure latency, r02_rocprof_summary_v1.md)
+__global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ partials, int nblk, int groups, int batch,
+                                                          float* __restrict__ stats) {
+    const int n = groups * 2;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);       // wave index = b * n + statistic
+    if (w >= batch * n) return;
+    const int lane = threadIdx.x & 63;
+    const int b = w / n, sidx = w - b * n;
+    const float* p = partials + ((int64_t)b * nblk) * n + sidx;
     float acc = 0.f;
-    if (s < n) {
-        const int per = (nblk + 7) / 8;
-        const int k0 = slice * per, k1 = min(nblk, k0 + per);
-        const float* p = partials + ((int64_t)b * nblk) * n + s;
-#pragma unroll 8
-        for (int k = k0; k < k1; ++k) acc += p[(int64_t)k * n];
-    }
-    part[slice][s] = acc;
-    __syncthreads();
-    if (threadIdx.x < n) {
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) t += part[i][threadIdx.x];     // fixed order
-        stats[(int64_t)b * n + threadIdx.x] = t;
-    }
+    for (int k = lane; k < nblk; k += 64) acc += p[(int64_t)k * n];
+    acc = wave_sum(acc);                                     // xor butterfly 32, 16, ..., 1: one fixed order
+    if (lane == 0) stats[w] = acc;
 }
 
 __global__ void __launch_bounds__(256) gn_apply_kernel(const bf16* __restrict__ x1, const bf16* __restrict__ x2,
@@ -323,7 +316,8 @@ extern "C" int seer_groupnorm_stats(const void* x1, int32_t C1, const void* x2, 
     hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), lds, st, reinterpret_cast<const bf16*>(x1),
                        reinterpret_cast<const bf16*>(x2), g, rows_per_batch, groups, workspace);
     SEER_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(1024), 0, st, workspace, g.nblk, groups, stats);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)((batch * groups * 2 + 3) / 4)), dim3(256), 0, st, workspace, g.nblk, groups,
+                       batch, stats);
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }
