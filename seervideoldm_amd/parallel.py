@@ -175,9 +175,45 @@ class FrameShard:
         return full
 
 
+def probe_capture(device) -> bool:
+    """Can this process group's collectives be recorded into a hipGraph and replayed?  One tiny all-reduce + all-gather is
+    captured and replayed on every rank; the verdicts are combined by an (eager) MIN all-reduce so that all ranks take the
+    same path.  A stack that cannot capture falls back to eager exchanges between graph segments instead of failing the step."""
+    ok = 1.0
+    try:
+        world = dist.get_world_size()
+        x = torch.ones(64, device=device)
+        out = torch.empty(64 * world, device=device)
+        dist.all_reduce(x)                      # communicator creation must not happen under capture
+        dist.all_gather_into_tensor(out, x)
+        torch.cuda.synchronize(device)
+        s = torch.cuda.Stream(device=device)
+        s.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(s):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                y = x * 2
+                dist.all_reduce(y)
+                dist.all_gather_into_tensor(out, y)
+        torch.cuda.current_stream(device).wait_stream(s)
+        x.fill_(1.0)
+        g.replay()
+        torch.cuda.synchronize(device)
+        ok = 1.0 if bool((out == 2.0 * world).all()) else 0.0
+    except Exception:       # noqa: BLE001  (capture unsupported / refused: every failure mode means "do not capture")
+        ok = 0.0
+    flag = torch.tensor([ok], device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item() > 0.5)
+
+
 def attach(model, world: int, rank: int, batch_groups: Optional[int] = None) -> FrameShard:
     """make `model.forward` run sharded: every rank passes the FULL (sample, timestep, context) and gets the FULL output."""
     shard = FrameShard(world, rank, batch_groups)
+    if shard.capture_collectives:
+        dev = next(model.parameters()).device
+        if dev.type != "cuda" or not probe_capture(dev):
+            shard.capture_collectives = False
     model._shard = shard
     model._engine = None
     return shard
