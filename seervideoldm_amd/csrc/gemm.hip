@@ -129,7 +129,6 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
         }
     }
     int64_t b_off[B_CH];
-#pragma unroll
     int b_rel[B_CH];                  // (gn - n0) * K: the W row relative to the tile's first, in elements
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
