@@ -775,6 +775,11 @@ __global__ void __launch_bounds__(256) seer_splitk_reduce_kernel(const seer_gemm
     }
 }
 
+// one flag per tile instantiation, at namespace scope (no function-local statics in the library): the dynamic-LDS opt-in of its
+// kernels has run
+template <int BM, int BN, int NS, int WM, int WN>
+std::once_flag g_tile_lds_once;
+
 template <int BM, int BN, int NS, int WM = 2, int WN = 2>
 int launch_tile(const seer_gemm_desc& d, hipStream_t st) {
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
@@ -784,8 +789,7 @@ int launch_tile(const seer_gemm_desc& d, hipStream_t st) {
     if (lds > 64 * 1024) {
         // above the default dynamic-LDS limit: opt in once per instantiation (160 KiB per CU on gfx950); std::call_once keeps
         // concurrent first calls from different host threads safe (the header promises thread safety)
-        static std::once_flag once;
-        std::call_once(once, [lds] {
+        std::call_once(g_tile_lds_once<BM, BN, NS, WM, WN>, [lds] {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, true, false, false, NS, WM, WN>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if constexpr (GEGLU_OK)

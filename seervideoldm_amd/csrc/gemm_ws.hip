@@ -295,6 +295,9 @@ __global__ void __launch_bounds__(512) seer_gemm_ws_kernel(const seer_gemm_desc 
 }
 
 template <int CW, int NK, bool GEGLU>
+std::once_flag g_ws_lds_once;        // the kernel's dynamic-LDS opt-in has run (namespace scope: no function-local statics)
+
+template <int CW, int NK, bool GEGLU>
 int ws_launch(const seer_gemm_desc& d, hipStream_t st) {
     constexpr int ROWS = WS_SLOT_BYTES / (NK * WS_BK * 2);
     constexpr int CWO = GEGLU ? CW / 2 : CW;
@@ -304,8 +307,7 @@ int ws_launch(const seer_gemm_desc& d, hipStream_t st) {
     if (wpp < 1) return SEER_ENOSYS;
     if (wpp > slots_m) wpp = slots_m;
     const size_t lds = (size_t)WS_NSLOT * WS_SLOT_BYTES + 8 * (32 * (CWO * 2 + 16) + CW * 4);
-    static std::once_flag once;
-    std::call_once(once, [lds] {
+    std::call_once(g_ws_lds_once<CW, NK, GEGLU>, [lds] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_ws_kernel<CW, NK, GEGLU>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });

@@ -895,6 +895,8 @@ extern "C" int seer_mse_loss_grad(const float* pred, const float* target, int32_
     return SEER_OK;
 }
 
+namespace { std::once_flag g_conv_out_bwd_lds_once; }      // dynamic-LDS opt-in of conv_out_bwd_kernel (no function-local statics)
+
 extern "C" int seer_conv_out_bwd(const float* dpred, int32_t B, int32_t C0, int32_t F, int32_t H, int32_t W_, const float* Wt,
                                  int32_t Cout, void* dx, void* stream) {
     if (!dpred || !Wt || !dx || B <= 0 || C0 <= 0 || F <= 0 || H <= 0 || W_ <= 0) return SEER_EINVAL;
@@ -902,8 +904,7 @@ extern "C" int seer_conv_out_bwd(const float* dpred, int32_t B, int32_t C0, int3
     const size_t lds = ((size_t)Cout * 9 * C0 + (size_t)Cout * 3 * (W_ + 2)) * sizeof(float);
     if (lds > 160 * 1024) return SEER_ENOSYS;
     if (lds > 64 * 1024) {
-        static std::once_flag once;
-        std::call_once(once, [] {
+        std::call_once(g_conv_out_bwd_lds_once, [] {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_out_bwd_kernel<4>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         });
