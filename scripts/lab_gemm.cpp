@@ -90,6 +90,7 @@ int main(int argc, char** argv) {
         memset(&d, 0, sizeof d);
         double flops;
         d.A = dA; d.W = dW; d.C = dC; d.batch = 1; d.tile = tile_override;
+        if (getenv("LAB_SPLITS")) d.splits = atoi(getenv("LAB_SPLITS"));      // split-K override (0 = auto)
         if (s.bias) d.bias = dB;
         if (s.conv) {
             const int Hs = s.up ? 2 * s.N : s.N, Ho = (Hs + 2 - 3) / s.stride + 1;
