@@ -142,6 +142,22 @@ __device__ __forceinline__ void lds_wait_v(VRegs& v, bf16x8& v00, bf16x8& v01, b
 template <bool B> struct BoolTag { static constexpr bool value = B; };
 
 // TRACK_ONLY: run the tracked-reference form directly (variant 4 / 5, and whenever lse is requested)
+#ifdef SEER_ATTN40_STAMPS      // measurement-only build (scripts/lab_a40stamps.cpp): s_memrealtime stamps of the first 16 blocks
+__device__ long long seer_a40_stamps[16 * 4 * 128];
+extern "C" long long* seer_lab_a40_stamps() {
+    long long* ptr = nullptr;
+    (void)hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(seer_a40_stamps));
+    return ptr;
+}
+#define A40_STAMP()                                                                                           \
+    do {                                                                                                      \
+        if (blockIdx.x < 16 && lane == 0 && nst < 128) seer_a40_stamps[(blockIdx.x * 4 + wave) * 128 + nst] = wall_clock64(); \
+        ++nst;                                                                                                \
+    } while (0)
+#else
+#define A40_STAMP() do {} while (0)
+#endif
+
 template <int QB, bool TRACK_ONLY>
 __global__ void __launch_bounds__(256, 3) seer_attn40_kernel(const seer_attn_desc p, const int ws_log2, const int nqb) {
     constexpr int D = A40_D;
@@ -155,6 +171,8 @@ __global__ void __launch_bounds__(256, 3) seer_attn40_kernel(const seer_attn_des
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane & 31, lh = lane >> 5;        // S^T / O^T layout: query column, key (or d row) half
+    [[maybe_unused]] int nst = 0;
+    A40_STAMP();
 
     // ---- block -> (batch, head, query block): XCD-contiguous chunks of the (b, head, qblk) order
     int wg;
@@ -324,9 +342,13 @@ __global__ void __launch_bounds__(256, 3) seer_attn40_kernel(const seer_attn_des
         }
 
         auto tile = [&](const int t, const unsigned st_a, unsigned char* st_next) {
+            A40_STAMP();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of tile t (and, at t = 0, Q) has landed
+            A40_STAMP();
             __builtin_amdgcn_s_barrier();                         // all of tile t has landed; everyone left tile t-1
+            A40_STAMP();
             if (t + 1 < ntiles) issue_tile(t + 1, st_next);
+            A40_STAMP();
             const int kt0 = t * A40_KT;
 
             if (t == 0) {
@@ -404,6 +426,7 @@ __global__ void __launch_bounds__(256, 3) seer_attn40_kernel(const seer_attn_des
                         oacc[qb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s2][1], pb, oacc[qb][1], 0, 0, 0);
                     }
                 }
+                A40_STAMP();
             }
         };
         const unsigned st0 = lds_addr(stage_a);
@@ -439,6 +462,7 @@ __global__ void __launch_bounds__(256, 3) seer_attn40_kernel(const seer_attn_des
         if (__syncthreads_or(!accumulators_finite())) run(BoolTag<true>{});
     }
 
+    A40_STAMP();
     // ---- finalize: O[q][d] = O^T[d][q] / l[q], staged through LDS (the stages are free) and stored as whole 80-byte rows
     unsigned char* ost = stage_a + wave * (QW * A40_ROWB);
 #pragma unroll
