@@ -14,6 +14,27 @@
 // tap -> pixel offset is wave-uniform scalar work, the per-row pixel decode is hoisted out of the K loop.
 #include "seer_common.h"
 #include <mutex>
+#include <type_traits>
+
+// Measurement build only (-DSEER_GEMM_STAMPS, scripts/lab_pp8stamps.cpp): wave 0..7 of the first 64 blocks of the 256x256
+// tile record wall_clock64() at the phase boundaries of one tile (entry, prologue issued, prologue landed, K loop done,
+// rows re-aligned, epilogue math done, tile staged, tile stored).
+#ifdef SEER_GEMM_STAMPS
+__device__ long long seer_pp8_stamps[64 * 8 * 16];
+extern "C" long long* seer_lab_pp8_stamps() {
+    long long* p = nullptr;
+    (void)hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(seer_pp8_stamps));
+    return p;
+}
+#define PSTAMP()                                                                                                       \
+    do {                                                                                                               \
+        if (PP8 && blockIdx.x < 64 && (threadIdx.x & 63) == 0 && nst_ < 16)                                            \
+            seer_pp8_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + nst_] = wall_clock64();                       \
+        ++nst_;                                                                                                        \
+    } while (0)
+#else
+#define PSTAMP() do { } while (0)
+#endif
 
 bool seer_gemm_ws_eligible(const seer_gemm_desc& d);             // gemm_ws.hip: weight-stationary persistent kernel (short K)
 bool seer_gemm_ws_profitable(const seer_gemm_desc& d);
@@ -56,10 +77,12 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
     constexpr int STAGE = (BM + BN) * BK;        // elements per stage: [A tile BM x 64][B tile BN x 64]
     bf16* const smem_b = reinterpret_cast<bf16*>(smem);
 
+    [[maybe_unused]] int nst_ = 0;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
+    PSTAMP();
 
     // ---- block -> tile mapping: XCD-contiguous chunks (blocks b and b+8 share an XCD), grouped along M
     const int tiles_m = (p.M + BM - 1) / BM;
@@ -381,12 +404,14 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
             barrier();                                                                                                       \
         } while (0)
 
+        PSTAMP();
         // prologue: K tile 0 whole, K tile 1 up to h2 (its h3 goes out in q0 of tile 0)
         stage_half(0, 0); stage_half(0, 1); stage_half(0, 2); stage_half(0, 3);
         stage_half(1, 0); stage_half(1, 1); stage_half(1, 2);
         if (T > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         barrier();
+        PSTAMP();
         if (wm == 1) barrier();                                       // wave row 1 runs one barrier behind from here on
         for (int u = 0; u < T; ++u) {
             // q0
@@ -414,7 +439,9 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
             SEER_PP8_MMA(1, 0);
         }
 #undef SEER_PP8_MMA
+        PSTAMP();
         if (wm == 0) barrier();                                       // re-align the two wave rows
+        PSTAMP();
     } else if constexpr (NS == 0) {
         load_tile(kt0);
         store_tile(0);
@@ -612,6 +639,78 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
                         ((reinterpret_cast<uintptr_t>(Cb) & 15) == 0);
     if (staged) __syncthreads();                        // every wave is done with the K-loop stages
 
+    // ---- fast epilogue: a full tile whose epilogue is bias / GEGLU / preloaded row vector / residual into the staged C tile
+    // (every FF, projection and conv GEMM of the U-Net).  The general body below tests each descriptor flag for each of the
+    // TM x TN accumulator quads and recomputes the staging address per quad: ~30 VALU instructions per quad, 3.2 us of VALU
+    // issue per 256x256 tile and 1.6 us per 128x128 tile (profiles/r02_pp8_stamps.log).  Here every term is its own pass over
+    // the accumulators behind ONE wave-uniform branch, in the general body's order of additions (bit-identical results), and
+    // the staging address is one XOR per fragment column plus an immediate offset per fragment row.
+    const bool fast_epi = staged && m0 + BM <= p.M && n0 + BN <= p.N && !do_silu && !do_rot &&
+                          !(p.epilogue & SEER_EPI_COLSCALE) && (!p.rowvec || (RV_PRE && rv_pre_ok)) &&
+                          (!R || RES_PRE);          // a residual that was not prefetched takes the general body
+    if (fast_epi) {
+        if (p.bias) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x4 bv;
+                if constexpr (BIAS_PRE) bv = bpre[j];
+                else bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * WTN + j * 16 + fq * 4);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][j] += bv;
+            }
+        }
+        if constexpr (GEGLU) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int j = 0; j < TN; j += 2) {
+                    const f32x4 g = acc[i][j + 1];
+                    const f32x2 ge0 = gelu_erf_f2(f32x2{g[0], g[1]}), ge1 = gelu_erf_f2(f32x2{g[2], g[3]});
+                    acc[i][j][0] *= ge0[0]; acc[i][j][1] *= ge0[1]; acc[i][j][2] *= ge1[0]; acc[i][j][3] *= ge1[1];
+                }
+                if constexpr (PP8) __builtin_amdgcn_sched_barrier(0);    // one fragment row of erf temporaries at a time
+            }
+        }
+        if constexpr (RV_PRE) {
+            if (p.rowvec) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) acc[i][j] += rvpre[j];
+                }
+            }
+        }
+        if constexpr (RES_PRE) {
+            if (R) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const u32x2 rv = rpre[i][j];
+                        acc[i][j][0] += __builtin_bit_cast(float, rv[0] << 16);
+                        acc[i][j][1] += __builtin_bit_cast(float, rv[0] & 0xffff0000u);
+                        acc[i][j][2] += __builtin_bit_cast(float, rv[1] << 16);
+                        acc[i][j][3] += __builtin_bit_cast(float, rv[1] & 0xffff0000u);
+                    }
+                }
+            }
+        }
+        // byte column of the lane's quad inside the staged row: GEGLU halves the column pitch (value columns only)
+        const int cb0 = GEGLU ? (wn * WTN + fq * 8) : (wn * WTN * 2 + fq * 8);
+        const int rowb = (wm * WTM + frow) * CPITCH;
+#pragma unroll
+        for (int j = 0; j < TN; j += (GEGLU ? 2 : 1)) {
+            const int cb = cb0 + (GEGLU ? j * 16 : j * 32);
+            const int at = rowb + (CSWZ ? (cb ^ (frow << 4)) : cb);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                u32x2 o;
+                o[0] = pack2(acc[i][j][0], acc[i][j][1]);
+                o[1] = pack2(acc[i][j][2], acc[i][j][3]);
+                *reinterpret_cast<u32x2*>(smem + at + i * 16 * CPITCH) = o;
+            }
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * WTM + i * 16 + frow;
@@ -708,8 +807,11 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
             }
         }
     }
+    }   // general epilogue
+    PSTAMP();
     if (staged) {
         __syncthreads();
+        PSTAMP();
         constexpr int CPR = BNO / 8;                    // 16-byte chunks per staged row
         const int n0o = GEGLU ? (n0 >> 1) : n0;
         const int n_out = GEGLU ? (p.N >> 1) : p.N;
@@ -723,6 +825,7 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
                     *reinterpret_cast<const u32x4*>(smem + row * CPITCH + (CSWZ ? (ch ^ (row & 15)) : ch) * 16);
         }
     }
+    PSTAMP();
 }
 
 // split-K second pass: C = epilogue( sum over slices, in slice order )
