@@ -24,6 +24,7 @@ struct Shape {
     int geglu, res, bias;
     int Cout, stride, up;
     int K2;               // plain: second source columns (skip concat), 0 = none
+    int epi;              // plain q|k|v: 1 = q columns scaled (spatial / cross attention), 2 = + rotary on q|k (temporal)
 };
 
 static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
@@ -38,8 +39,10 @@ int main(int argc, char** argv) {
         {"ff1 geglu L2", 10, 0, 1536, 10240, 1280, 1, 0, 1}, {"ff1 geglu mid", 2, 0, 384, 10240, 1280, 1, 0, 1},
         {"ff2 +res L0", 10, 0, 24576, 320, 1280, 0, 1, 1}, {"ff2 +res L1", 10, 0, 6144, 640, 2560, 0, 1, 1},
         {"ff2 +res L2", 10, 0, 1536, 1280, 5120, 0, 1, 1}, {"ff2 +res mid", 2, 0, 384, 1280, 5120, 0, 1, 1},
-        {"qkv L0", 10, 0, 24576, 960, 320, 0, 0, 0}, {"qkv L1", 10, 0, 6144, 1920, 640, 0, 0, 0},
-        {"qkv L2", 10, 0, 1536, 3840, 1280, 0, 0, 0}, {"qkv mid", 2, 0, 384, 3840, 1280, 0, 0, 0},
+        {"qkv L0", 5, 0, 24576, 960, 320, 0, 0, 0, 0, 0, 0, 0, 1}, {"qkv L1", 5, 0, 6144, 1920, 640, 0, 0, 0, 0, 0, 0, 0, 1},
+        {"qkv L2", 5, 0, 1536, 3840, 1280, 0, 0, 0, 0, 0, 0, 0, 1}, {"qkv mid", 1, 0, 384, 3840, 1280, 0, 0, 0, 0, 0, 0, 0, 1},
+        {"qkv rotary L0", 5, 0, 24576, 960, 320, 0, 0, 0, 0, 0, 0, 0, 2}, {"qkv rotary L1", 5, 0, 6144, 1920, 640, 0, 0, 0, 0, 0, 0, 0, 2},
+        {"qkv rotary L2", 5, 0, 1536, 3840, 1280, 0, 0, 0, 0, 0, 0, 0, 2}, {"qkv rotary mid", 1, 0, 384, 3840, 1280, 0, 0, 0, 0, 0, 0, 0, 2},
         {"proj/to_out +res L0", 25, 0, 24576, 320, 320, 0, 1, 1}, {"proj_in/q L0", 15, 0, 24576, 320, 320, 0, 0, 1},
         {"proj/to_out +res L1", 25, 0, 6144, 640, 640, 0, 1, 1}, {"proj_in/q L1", 15, 0, 6144, 640, 640, 0, 0, 1},
         {"proj/to_out +res L2", 25, 0, 1536, 1280, 1280, 0, 1, 1}, {"proj_in/q L2", 15, 0, 1536, 1280, 1280, 0, 0, 1},
@@ -78,6 +81,8 @@ int main(int argc, char** argv) {
     uint16_t *dA, *dW, *dC, *dR; float *dB; void* dWs;
     CK(hipMalloc(&dA, pool_elems * 2)); CK(hipMalloc(&dW, pool_elems * 2)); CK(hipMalloc(&dC, pool_elems * 2)); CK(hipMalloc(&dR, pool_elems * 2));
     CK(hipMalloc(&dB, 65536 * 4)); CK(hipMalloc(&dWs, (size_t)512 << 20));
+    float* dTab;                                   // rotary (cos, sin) table: 12288 positions x 16 pairs
+    CK(hipMalloc(&dTab, (size_t)12288 * 32 * 4)); CK(hipMemset(dTab, 0, (size_t)12288 * 32 * 4));
     CK(hipMemcpy(dA, h.data(), pool_elems * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dW, h.data() + 12345, (pool_elems - 12345) * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(dR, h.data() + 777, (pool_elems - 777) * 2, hipMemcpyHostToDevice)); CK(hipMemset(dB, 0, 65536 * 4));
     printf("seer ABI %d, iters %d, tile override %d\n%-28s %5s %9s %8s %9s\n", seer_abi_version(), iters, tile_override, "shape", "calls", "us/call", "TF/s", "ms/step");
@@ -102,6 +107,12 @@ int main(int argc, char** argv) {
             d.mode = SEER_GEMM_PLAIN; d.M = s.M; d.N = s.N; d.K = s.K + s.K2; d.K1 = s.K; d.lda = s.K; d.ldc = s.geglu ? s.N / 2 : s.N;
             if (s.K2) { d.A2 = dR; d.lda2 = s.K2; }
             if (s.geglu) d.epilogue |= SEER_EPI_GEGLU;
+            if (s.epi >= 1) { d.epilogue |= SEER_EPI_COLSCALE; d.col_scale = 0.125f; d.col_scale_cols = s.N / 3; }
+            if (s.epi == 2) {
+                const int hd = s.N / 3 / 8;
+                d.epilogue |= SEER_EPI_ROTARY; d.rot_table = dTab; d.rot_tokens_per_batch = s.M / 2; d.rot_pos_offset = 0;
+                d.rot_head_dim = hd; d.rot_dim = hd < 32 ? hd : 32; d.rot_cols = 2 * s.N / 3;
+            }
             flops = 2.0 * d.M * d.N * d.K;
         }
         if (s.res) { d.residual = dR; d.ldr = d.ldc; }

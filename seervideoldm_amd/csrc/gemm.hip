@@ -16,9 +16,10 @@
 #include <mutex>
 #include <type_traits>
 
-// Measurement build only (-DSEER_GEMM_STAMPS, scripts/lab_pp8stamps.cpp): wave 0..7 of the first 64 blocks of the 256x256
-// tile record wall_clock64() at the phase boundaries of one tile (entry, prologue issued, prologue landed, K loop done,
-// rows re-aligned, epilogue math done, tile staged, tile stored).
+// Measurement build only (-DSEER_GEMM_STAMPS, scripts/lab_pp8stamps.cpp): every wave of the first 64 blocks records
+// wall_clock64() at the phase boundaries of its tile.  256x256 tile: entry, prologue issued, prologue landed, K loop done, rows
+// re-aligned, epilogue math done, tile staged, tile stored.  LDS-direct ring tiles: entry, set-up done, first K tile landed,
+// K loop done, then epilogue math done, tile staged, tile stored (split-K: partial tile stored).
 #ifdef SEER_GEMM_STAMPS
 __device__ long long seer_pp8_stamps[64 * 8 * 16];
 extern "C" long long* seer_lab_pp8_stamps() {
@@ -26,14 +27,26 @@ extern "C" long long* seer_lab_pp8_stamps() {
     (void)hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(seer_pp8_stamps));
     return p;
 }
+// entry / exit time of wave 0 of every block (first 8192 blocks of z = 0): the dispatch ramp and the tail of a launch
+__device__ long long seer_block_span[8192 * 2];
+extern "C" long long* seer_lab_block_span() {
+    long long* p = nullptr;
+    (void)hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(seer_block_span));
+    return p;
+}
+#define PSPAN(which)                                                                                                   \
+    do {                                                                                                               \
+        if (threadIdx.x == 0 && blockIdx.z == 0 && blockIdx.x < 8192) seer_block_span[blockIdx.x * 2 + (which)] = wall_clock64(); \
+    } while (0)
 #define PSTAMP()                                                                                                       \
     do {                                                                                                               \
-        if (PP8 && blockIdx.x < 64 && (threadIdx.x & 63) == 0 && nst_ < 16)                                            \
+        if (blockIdx.x < 64 && blockIdx.z == 0 && (threadIdx.x & 63) == 0 && nst_ < 16)                                \
             seer_pp8_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + nst_] = wall_clock64();                       \
         ++nst_;                                                                                                        \
     } while (0)
 #else
 #define PSTAMP() do { } while (0)
+#define PSPAN(which) do { } while (0)
 #endif
 
 bool seer_gemm_ws_eligible(const seer_gemm_desc& d);             // gemm_ws.hip: weight-stationary persistent kernel (short K)
@@ -83,6 +96,7 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     PSTAMP();
+    PSPAN(0);
 
     // ---- block -> tile mapping: XCD-contiguous chunks (blocks b and b+8 share an XCD), grouped along M
     const int tiles_m = (p.M + BM - 1) / BM;
@@ -526,6 +540,7 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
         };
         {
+        PSTAMP();
 #pragma unroll
         for (int s_ = 0; s_ < NS; ++s_)
             if (kt0 + s_ < nk) issue_tile(kt0 + s_, s_);
@@ -540,6 +555,9 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
             else if (pending == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_barrier" ::: "memory");            // every wave's part of tile kt has landed
+#ifdef SEER_GEMM_STAMPS
+            if (kt == kt0) PSTAMP();
+#endif
 #if !(SEER_GEMM_PROBE & 2)
             read_frags(stage);
 #endif
@@ -562,6 +580,7 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
 #endif
             stage = (stage + 1 == NS) ? 0 : stage + 1;
         }
+        PSTAMP();
         }
 #else
 #pragma unroll
@@ -602,6 +621,8 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
                 *reinterpret_cast<f32x4*>(ws + (int64_t)m * p.N + n) = acc[i][j];
             }
         }
+        PSTAMP();
+        PSPAN(1);
         return;
     }
 
@@ -639,14 +660,14 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
                         ((reinterpret_cast<uintptr_t>(Cb) & 15) == 0);
     if (staged) __syncthreads();                        // every wave is done with the K-loop stages
 
-    // ---- fast epilogue: a full tile whose epilogue is bias / GEGLU / preloaded row vector / residual into the staged C tile
-    // (every FF, projection and conv GEMM of the U-Net).  The general body below tests each descriptor flag for each of the
+    // ---- fast epilogue: a full tile whose epilogue is bias / GEGLU / preloaded row vector / rotary / column scale / preloaded
+    // residual into the staged C tile (every FF, projection, q|k|v and conv GEMM of the U-Net).  The general body below tests each descriptor flag for each of the
     // TM x TN accumulator quads and recomputes the staging address per quad: ~30 VALU instructions per quad, 3.2 us of VALU
     // issue per 256x256 tile and 1.6 us per 128x128 tile (profiles/r02_pp8_stamps.log).  Here every term is its own pass over
     // the accumulators behind ONE wave-uniform branch, in the general body's order of additions (bit-identical results), and
     // the staging address is one XOR per fragment column plus an immediate offset per fragment row.
-    const bool fast_epi = staged && m0 + BM <= p.M && n0 + BN <= p.N && !do_silu && !do_rot &&
-                          !(p.epilogue & SEER_EPI_COLSCALE) && (!p.rowvec || (RV_PRE && rv_pre_ok)) &&
+    const bool fast_epi = staged && m0 + BM <= p.M && n0 + BN <= p.N && !do_silu &&
+                          (!GEGLU || !(do_rot || (p.epilogue & SEER_EPI_COLSCALE))) && (!p.rowvec || (RV_PRE && rv_pre_ok)) &&
                           (!R || RES_PRE);          // a residual that was not prefetched takes the general body
     if (fast_epi) {
         if (p.bias) {
@@ -677,6 +698,45 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
                 for (int j = 0; j < TN; ++j) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i) acc[i][j] += rvpre[j];
+                }
+            }
+        }
+        if constexpr (!GEGLU) {
+            if (do_rot) {
+                // rotary on the q|k columns (attention.py:649-651), as in the general body, with the channel of each fragment
+                // column and the position of each fragment row computed once per lane instead of once per quad
+                int tj[TN];                                 // float offset of the lane's (cos, sin) pairs in a table row, or -1
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn * WTN + j * 16 + fq * 4;
+                    const int ch = n % p.rot_head_dim;
+                    tj[j] = (n < p.rot_cols && ch < p.rot_dim) ? (ch / 2) * 2 : -1;
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int m = m0 + wm * WTM + i * 16 + frow;
+                    const int pos = m % p.rot_tokens_per_batch + p.rot_pos_offset;
+                    const float* trow = p.rot_table + (int64_t)pos * (p.rot_dim / 2) * 2;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if (tj[j] >= 0) {
+                            const f32x4 cs = *reinterpret_cast<const f32x4*>(trow + tj[j]);
+                            const float a0 = acc[i][j][0], b0 = acc[i][j][1], a1 = acc[i][j][2], b1 = acc[i][j][3];
+                            acc[i][j][0] = a0 * cs[0] - b0 * cs[1];
+                            acc[i][j][1] = b0 * cs[0] + a0 * cs[1];
+                            acc[i][j][2] = a1 * cs[2] - b1 * cs[3];
+                            acc[i][j][3] = b1 * cs[2] + a1 * cs[3];
+                        }
+                    }
+                }
+            }
+            if (p.epilogue & SEER_EPI_COLSCALE) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    // x * 1.0f is exact: the columns past col_scale_cols keep their bits
+                    const float sc = (n0 + wn * WTN + j * 16 + fq * 4) < p.col_scale_cols ? p.col_scale : 1.f;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) acc[i][j] *= sc;
                 }
             }
         }
@@ -826,6 +886,7 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
         }
     }
     PSTAMP();
+    PSPAN(1);
 }
 
 // split-K second pass: C = epilogue( sum over slices, in slice order )
