@@ -312,6 +312,7 @@ def main():
                         algorithmic_gflop_per_launch=round(per_launch_flops / 1e9, 3),
                         step_breakdown_ms={k: round(v["ms"] / reps, 3) for k, v in summ.items()},
                         attention_tflops=round(summ.get("attention", {}).get("tflops", 0.0), 2),
+                        groupnorms_from_colsums=f"{eng.gn_from_colsums} of {eng.n_groupnorms()}",
                         spatial_attention_block=attn_block)
         if traffic_note:
             roofline["traffic_note"] = traffic_note

@@ -103,6 +103,13 @@ typedef struct seer_gemm_desc {
     /* SEER_EPI_COLSCALE */
     int32_t col_scale_cols;
     float col_scale;
+    /* optional: per-tile column sums of C as stored (bf16-rounded), colsum[z][ceil(M / rows)][N][2] = (sum, sum of squares) over
+     * the tile's rows, rows = seer_gemm_colsum_rows(desc), z = the phase of an upsample == 2 conv (else 0).  The GroupNorm that
+     * consumes C (ResnetBlock3D.norm1/norm2, SpatialTransformer3D.norm: resnet.py / attention.py of the reference run
+     * F.group_norm on it) takes its statistics from these sums instead of a pass over C: seer_groupnorm_stats_from_colsums.
+     * A launch that cannot produce them (GEGLU, fp32 / transposed output, the weight-stationary kernel) fails with
+     * SEER_EINVAL when colsum is set: ask seer_gemm_colsum_rows first. */
+    float* colsum;
 } seer_gemm_desc;
 
 #define SEER_TILE_AUTO 0
@@ -136,6 +143,9 @@ typedef struct seer_gemm_desc {
 int seer_gemm_bf16(const seer_gemm_desc* desc /* host */, void* stream);
 /* bytes of workspace the call would use for split-K with this descriptor (0: it will not split) */
 int64_t seer_gemm_workspace_bytes(const seer_gemm_desc* desc /* host */);
+/* rows per partial of the column sums this exact launch (same tile / splits / workspace fields) would write to desc->colsum,
+ * or 0 when it cannot produce them; the buffer is [z][ceil(M / rows)][N][2] floats */
+int32_t seer_gemm_colsum_rows(const seer_gemm_desc* desc /* host */);
 
 /* ---- attention -------------------------------------------------------------------------- */
 /* Replaces xformers.ops.memory_efficient_attention as called from CrossAttention
@@ -218,6 +228,13 @@ int seer_rotary_inplace(void* x, int64_t rows, int32_t ld, int32_t col0_q, int32
 int64_t seer_groupnorm_workspace_floats(int32_t C, int32_t batch, int64_t rows_per_batch, int32_t groups);
 int seer_groupnorm_stats(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t batch,
                          int64_t rows_per_batch, int32_t groups, float* stats, float* workspace, void* stream);
+/* The same stats[b][g][2] from the column sums the producers of x1 / x2 left behind (seer_gemm_desc::colsum) -- no pass over
+ * the activations.  Source i: C_i channels, partial rows [phases_i][tiles_i][C_i][2]; the tiles of a phase cover the batch
+ * elements in order, tiles_i / batch each (tiles_i % batch == 0).  One wave per (b, g) adds its channels' partials in a fixed
+ * order: deterministic; equal to seer_groupnorm_stats up to the fp32 order of additions. */
+int seer_groupnorm_stats_from_colsums(const float* cs1, int32_t C1, int32_t phases1, int32_t tiles1, const float* cs2,
+                                      int32_t C2, int32_t phases2, int32_t tiles2, int32_t batch, int32_t groups,
+                                      float* stats, void* stream);
 int seer_groupnorm_apply(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t batch,
                          int64_t rows_per_batch, int32_t groups, const float* stats, double count, float eps,
                          const float* gamma, const float* beta, int32_t silu, void* y, void* stream);

@@ -81,6 +81,8 @@ int main(int argc, char** argv) {
     uint16_t *dA, *dW, *dC, *dR; float *dB; void* dWs;
     CK(hipMalloc(&dA, pool_elems * 2)); CK(hipMalloc(&dW, pool_elems * 2)); CK(hipMalloc(&dC, pool_elems * 2)); CK(hipMalloc(&dR, pool_elems * 2));
     CK(hipMalloc(&dB, 65536 * 4)); CK(hipMalloc(&dWs, (size_t)512 << 20));
+    float* dCs;                                    // column-sum partials (LAB_COLSUM=1)
+    CK(hipMalloc(&dCs, (size_t)64 << 20));
     float* dTab;                                   // rotary (cos, sin) table: 12288 positions x 16 pairs
     CK(hipMalloc(&dTab, (size_t)12288 * 32 * 4)); CK(hipMemset(dTab, 0, (size_t)12288 * 32 * 4));
     CK(hipMemcpy(dA, h.data(), pool_elems * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dW, h.data() + 12345, (pool_elems - 12345) * 2, hipMemcpyHostToDevice));
@@ -119,6 +121,10 @@ int main(int argc, char** argv) {
         int64_t ws = seer_gemm_workspace_bytes(&d);
         if (ws < 0) { printf("%-28s workspace query failed: %s\n", s.name, seer_strerror((int)ws)); continue; }
         if (ws > 0) { d.workspace = dWs; d.workspace_bytes = ws; }
+        if (getenv("LAB_COLSUM") && !s.geglu) {      // the launch also leaves per-tile column sums (outputs that feed a GroupNorm)
+            d.colsum = dCs;
+            if (seer_gemm_colsum_rows(&d) <= 0) d.colsum = nullptr;
+        }
         const bool stamps = getenv("LAB_STAMPS") != nullptr;
         if (stamps) { d.workspace = dWs; d.workspace_bytes = 777; CK(hipMemset(dWs, 0, 1 << 22)); }
         int rc = 0;
@@ -131,7 +137,8 @@ int main(int argc, char** argv) {
         float ms;
         CK(hipEventElapsedTime(&ms, e0, e1));
         const double us = ms * 1e3 / iters;
-        printf("%-28s %5d %9.1f %8.0f %9.3f%s\n", s.name, s.calls, us, flops / us * 1e-6, us * s.calls * 1e-3, ws > 0 ? "  (split-K)" : "");
+        printf("%-28s %5d %9.1f %8.0f %9.3f%s%s\n", s.name, s.calls, us, flops / us * 1e-6, us * s.calls * 1e-3, ws > 0 ? "  (split-K)" : "",
+               d.colsum ? "  +colsum" : "");
         if (stamps) {
             std::vector<long long> hs((1 << 22) / 8);
             CK(hipMemcpy(hs.data(), dWs, 1 << 22, hipMemcpyDeviceToHost));

@@ -13,7 +13,7 @@ _PKG = Path(__file__).resolve().parent
 _LIB_PATH = _PKG / "lib" / "libseer_hip.so"
 _lib = None
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 SEER_GEMM_PLAIN = 0
 SEER_GEMM_CONV3X3 = 1
@@ -48,6 +48,7 @@ class GemmDesc(C.Structure):
         ("rot_head_dim", C.c_int32), ("rot_dim", C.c_int32), ("rot_cols", C.c_int32),
         ("pad_after_only", C.c_int32),
         ("col_scale_cols", C.c_int32), ("col_scale", C.c_float),
+        ("colsum", C.c_void_p),
     ]
 
 
@@ -84,11 +85,13 @@ SIGNATURES = {
     "seer_build_arch": ([], C.c_char_p),
     "seer_gemm_bf16": ([C.POINTER(GemmDesc), _vp], C.c_int),
     "seer_gemm_workspace_bytes": ([C.POINTER(GemmDesc)], C.c_int64),
+    "seer_gemm_colsum_rows": ([C.POINTER(GemmDesc)], C.c_int32),
     "seer_attn_fwd": ([C.POINTER(AttnDesc), _vp], C.c_int),
     "seer_rotary_table": ([_vp, _i32, _i32, _vp, _vp], C.c_int),
     "seer_rotary_inplace": ([_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp], C.c_int),
     "seer_groupnorm_workspace_floats": ([_i32, _i32, _i64, _i32], C.c_int64),
     "seer_groupnorm_stats": ([_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _vp], C.c_int),
+    "seer_groupnorm_stats_from_colsums": ([_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp], C.c_int),
     "seer_groupnorm_apply": ([_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _f64, _f32, _vp, _vp, _i32, _vp, _vp], C.c_int),
     "seer_layernorm": ([_vp, _i64, _i32, _i32, _vp, _vp, _f32, _vp, _i32, _vp], C.c_int),
     "seer_softmax_rows": ([_vp, _i32, _i64, _i32, _i32, _f32, _vp, _i32, _vp], C.c_int),

@@ -74,6 +74,17 @@ __device__ __attribute__((aligned(16))) unsigned int seer_zero_page[4] = {0u, 0u
 //          flight across raw s_barriers behind counted s_waitcnt vmcnt(N).  Same LDS image either way.
 // WM x WN: the wave grid.  WN = 2: WM = 2 -> 256 threads, 4 -> 512 threads (256-row tiles, same 64x64 wave tile).
 // WM = 2, WN = 4 with a 256 x 256 tile is the 8-phase ping-pong kernel (PP8 below): 128 x 64 wave tiles, its own main loop.
+// whether a tile instantiation can produce column sums (seer_gemm_desc::colsum): the staged C tile plus the row-segment
+// partials have to fit in the K-loop LDS, one thread per output column adds them
+template <int BM, int BN, int NS, int WM, int WN>
+constexpr bool tile_colsum_ok() {
+    constexpr int NT = 64 * WM * WN, STAGE = (BM + BN) * BK;
+    constexpr bool PP8 = WM == 2 && WN == 4 && BM == 256 && BN == 256;
+    constexpr bool CSWZ = BM * (BN * 2 + 16) > 2 * STAGE * (int)sizeof(bf16);
+    constexpr int CPITCH = BN * 2 + (CSWZ ? 0 : 16);
+    return !PP8 && BN <= NT && BM * CPITCH + (NT / (BN / 2)) * BN * 8 <= (NS == 0 ? 2 : NS) * STAGE * (int)sizeof(bf16);
+}
+
 template <int BM, int BN, bool CONV, bool GEGLU, bool SPLIT, int NS, int WM = 2, int WN = 2>
 __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm_desc p) {
     constexpr int NT = 64 * WM * WN;               // threads per block
@@ -875,6 +886,33 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
         constexpr int CPR = BNO / 8;                    // 16-byte chunks per staged row
         const int n0o = GEGLU ? (n0 >> 1) : n0;
         const int n_out = GEGLU ? (p.N >> 1) : p.N;
+        // ---- column sums of the tile as stored (bf16-rounded): sum and sum of squares per output column over the tile's rows,
+        // written to colsum[z][tile_m][N][2].  The GroupNorm that consumes C adds them per (batch element, group) in a fixed
+        // order (seer_groupnorm_stats_from_colsums) instead of re-reading C.  Thread -> (column pair, row segment): a wave reads
+        // 256 contiguous bytes of one staged row per instruction (conflict-free), row segments are added in order by the
+        // column's thread: deterministic, no atomics.
+        constexpr int CS_CP = BNO / 2;                  // column pairs
+        constexpr int CS_RS = NT / CS_CP;               // row segments
+        constexpr bool COLSUM_OK = !GEGLU && !SPLIT && tile_colsum_ok<BM, BN, NS, WM, WN>();
+        float* cs_scratch = reinterpret_cast<float*>(smem + BM * CPITCH);
+        if constexpr (COLSUM_OK) {
+            if (p.colsum) {
+                const int cp = tid % CS_CP, rs = tid / CS_CP;
+                if (rs < CS_RS) {
+                    const int rows = min(BM, p.M - m0);
+                    const int chunk = cp >> 2, within = (cp & 3) * 4;
+                    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+                    for (int r = rs; r < rows; r += CS_RS) {
+                        const uint32_t v = *reinterpret_cast<const uint32_t*>(
+                            smem + r * CPITCH + (CSWZ ? (chunk ^ (r & 15)) : chunk) * 16 + within);
+                        const float f0 = __builtin_bit_cast(float, v << 16), f1 = __builtin_bit_cast(float, v & 0xffff0000u);
+                        s0 += f0; q0 += f0 * f0;
+                        s1 += f1; q1 += f1 * f1;
+                    }
+                    *reinterpret_cast<f32x4*>(cs_scratch + (rs * CS_CP + cp) * 4) = f32x4{s0, q0, s1, q1};
+                }
+            }
+        }
 #pragma unroll
         for (int it = 0; it < (BM * CPR + NT - 1) / NT; ++it) {
             const int c = tid + it * NT;
@@ -884,20 +922,34 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
                 *reinterpret_cast<u32x4*>(Cb + crow(m) * p.ldc + n) =
                     *reinterpret_cast<const u32x4*>(smem + row * CPITCH + (CSWZ ? (ch ^ (row & 15)) : ch) * 16);
         }
+        if constexpr (COLSUM_OK) {
+            if (p.colsum) {
+                __syncthreads();                        // the row-segment partials are parked
+                if (tid < BNO && n0o + tid < n_out) {
+                    float sm = 0.f, sq = 0.f;
+#pragma unroll
+                    for (int rs = 0; rs < CS_RS; ++rs) {
+                        const float* e = cs_scratch + (rs * CS_CP + (tid >> 1)) * 4 + (tid & 1) * 2;
+                        sm += e[0];
+                        sq += e[1];
+                    }
+                    const int tiles_m = (p.M + BM - 1) / BM;
+                    float* o = p.colsum + (((int64_t)blockIdx.z * tiles_m + m0 / BM) * p.N + n0o + tid) * 2;
+                    *reinterpret_cast<f32x2*>(o) = f32x2{sm, sq};
+                }
+            }
+        }
     }
     PSTAMP();
     PSPAN(1);
 }
 
-// split-K second pass: C = epilogue( sum over slices, in slice order )
-__global__ void __launch_bounds__(256) seer_splitk_reduce_kernel(const seer_gemm_desc p) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int n4 = p.N / 4;
-    if (idx >= (int64_t)p.M * n4) return;
-    const int m = (int)(idx / n4);
-    const int n = (int)(idx - (int64_t)m * n4) * 4;
+// split-K second pass: C = epilogue( sum over slices, in slice order ).  One quad of 4 output columns of row m; returns the
+// four values as stored (bf16-rounded unless the output is fp32).
+__device__ __forceinline__ f32x4 splitk_reduce_quad(const seer_gemm_desc& p, int m, int n) {
     const float* ws = reinterpret_cast<const float*>(p.workspace) + (int64_t)m * p.N + n;
     f32x4 a = *reinterpret_cast<const f32x4*>(ws);
+#pragma unroll 4
     for (int z = 1; z < p.splits; ++z) {
         const f32x4 b = *reinterpret_cast<const f32x4*>(ws + (int64_t)z * p.M * p.N);
 #pragma unroll
@@ -931,12 +983,63 @@ __global__ void __launch_bounds__(256) seer_splitk_reduce_kernel(const seer_gemm
     }
     if (p.epilogue & SEER_EPI_OUT_F32) {
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
-    } else {
-        u32x2 o;
-        o[0] = pack2(v[0], v[1]);
-        o[1] = pack2(v[2], v[3]);
-        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + n) = o;
+        return f32x4{v[0], v[1], v[2], v[3]};
     }
+    u32x2 o;
+    o[0] = pack2(v[0], v[1]);
+    o[1] = pack2(v[2], v[3]);
+    *reinterpret_cast<u32x2*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + n) = o;
+    return f32x4{__builtin_bit_cast(float, o[0] << 16), __builtin_bit_cast(float, o[0] & 0xffff0000u),
+                 __builtin_bit_cast(float, o[1] << 16), __builtin_bit_cast(float, o[1] & 0xffff0000u)};
+}
+
+__global__ void __launch_bounds__(256) seer_splitk_reduce_kernel(const seer_gemm_desc p) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int n4 = p.N / 4;
+    if (idx >= (int64_t)p.M * n4) return;
+    const int m = (int)(idx / n4);
+    const int n = (int)(idx - (int64_t)m * n4) * 4;
+    (void)splitk_reduce_quad(p, m, n);
+}
+
+// the same pass with column sums (seer_gemm_desc::colsum): a block owns splitk_cs_rows(M) rows x 256 columns, thread -> (column
+// quad, row lane) with the rows of a lane added in order, the four row lanes of a column added in order by its thread;
+// colsum[ceil(M / rows)][N][2].  Few rows (the 4x4 / 8x8 levels): one row per thread, as many blocks as the plain reduce pass --
+// at 16 rows per block the 384-row convs ran 120 blocks of 64-deep load chains, +12 us (profiles/r02_gn_colsums.log).
+__host__ __device__ inline int splitk_cs_rows(int M) { return M >= 2048 ? 16 : 4; }
+__global__ void __launch_bounds__(256) seer_splitk_reduce_colsum_kernel(const seer_gemm_desc p) {
+    __shared__ float part[4][64][8];
+    const int cq = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int n = (blockIdx.x * 64 + cq) * 4;
+    const int cs_rows = splitk_cs_rows(p.M);
+    const int mb = blockIdx.y * cs_rows;
+    float sm[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+    if (n < p.N) {
+        for (int m = mb + rl; m < min(mb + cs_rows, p.M); m += 4) {
+            const f32x4 v = splitk_reduce_quad(p, m, n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sm[r] += v[r]; sq[r] += v[r] * v[r]; }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { part[rl][cq][r * 2] = sm[r]; part[rl][cq][r * 2 + 1] = sq[r]; }
+    __syncthreads();
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col < p.N) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a += part[k][threadIdx.x >> 2][(threadIdx.x & 3) * 2];
+            b += part[k][threadIdx.x >> 2][(threadIdx.x & 3) * 2 + 1];
+        }
+        *reinterpret_cast<f32x2*>(p.colsum + ((int64_t)blockIdx.y * p.N + col) * 2) = f32x2{a, b};
+    }
+}
+
+// the kernel's `staged` condition, host side: column sums are taken from the staged bf16 tile
+bool colsum_store_ok(const seer_gemm_desc& d) {
+    return !(d.epilogue & (SEER_EPI_OUT_F32 | SEER_EPI_TRANS_OUT | SEER_EPI_GEGLU)) && d.ldc % 8 == 0 && d.N % 8 == 0 &&
+           (reinterpret_cast<uintptr_t>(d.C) & 15) == 0 && (d.batch <= 1 || (d.strideC % 8) == 0);
 }
 
 // one flag per tile instantiation, at namespace scope (no function-local statics in the library): the dynamic-LDS opt-in of its
@@ -966,6 +1069,7 @@ int launch_tile(const seer_gemm_desc& d, hipStream_t st) {
     const bool conv = d.mode == SEER_GEMM_CONV3X3;
     const bool geglu = (d.epilogue & SEER_EPI_GEGLU) != 0;
     if (conv && geglu) return SEER_EINVAL;
+    if (d.colsum && (geglu || !tile_colsum_ok<BM, BN, NS, WM, WN>() || !colsum_store_ok(d))) return SEER_EINVAL;
     if (conv) {
         hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, true, false, false, NS, WM, WN>), grid, dim3(64 * WM * WN), lds, st, d);
     } else if (geglu) {
@@ -990,8 +1094,15 @@ int launch_split_tile(const seer_gemm_desc& d, hipStream_t st) {
     else
         hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, false, true, NS>), grid, dim3(256), lds, st, d);
     SEER_LAUNCH_CHECK();
-    const int64_t n = (int64_t)d.M * (d.N / 4);
-    hipLaunchKernelGGL(seer_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d);
+    if (d.colsum) {
+        if (d.epilogue & (SEER_EPI_OUT_F32 | SEER_EPI_TRANS_OUT | SEER_EPI_GEGLU)) return SEER_EINVAL;
+        const int cs_rows = splitk_cs_rows(d.M);
+        hipLaunchKernelGGL(seer_splitk_reduce_colsum_kernel, dim3((unsigned)((d.N + 255) / 256),
+                           (unsigned)((d.M + cs_rows - 1) / cs_rows)), dim3(256), 0, st, d);
+    } else {
+        const int64_t n = (int64_t)d.M * (d.N / 4);
+        hipLaunchKernelGGL(seer_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d);
+    }
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }
@@ -1084,39 +1195,8 @@ int prepare(seer_gemm_desc& d, int* splits) {
     return SEER_OK;
 }
 
-}  // namespace
-
-extern "C" int64_t seer_gemm_workspace_bytes(const seer_gemm_desc* desc) {
-    if (!desc) return SEER_EINVAL;
-    seer_gemm_desc d = *desc;
-    if (d.tile == SEER_TILE_WS || d.tile == SEER_TILE_AUTO_TILED) d.tile = SEER_TILE_AUTO;
-    int s = 1;
-    const int rc = prepare(d, &s);
-    if (rc != SEER_OK) return rc;
-    return s > 1 ? (int64_t)s * d.M * d.N * (int64_t)sizeof(float) : 0;
-}
-
-extern "C" int seer_gemm_bf16(const seer_gemm_desc* desc, void* stream) {
-    if (!desc) return SEER_EINVAL;
-    seer_gemm_desc d = *desc;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int requested = d.tile;       // WS / AUTO_TILED are AUTO as far as tile and split-K selection go
-    if (requested == SEER_TILE_WS || requested == SEER_TILE_AUTO_TILED) d.tile = SEER_TILE_AUTO;
-    int s = 1;
-    const int rc = prepare(d, &s);
-    if (rc != SEER_OK) return rc;
-    if (s > 1 && d.workspace && d.workspace_bytes >= (int64_t)s * d.M * d.N * (int64_t)sizeof(float)) {
-        d.splits = s;
-        return launch_split(d, st);
-    }
-    d.splits = 1;
-    d.tile = desc->tile;            // prepare() may have picked a split tile; unsplit launches choose their own below
-    if (seer_gemm_ws_eligible(d) && (requested == SEER_TILE_WS || (requested == SEER_TILE_AUTO && seer_gemm_ws_profitable(d)))) {
-        const int rc_ws = seer_gemm_ws_launch(d, st);
-        if (rc_ws != SEER_ENOSYS) return rc_ws;
-    }
-    if (requested == SEER_TILE_WS || requested == SEER_TILE_AUTO_TILED) d.tile = SEER_TILE_AUTO;   // the tile kernel picks its own
-
+// the tile an unsplit, non-weight-stationary launch of `d` runs (d.tile, or the AUTO choice)
+int resolve_tile(const seer_gemm_desc& d) {
     int tile = d.tile;
     if (tile == SEER_TILE_AUTO) {
         // from the MI355X sweep (profiles/r01_gemm_tile_sweep.log): LDS-direct 2-stage 128x128 wherever it fills the chip,
@@ -1141,25 +1221,94 @@ extern "C" int seer_gemm_bf16(const seer_gemm_desc* desc, void* stream) {
         else if (nk >= 12) tile = SEER_TILE_G64x64_3;
         else tile = SEER_TILE_64x64;
     }
+    return tile;
+}
+
+template <int BM_, int BN_, int NS_, int WM_ = 2, int WN_ = 2>
+struct TileTag { static constexpr int BM = BM_, BN = BN_, NS = NS_, WM = WM_, WN = WN_; };
+
+template <class F>
+int dispatch_tile(int tile, F&& f) {
     switch (tile) {
-        case SEER_TILE_128x128: return launch_tile<128, 128, 0>(d, st);
-        case SEER_TILE_128x64: return launch_tile<128, 64, 0>(d, st);
-        case SEER_TILE_64x64: return launch_tile<64, 64, 0>(d, st);
-        case SEER_TILE_G128x128_2: return launch_tile<128, 128, 2>(d, st);
-        case SEER_TILE_G128x128_3: return launch_tile<128, 128, 3>(d, st);
-        case SEER_TILE_G128x64_3: return launch_tile<128, 64, 3>(d, st);
-        case SEER_TILE_G64x64_3: return launch_tile<64, 64, 3>(d, st);
-        case SEER_TILE_G64x64_4: return launch_tile<64, 64, 4>(d, st);
-        case SEER_TILE_G64x64_5: return launch_tile<64, 64, 5>(d, st);
-        case SEER_TILE_G128x64_4: return launch_tile<128, 64, 4>(d, st);
-        case SEER_TILE_G128x160_2: return launch_tile<128, 160, 2>(d, st);
-        case SEER_TILE_G64x160_3: return launch_tile<64, 160, 3>(d, st);
-        case SEER_TILE_G256x128_2: return launch_tile<256, 128, 2, 4>(d, st);
-        case SEER_TILE_G256x64_3: return launch_tile<256, 64, 3, 4>(d, st);
-        case SEER_TILE_G256x256_2: return launch_tile<256, 256, 2, 2, 4>(d, st);
-        case SEER_TILE_G96x160_2: return launch_tile<96, 160, 2>(d, st);
-        case SEER_TILE_G96x160_3: return launch_tile<96, 160, 3>(d, st);
-        case SEER_TILE_G96x128_2: return launch_tile<96, 128, 2>(d, st);
+        case SEER_TILE_128x128: return f(TileTag<128, 128, 0>{});
+        case SEER_TILE_128x64: return f(TileTag<128, 64, 0>{});
+        case SEER_TILE_64x64: return f(TileTag<64, 64, 0>{});
+        case SEER_TILE_G128x128_2: return f(TileTag<128, 128, 2>{});
+        case SEER_TILE_G128x128_3: return f(TileTag<128, 128, 3>{});
+        case SEER_TILE_G128x64_3: return f(TileTag<128, 64, 3>{});
+        case SEER_TILE_G64x64_3: return f(TileTag<64, 64, 3>{});
+        case SEER_TILE_G64x64_4: return f(TileTag<64, 64, 4>{});
+        case SEER_TILE_G64x64_5: return f(TileTag<64, 64, 5>{});
+        case SEER_TILE_G128x64_4: return f(TileTag<128, 64, 4>{});
+        case SEER_TILE_G128x160_2: return f(TileTag<128, 160, 2>{});
+        case SEER_TILE_G64x160_3: return f(TileTag<64, 160, 3>{});
+        case SEER_TILE_G256x128_2: return f(TileTag<256, 128, 2, 4>{});
+        case SEER_TILE_G256x64_3: return f(TileTag<256, 64, 3, 4>{});
+        case SEER_TILE_G256x256_2: return f(TileTag<256, 256, 2, 2, 4>{});
+        case SEER_TILE_G96x160_2: return f(TileTag<96, 160, 2>{});
+        case SEER_TILE_G96x160_3: return f(TileTag<96, 160, 3>{});
+        case SEER_TILE_G96x128_2: return f(TileTag<96, 128, 2>{});
         default: return SEER_EINVAL;
     }
+}
+
+}  // namespace
+
+extern "C" int64_t seer_gemm_workspace_bytes(const seer_gemm_desc* desc) {
+    if (!desc) return SEER_EINVAL;
+    seer_gemm_desc d = *desc;
+    if (d.tile == SEER_TILE_WS || d.tile == SEER_TILE_AUTO_TILED) d.tile = SEER_TILE_AUTO;
+    int s = 1;
+    const int rc = prepare(d, &s);
+    if (rc != SEER_OK) return rc;
+    return s > 1 ? (int64_t)s * d.M * d.N * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int32_t seer_gemm_colsum_rows(const seer_gemm_desc* desc) {
+    if (!desc) return 0;
+    seer_gemm_desc d = *desc;
+    const int requested = d.tile;
+    if (requested == SEER_TILE_WS || requested == SEER_TILE_AUTO_TILED) d.tile = SEER_TILE_AUTO;
+    int s = 1;
+    if (prepare(d, &s) != SEER_OK) return 0;
+    if (!colsum_store_ok(d)) return 0;
+    if (s > 1 && d.workspace && d.workspace_bytes >= (int64_t)s * d.M * d.N * (int64_t)sizeof(float))
+        return d.batch <= 1 ? splitk_cs_rows(d.M) : 0;
+    d.splits = 1;
+    d.tile = desc->tile;
+    if (requested == SEER_TILE_WS || requested == SEER_TILE_AUTO_TILED) d.tile = SEER_TILE_AUTO;
+    const int rows = dispatch_tile(resolve_tile(d), [&](auto t) {
+        using T = decltype(t);
+        return tile_colsum_ok<T::BM, T::BN, T::NS, T::WM, T::WN>() ? (int)T::BM : 0;
+    });
+    return rows > 0 ? rows : 0;           // an unknown tile code comes back as a negative status
+}
+
+extern "C" int seer_gemm_bf16(const seer_gemm_desc* desc, void* stream) {
+    if (!desc) return SEER_EINVAL;
+    seer_gemm_desc d = *desc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int requested = d.tile;       // WS / AUTO_TILED are AUTO as far as tile and split-K selection go
+    if (requested == SEER_TILE_WS || requested == SEER_TILE_AUTO_TILED) d.tile = SEER_TILE_AUTO;
+    int s = 1;
+    const int rc = prepare(d, &s);
+    if (rc != SEER_OK) return rc;
+    if (s > 1 && d.workspace && d.workspace_bytes >= (int64_t)s * d.M * d.N * (int64_t)sizeof(float)) {
+        d.splits = s;
+        return launch_split(d, st);
+    }
+    d.splits = 1;
+    d.tile = desc->tile;            // prepare() may have picked a split tile; unsplit launches choose their own below
+    if (!d.colsum && seer_gemm_ws_eligible(d) &&
+        (requested == SEER_TILE_WS || (requested == SEER_TILE_AUTO && seer_gemm_ws_profitable(d)))) {
+        const int rc_ws = seer_gemm_ws_launch(d, st);
+        if (rc_ws != SEER_ENOSYS) return rc_ws;
+    }
+    if (requested == SEER_TILE_WS || requested == SEER_TILE_AUTO_TILED) d.tile = SEER_TILE_AUTO;   // the tile kernel picks its own
+
+    const int tile = resolve_tile(d);
+    return dispatch_tile(tile, [&](auto t) {
+        using T = decltype(t);
+        return launch_tile<T::BM, T::BN, T::NS, T::WM, T::WN>(d, st);
+    });
 }

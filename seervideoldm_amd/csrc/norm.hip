@@ -94,6 +94,62 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restric
     if (lane == 0) stats[w] = acc;
 }
 
+// stats[b][g][2] from per-tile column sums (seer_gemm_desc::colsum): one BLOCK per (b, g); thread t adds the (tile, channel)
+// partials t, t + 256, ... of source 1, then of source 2 (four independent loads in flight per thread), the 64 lane sums of a
+// wave meet in a fixed butterfly and wave 0 adds the four wave sums in order: deterministic, no atomics
+struct GnColsumSrc {
+    const float* cs;
+    int C, phases, tiles;
+};
+__global__ void __launch_bounds__(256) gn_colsum_finalize_kernel(GnColsumSrc s1, GnColsumSrc s2, int batch, int groups,
+                                                                 float* __restrict__ stats) {
+    __shared__ float wsum[4][2];
+    const int w = blockIdx.x;                                // b * groups + g
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int b = w / groups, g = w - b * groups;
+    const int cpg = (s1.C + s2.C) / groups;
+    const int c_lo = g * cpg, c_hi = c_lo + cpg;
+    float sm = 0.f, sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const GnColsumSrc& s = k == 0 ? s1 : s2;
+        const int base = k == 0 ? 0 : s1.C;                  // first concat channel of this source
+        const int a = max(c_lo, base) - base, e = min(c_hi, base + s.C) - base;
+        if (s.C == 0 || e <= a) continue;
+        const int nch = e - a, tpb = s.tiles / batch;
+        const int items = s.phases * tpb * nch;
+        auto item = [&](int i) -> f32x2 {
+            const int t = i / nch, ch = i - t * nch;
+            const int ph = t / tpb, tl = t - ph * tpb;
+            return *reinterpret_cast<const f32x2*>(s.cs + (((int64_t)ph * s.tiles + b * tpb + tl) * s.C + a + ch) * 2);
+        };
+        int i = tid;
+        for (; i + 768 < items; i += 1024) {
+            const f32x2 v0 = item(i), v1 = item(i + 256), v2 = item(i + 512), v3 = item(i + 768);
+            sm += v0[0]; sq += v0[1];
+            sm += v1[0]; sq += v1[1];
+            sm += v2[0]; sq += v2[1];
+            sm += v3[0]; sq += v3[1];
+        }
+        for (; i < items; i += 256) {
+            const f32x2 v = item(i);
+            sm += v[0];
+            sq += v[1];
+        }
+    }
+    sm = wave_sum(sm);
+    sq = wave_sum(sq);
+    if (lane == 0) {
+        wsum[tid >> 6][0] = sm;
+        wsum[tid >> 6][1] = sq;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        stats[(int64_t)w * 2] = ((wsum[0][0] + wsum[1][0]) + wsum[2][0]) + wsum[3][0];
+        stats[(int64_t)w * 2 + 1] = ((wsum[0][1] + wsum[1][1]) + wsum[2][1]) + wsum[3][1];
+    }
+}
+
 __global__ void __launch_bounds__(256) gn_apply_kernel(const bf16* __restrict__ x1, const bf16* __restrict__ x2,
                                                        GnGeom g, int64_t rows_per_batch, int groups,
                                                        const float* __restrict__ stats, float inv_count, float eps,
@@ -318,6 +374,20 @@ extern "C" int seer_groupnorm_stats(const void* x1, int32_t C1, const void* x2, 
     SEER_LAUNCH_CHECK();
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)((batch * groups * 2 + 3) / 4)), dim3(256), 0, st, workspace, g.nblk, groups,
                        batch, stats);
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int seer_groupnorm_stats_from_colsums(const float* cs1, int32_t C1, int32_t phases1, int32_t tiles1,
+                                                 const float* cs2, int32_t C2, int32_t phases2, int32_t tiles2,
+                                                 int32_t batch, int32_t groups, float* stats, void* stream) {
+    if (!cs1 || !stats || batch <= 0 || groups <= 0 || C1 <= 0 || phases1 <= 0 || tiles1 <= 0 || tiles1 % batch) return SEER_EINVAL;
+    if (!cs2) C2 = 0;
+    if (C2 < 0 || (C2 > 0 && (phases2 <= 0 || tiles2 <= 0 || tiles2 % batch))) return SEER_EINVAL;
+    if ((C1 + C2) % groups) return SEER_EINVAL;
+    const GnColsumSrc s1{cs1, C1, phases1, tiles1}, s2{cs2, C2, C2 ? phases2 : 0, C2 ? tiles2 : 0};
+    hipLaunchKernelGGL(gn_colsum_finalize_kernel, dim3((unsigned)(batch * groups)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), s1, s2, batch, groups, stats);
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }

@@ -35,11 +35,23 @@ def _req(t: torch.Tensor, dtype, name: str):
         raise _lib.SeerHipError(f"{name}: tensor must be on a ROCm device (no CPU fallback)")
 
 
+class ColSums:
+    """Per-tile column sums a GEMM / conv left next to its output (seer_gemm_desc::colsum): buf [phases, tiles, C, 2] fp32 =
+    (sum, sum of squares) of the stored bf16 values over each tile's rows.  groupnorm_stats_from_colsums turns them into
+    GroupNorm statistics without a pass over the activations."""
+    __slots__ = ("buf", "C", "phases", "tiles")
+
+    def __init__(self, buf: torch.Tensor, C_: int, phases: int, tiles: int):
+        self.buf, self.C, self.phases, self.tiles = buf, C_, phases, tiles
+
+
 # ------------------------------------------------------------------------------------------------------------
 def gemm(a: torch.Tensor, w: torch.Tensor, *, bias=None, residual=None, rowvec=None, rows_per_batch=0,
          a2: Optional[torch.Tensor] = None, geglu=False, silu=False, out_f32=False, out: Optional[torch.Tensor] = None,
-         tile=0, splits=0, rotary=None, col_scale=None) -> torch.Tensor:
+         tile=0, splits=0, rotary=None, col_scale=None, colsum_batch=0) -> torch.Tensor:
     """out[M,N] = epi(a[M,K1] | a2[M,K-K1]) @ w[N,K]^T ; a/a2 may be row-strided views (last dim contiguous).
+    colsum_batch = B > 0: the output feeds a GroupNorm over B batch elements -- out.colsums is set to the ColSums the launch
+    left (or None when this launch cannot produce them; the caller then runs groupnorm_stats on the output).
     rotary = (cos_sin table, tokens_per_batch, pos_offset, head_dim, rot_dim, cols): rotate columns < cols in the epilogue.
     col_scale = (factor, cols): multiply output columns < cols by factor (the q columns of a projection carry the softmax
     scale * log2(e) for attention(..., q_prescaled=True))."""
@@ -88,12 +100,16 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias=None, residual=None, rowvec=N
     d.batch = 1
     d.tile = tile
     d.splits = splits
-    _launch_gemm(d, a.device, "seer_gemm_bf16")
+    cs = _launch_gemm(d, a.device, "seer_gemm_bf16", colsum_batch)
+    if colsum_batch:
+        out.colsums = cs
     return out
 
 
-def _launch_gemm(d: GemmDesc, device, what: str) -> None:
-    """split-K needs a caller-provided fp32 workspace (the library never allocates): ask, allocate, launch."""
+def _launch_gemm(d: GemmDesc, device, what: str, colsum_batch: int = 0) -> Optional[ColSums]:
+    """split-K needs a caller-provided fp32 workspace (the library never allocates): ask, allocate, launch.
+    colsum_batch > 0: also ask for per-tile column sums when the launch can produce them and no tile straddles two of the
+    colsum_batch batch elements the M rows (of each phase) are split into."""
     lib = _lib.load()
     nbytes = lib.seer_gemm_workspace_bytes(C.byref(d))
     if nbytes < 0:
@@ -101,7 +117,16 @@ def _launch_gemm(d: GemmDesc, device, what: str) -> None:
     if nbytes > 0:
         ws = torch.empty((nbytes // 4,), device=device, dtype=torch.float32)
         d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
+    cs = None
+    if colsum_batch > 0 and d.M % colsum_batch == 0:
+        rows = lib.seer_gemm_colsum_rows(C.byref(d))
+        if rows > 0 and (d.M // colsum_batch) % rows == 0:
+            phases, tiles = max(int(d.batch), 1), d.M // rows
+            buf = torch.empty((phases, tiles, d.N, 2), device=device, dtype=torch.float32)
+            d.colsum = buf.data_ptr()
+            cs = ColSums(buf, int(d.N), phases, tiles)
     check(lib.seer_gemm_bf16(C.byref(d), _stream()), what)
+    return cs
 
 
 def gemm_batched(a: torch.Tensor, w: torch.Tensor, *, trans_out=False, out: Optional[torch.Tensor] = None,
@@ -134,7 +159,7 @@ def gemm_batched(a: torch.Tensor, w: torch.Tensor, *, trans_out=False, out: Opti
 
 def conv3x3(x: torch.Tensor, w: torch.Tensor, n_img: int, Hin: int, Win: int, *, stride=1, upsample=False,
             bias=None, residual=None, rowvec=None, rows_per_batch=0, out: Optional[torch.Tensor] = None,
-            tile=0, splits=0, pad_after_only=False) -> torch.Tensor:
+            tile=0, splits=0, pad_after_only=False, colsum_batch=0) -> torch.Tensor:
     """x: channels-last [n_img*Hin*Win, Cin] bf16; w: [Cout, 9*Cin] ((ky,kx,ci) order). Returns [n_img*Ho*Wo, Cout].
     pad_after_only: zero padding of one row / column only after the image (the VAE encoder's Downsample)."""
     _req(x, bf16, "x"); _req(w, bf16, "w")
@@ -167,12 +192,14 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, n_img: int, Hin: int, Win: int, *,
     d.batch = 1
     d.tile = tile
     d.splits = splits
-    _launch_gemm(d, x.device, "seer_gemm_bf16(conv3x3)")
+    cs = _launch_gemm(d, x.device, "seer_gemm_bf16(conv3x3)", colsum_batch)
+    if colsum_batch:
+        out.colsums = cs
     return out
 
 
 def conv_up2x(x: torch.Tensor, w4: torch.Tensor, n_img: int, Hin: int, Win: int, *, bias=None,
-              out: Optional[torch.Tensor] = None, tile=0) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, tile=0, colsum_batch=0) -> torch.Tensor:
     """nearest-2x upsample + conv3x3 (Upsample3D, resnet.py:52-57) as four 2x2 phase convs in one launch.
     x: channels-last [n_img*Hin*Win, Cin] bf16; w4: [4, Cout, 4*Cin] from weights.pack_conv3x3_up_phases.
     Returns [n_img*2Hin*2Win, Cout]."""
@@ -194,7 +221,9 @@ def conv_up2x(x: torch.Tensor, w4: torch.Tensor, n_img: int, Hin: int, Win: int,
     d.batch = 4
     d.tile = tile
     d.splits = 1
-    _launch_gemm(d, x.device, "seer_gemm_bf16(conv_up2x)")
+    cs = _launch_gemm(d, x.device, "seer_gemm_bf16(conv_up2x)", colsum_batch)
+    if colsum_batch:
+        out.colsums = cs
     return out
 
 
@@ -290,6 +319,16 @@ def groupnorm_stats(x1: torch.Tensor, x2: Optional[torch.Tensor], batch: int, gr
     ws = torch.empty((nws,), device=x1.device, dtype=torch.float32)
     check(lib.seer_groupnorm_stats(_p(x1), x1.shape[1], _p(x2), C2, batch, rows, groups, _p(stats), _p(ws),
                                    _stream()), "seer_groupnorm_stats")
+    return stats
+
+
+def groupnorm_stats_from_colsums(cs1: ColSums, cs2: Optional[ColSums], batch: int, groups: int,
+                                 stats: torch.Tensor) -> torch.Tensor:
+    """The statistics of groupnorm_stats from the column sums the producers of x1 (and its concat partner x2) left."""
+    check(_lib.load().seer_groupnorm_stats_from_colsums(
+        _p(cs1.buf), cs1.C, cs1.phases, cs1.tiles, _p(cs2.buf) if cs2 is not None else None,
+        cs2.C if cs2 is not None else 0, cs2.phases if cs2 is not None else 0, cs2.tiles if cs2 is not None else 0,
+        batch, groups, _p(stats), _stream()), "seer_groupnorm_stats_from_colsums")
     return stats
 
 

@@ -74,6 +74,12 @@ class TimedOps:
         base = getattr(self._base, name)
         if name in ("groupnorm_stats",):
             return self._bw(name, lambda x1, x2, *a, **k: 2 * (x1.numel() + (0 if x2 is None else x2.numel())))
+        if name == "groupnorm_stats_from_colsums":
+            # the column-sum form of the same statistics: timed under the same class, bytes = the partials it reads
+            def f(cs1, cs2, *a, **k):
+                nb = 4 * (cs1.buf.numel() + (0 if cs2 is None else cs2.buf.numel()))
+                return self._timed("groupnorm_stats", 0.0, nb, base, cs1, cs2, *a, **k)
+            return f
         if name in ("groupnorm_apply",):
             return self._bw(name, lambda x1, x2, *a, **k: 4 * (x1.numel() + (0 if x2 is None else x2.numel())))
         if name in ("layernorm",):

@@ -197,6 +197,10 @@ class _Engine:
         self.heads = self.cfg.attention_head_dim
         self.G = self.cfg.norm_num_groups
         self.eps = self.cfg.norm_eps
+        # GroupNorm statistics from the producers' column sums (ops.ColSums) instead of a pass over the activations;
+        # SEER_GN_COLSUMS=0 keeps the two-stage reduction everywhere (A/B runs)
+        self.gn_colsums = os.environ.get("SEER_GN_COLSUMS", "1") != "0"
+        self.gn_from_colsums = 0
         self.w: Dict[str, torch.Tensor] = {}
         self._pack(sd)
         self._rot_cache: Dict[Tuple, torch.Tensor] = {}
@@ -269,7 +273,15 @@ class _Engine:
         ops = self.ops
         stats = self._stats_arena[self._stats_i]
         self._stats_i += 1
-        ops.groupnorm_stats(x1, x2, B, self.G, stats)
+        # statistics from the column sums the producing GEMM / conv left next to its output (ops.ColSums) when every source
+        # has them: no pass over the activations; otherwise the two-stage reduction over x1 | x2
+        cs1 = getattr(x1, "colsums", None)
+        cs2 = getattr(x2, "colsums", None) if x2 is not None else None
+        if self.gn_colsums and cs1 is not None and (x2 is None or cs2 is not None):
+            ops.groupnorm_stats_from_colsums(cs1, cs2, B, self.G, stats)
+            self.gn_from_colsums += 1
+        else:
+            ops.groupnorm_stats(x1, x2, B, self.G, stats)
         C = x1.shape[1] + (0 if x2 is None else x2.shape[1])
         count = rows_pb * (C // self.G)
         if self.shard is not None:
@@ -284,16 +296,17 @@ class _Engine:
         rows_pb = Fr * H * W
         off, n = self.temb_slices[p]
         temb = self._temb[:, off:off + n]
+        cb = B if self.gn_colsums else 0        # outputs that feed a GroupNorm leave their column sums behind
         h = self._gn(x, skip, B, rows_pb, p + ".norm1", self.eps, True)
         h = ops.conv3x3(h, w[p + ".conv1.weight"], B * Fr, H, W, bias=w[p + ".conv1.bias"], rowvec=temb,
-                        rows_per_batch=rows_pb)
+                        rows_per_batch=rows_pb, colsum_batch=cb)
         h = self._gn(h, None, B, rows_pb, p + ".norm2", self.eps, True)
         if (p + ".conv_shortcut.weight") in w:
             sc = ops.gemm(x, w[p + ".conv_shortcut.weight"], a2=skip, bias=w[p + ".conv_shortcut.bias"])
         else:
             assert skip is None
             sc = x
-        return ops.conv3x3(h, w[p + ".conv2.weight"], B * Fr, H, W, bias=w[p + ".conv2.bias"], residual=sc)
+        return ops.conv3x3(h, w[p + ".conv2.weight"], B * Fr, H, W, bias=w[p + ".conv2.bias"], residual=sc, colsum_batch=cb)
 
     def _ff(self, tb, h_rows):
         ops, w = self.ops, self.w
@@ -332,7 +345,8 @@ class _Engine:
         ops.attention(q, kv[:, :C], kv[:, C:], a, batch=B * Fr, heads=heads, head_dim=d, Sq=HW, Sk=L, q_prescaled=True)
         ops.gemm(a, w[tb + ".attn2.to_out.0.weight"], bias=w[tb + ".attn2.to_out.0.bias"], residual=h, out=h)
         self._ff(tb, h)
-        return ops.gemm(h, w[p + ".proj_out.weight"], bias=w[p + ".proj_out.bias"], residual=x)
+        return ops.gemm(h, w[p + ".proj_out.weight"], bias=w[p + ".proj_out.bias"], residual=x,
+                        colsum_batch=B if self.gn_colsums else 0)
 
     def _rotary_table(self, tb, T):
         freqs = self.w[tb + ".attn1.rotary_emb.freqs"]
@@ -385,7 +399,8 @@ class _Engine:
         elif skip_f < Fr:
             for b in range(B):
                 self._ff(tb, h[b * Fr * HW + skip_f * HW:(b + 1) * Fr * HW])
-        return ops.gemm(h, w[p + ".proj_out.weight"], bias=w[p + ".proj_out.bias"], residual=x)
+        return ops.gemm(h, w[p + ".proj_out.weight"], bias=w[p + ".proj_out.bias"], residual=x,
+                        colsum_batch=B if self.gn_colsums else 0)
 
     # ---- the schedule ---------------------------------------------------------------------------------------------
     def n_groupnorms(self):
@@ -400,6 +415,7 @@ class _Engine:
         self._ctx, self._ctx_len = ctx_bf16, ctx_len
         self._stats_arena = torch.empty((self.n_groupnorms(), B, self.G, 2), device=sample.device, dtype=torch.float32)
         self._stats_i = 0
+        self.gn_from_colsums = 0        # GroupNorms of this forward that took their statistics from column sums
         emb = ops.timestep_embedding(t, boc[0], self.cfg.flip_sin_to_cos, self.cfg.freq_shift)
         emb = ops.linear_smallm(emb, w["time_embedding.linear_1.weight"], w["time_embedding.linear_1.bias"], silu_out=True)
         emb = ops.linear_smallm(emb, w["time_embedding.linear_2.weight"], w["time_embedding.linear_2.bias"])
@@ -418,7 +434,7 @@ class _Engine:
                 skips.append(x)
             if i < n - 1:
                 x = ops.conv3x3(x, w[f"{p}.downsamplers.0.conv.weight"], B * Fr, geo[2], geo[3], stride=2,
-                                bias=w[f"{p}.downsamplers.0.conv.bias"])
+                                bias=w[f"{p}.downsamplers.0.conv.bias"], colsum_batch=B if self.gn_colsums else 0)
                 geo = (B, Fr, (geo[2] - 1) // 2 + 1, (geo[3] - 1) // 2 + 1)
                 skips.append(x)
         x = self._resnet("mid_block.resnets.0", x, None, geo)
@@ -434,7 +450,7 @@ class _Engine:
                     x = self._temporal_transformer(f"{p}.temporal_attentions.{j}", x, geo, cond_frame)
             if i < n - 1:
                 x = ops.conv_up2x(x, w[f"{p}.upsamplers.0.conv.weight_up4"], B * Fr, geo[2], geo[3],
-                                  bias=w[f"{p}.upsamplers.0.conv.bias"])
+                                  bias=w[f"{p}.upsamplers.0.conv.bias"], colsum_batch=B if self.gn_colsums else 0)
                 geo = (B, Fr, geo[2] * 2, geo[3] * 2)
         x = self._gn(x, None, B, Fr * geo[2] * geo[3], "conv_norm_out", self.eps, True)
         return ops.conv_out(x, w["conv_out.weight"], w["conv_out.bias"], B, Fr, geo[2], geo[3])

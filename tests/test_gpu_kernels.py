@@ -655,6 +655,115 @@ def test_groupnorm(device, B, rows, C1, C2, silu):
     _close(y, ref.permute(0, 2, 1).reshape(B * rows, Ct), what="groupnorm")
 
 
+def _colsum_reference(y, B, groups):
+    """(sum, sumsq) per (b, group) of the bf16 tensor y [B*rows, C] in float64."""
+    rows, Ct = y.shape[0] // B, y.shape[1]
+    v = y.double().reshape(B, rows, groups, Ct // groups)
+    return torch.stack([v.sum(dim=(1, 3)), (v * v).sum(dim=(1, 3))], -1)
+
+
+@pytest.mark.parametrize("kind,B,shape,tile", [
+    ("conv", 2, (4, 32, 32, 320, 320, 1), 0),          # 96x160 / 128x160 tile, bias + row vector + residual
+    ("conv", 2, (6, 16, 16, 640, 640, 1), 0),          # split-K reduce with column sums
+    ("conv", 2, (4, 8, 8, 1280, 1280, 1), 0),          # split-K, 16-row partials over 64-row batch elements x frames
+    ("conv", 2, (4, 32, 32, 320, 320, 2), 0),          # stride 2 (downsampler)
+    ("conv", 3, (3, 16, 16, 320, 640, 1), 5),          # 128x128 tile, batch of 3
+    ("conv", 2, (4, 16, 16, 320, 320, 1), 2),          # register-staged 64x64
+    ("gemm", 2, (4096, 320, 320), 0),                  # proj_out + residual, short K
+    ("gemm", 2, (2048, 640, 640), 0),
+    ("gemm", 2, (1024, 1280, 1280), 0),
+    ("gemm", 2, (6144, 640, 640), 7),                  # 128x64 ring
+    ("up", 2, (4, 8, 8, 640, 640), 0),                 # four phase convs
+    ("up", 2, (2, 16, 16, 320, 320), 0),
+])
+def test_groupnorm_stats_from_colsums(device, kind, B, shape, tile):
+    """The column sums a GEMM / conv leaves next to its output give the same GroupNorm statistics as the pass over the output
+    (seer_groupnorm_stats), and both match float64 sums of the stored bf16 values."""
+    from seervideoldm_amd import ops
+    G = 32
+    if kind == "conv":
+        n_img, H, W, Ci, Co, stride = shape
+        x = _rand((n_img * H * W, Ci), device, 1).to(bf16)
+        w = (_rand((Co, 9 * Ci), device, 2) / math.sqrt(9 * Ci)).to(bf16)
+        Ho = (H - 1) // stride + 1
+        rows_pb = n_img // B * Ho * Ho if n_img % B == 0 else None
+        if rows_pb is None:
+            pytest.skip("images do not split over the batch")
+        res = _rand((n_img * Ho * Ho, Co), device, 3).to(bf16) if stride == 1 else None
+        temb = _rand((B, Co), device, 4)
+        y = ops.conv3x3(x, w, n_img, H, W, stride=stride, bias=_rand((Co,), device, 5), residual=res, rowvec=temb,
+                        rows_per_batch=rows_pb, tile=tile, colsum_batch=B)
+    elif kind == "gemm":
+        M, N, K = shape
+        a = _rand((M, K), device, 1).to(bf16)
+        w = (_rand((N, K), device, 2) / math.sqrt(K)).to(bf16)
+        y = ops.gemm(a, w, bias=_rand((N,), device, 5), residual=_rand((M, N), device, 3).to(bf16), tile=tile, colsum_batch=B)
+    else:
+        from seervideoldm_amd.weights import pack_conv3x3_up_phases
+        n_img, H, W, Ci, Co = shape
+        x = _rand((n_img * H * W, Ci), device, 1).to(bf16)
+        w = _rand((Co, Ci, 3, 3), device, 2) / math.sqrt(9 * Ci)
+        y = ops.conv_up2x(x, pack_conv3x3_up_phases(w).to(bf16), n_img, H, W, bias=_rand((Co,), device, 5), tile=tile,
+                          colsum_batch=B)
+    cs = y.colsums
+    assert cs is not None, "this launch was expected to produce column sums"
+    got = torch.zeros((B, G, 2), device=device, dtype=torch.float32)
+    ops.groupnorm_stats_from_colsums(cs, None, B, G, got)
+    two_stage = torch.zeros_like(got)
+    ops.groupnorm_stats(y, None, B, G, two_stage)
+    ref = _colsum_reference(y, B, G)
+    scale = ref[..., 1].abs().max().item() + 1.0
+    assert (got.double() - ref).abs().max().item() <= 2e-5 * scale, (got.double() - ref).abs().max().item()
+    assert (got - two_stage).abs().max().item() <= 4e-5 * scale
+    # deterministic: a second launch leaves bit-identical sums
+    first = cs.buf.clone()
+    if kind == "gemm":
+        y2 = ops.gemm(a, w, bias=_rand((N,), device, 5), residual=_rand((M, N), device, 3).to(bf16), tile=tile, colsum_batch=B)
+        assert torch.equal(y2.colsums.buf, first) and torch.equal(y2, y)
+
+
+def test_groupnorm_stats_from_colsums_concat(device):
+    """Two sources with different producers (a conv with 96-row tiles and a split-K conv) and a group that straddles the
+    concat boundary: 640 + 320 channels in 32 groups of 30."""
+    from seervideoldm_amd import ops
+    B, n_img, H = 2, 4, 16
+    xa = _rand((n_img * H * H, 320), device, 1).to(bf16)
+    wa = (_rand((640, 9 * 320), device, 2) / math.sqrt(9 * 320)).to(bf16)
+    ya = ops.conv3x3(xa, wa, n_img, H, H, bias=_rand((640,), device, 3), colsum_batch=B)
+    a = _rand((n_img * H * H, 320), device, 4).to(bf16)
+    wb = (_rand((320, 320), device, 5) / math.sqrt(320)).to(bf16)
+    yb = ops.gemm(a, wb, bias=_rand((320,), device, 6), residual=_rand((n_img * H * H, 320), device, 7).to(bf16), colsum_batch=B)
+    assert ya.colsums is not None and yb.colsums is not None
+    got = torch.zeros((B, 32, 2), device=device, dtype=torch.float32)
+    ops.groupnorm_stats_from_colsums(ya.colsums, yb.colsums, B, 32, got)
+    ref = _colsum_reference(torch.cat([ya, yb], 1), B, 32)
+    scale = ref[..., 1].abs().max().item() + 1.0
+    assert (got.double() - ref).abs().max().item() <= 2e-5 * scale
+
+
+def test_colsums_refused_where_unsupported(device):
+    """GEGLU and fp32 outputs cannot leave column sums: the wrapper reports None (the engine then runs groupnorm_stats), and
+    a descriptor that forces them fails loudly."""
+    import ctypes as C
+    from seervideoldm_amd import _lib, ops
+    a = _rand((1024, 320), device, 1).to(bf16)
+    w = (_rand((2560, 320), device, 2) / 18).to(bf16)
+    y = ops.gemm(a, w, geglu=True, colsum_batch=2)
+    assert y.colsums is None
+    y = ops.gemm(a, w[:320].contiguous(), out_f32=True, colsum_batch=2)
+    assert y.colsums is None
+    d = _lib.GemmDesc()
+    out = torch.empty((1024, 1280), device=device, dtype=bf16)
+    buf = torch.empty((1 << 20,), device=device, dtype=torch.float32)
+    d.A, d.W, d.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    d.M, d.N, d.K, d.K1, d.lda, d.ldc, d.batch = 1024, 2560, 320, 320, 320, 1280, 1
+    d.epilogue = _lib.SEER_EPI_GEGLU
+    d.colsum = buf.data_ptr()
+    lib = _lib.load()
+    assert lib.seer_gemm_colsum_rows(C.byref(d)) == 0
+    assert lib.seer_gemm_bf16(C.byref(d), torch.cuda.current_stream().cuda_stream) != 0
+
+
 @pytest.mark.parametrize("rows,C", [(1000, 320), (513, 640), (77, 1280)])
 def test_layernorm(device, rows, C):
     from seervideoldm_amd import ops

@@ -42,7 +42,7 @@ def _epilogue(acc, bias, geglu, rowvec, rows_per_batch, silu, residual, out_f32,
 
 
 def gemm(a, w, *, bias=None, residual=None, rowvec=None, rows_per_batch=0, a2=None, geglu=False, silu=False,
-         out_f32=False, out=None, tile=0, splits=0, rotary=None, col_scale=None):
+         out_f32=False, out=None, tile=0, splits=0, rotary=None, col_scale=None, colsum_batch=0):
     A = a.float() if a2 is None else torch.cat([a.float(), a2.float()], 1)
     assert A.shape[1] % 64 == 0 and w.dtype == bf16 and a.dtype == bf16
     acc = A @ w.float().t()
@@ -72,7 +72,7 @@ def gemm_batched(a, w, *, trans_out=False, out=None, bias=None, out_f32=False, t
 
 
 def conv3x3(x, w, n_img, Hin, Win, *, stride=1, upsample=False, bias=None, residual=None, rowvec=None,
-            rows_per_batch=0, out=None, tile=0, splits=0):
+            rows_per_batch=0, out=None, tile=0, splits=0, colsum_batch=0):
     Ci, Co = x.shape[1], w.shape[0]
     assert Ci % 64 == 0 and w.shape[1] == 9 * Ci
     xi = x.float().reshape(n_img, Hin, Win, Ci).permute(0, 3, 1, 2)
@@ -83,7 +83,7 @@ def conv3x3(x, w, n_img, Hin, Win, *, stride=1, upsample=False, bias=None, resid
     return _epilogue(y, bias, False, rowvec, rows_per_batch, False, residual, False, out)
 
 
-def conv_up2x(x, w4, n_img, Hin, Win, *, bias=None, out=None, tile=0):
+def conv_up2x(x, w4, n_img, Hin, Win, *, bias=None, out=None, tile=0, colsum_batch=0):
     """the four 2x2 phase convs of weights.pack_conv3x3_up_phases, written out: phase (a, b) reads source rows y+a-1, y+a"""
     Ci, Co = x.shape[1], w4.shape[1]
     xi = F.pad(x.float().reshape(n_img, Hin, Win, Ci), (0, 0, 1, 1, 1, 1))          # zero border of one source pixel
