@@ -1176,17 +1176,22 @@ int prepare(seer_gemm_desc& d, int* splits) {
             // sliced until the grid holds ~2 blocks per CU -- the 16x16-level convs at B*F = 24 (x2), the 8x8 level (x4),
             // the 4x4 level (x16) and, with fewer frames or one CFG half per rank, the same levels sliced deeper.
             const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
+            const long blocks64 = (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
+            // a plain GEMM whose 64x64 grid already holds ~2 blocks per CU and whose K is only moderately long (the 8x8-level
+            // feed-forward output projection, K = 5120): the 5-stage 64x64 ring unsplit beats 128x128 x 4 slices + the reduce
+            // pass, 40.8 vs 47.4 us (profiles/r02_tile_sweep_fastepi.log)
+            const bool unsplit_ring = d.mode == SEER_GEMM_PLAIN && nk < 128 && blocks64 >= 384;
             int s128 = 1;
-            if (d.N % 128 == 0 && d.N >= 640 && d.M >= 256 && t128 < 256 && nk >= 64)
+            if (d.N % 128 == 0 && d.N >= 640 && d.M >= 256 && t128 < 256 && nk >= 64 && !unsplit_ring)
                 while (t128 * s128 < 400 && s128 < 16 && nk / (2 * s128) >= 11) s128 *= 2;
             if (s128 > 1 && t128 * s128 >= 200 && d.tile == SEER_TILE_AUTO) {
                 s = s128;
                 d.tile = SEER_TILE_G128x128_2;
             } else {
-                const long blocks = (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
+                const long blocks = blocks64;
                 if (blocks <= 160 && nk >= 160) s = blocks <= 40 ? 16 : 8;      // 4x4 / 8x8 level convs of a frame shard
                 else if (blocks <= 160 && nk >= 40) s = nk / 20 < 8 ? nk / 20 : 8;
-                else if (blocks <= 512 && nk >= 80) s = 4;
+                else if (blocks <= 512 && nk >= 80 && !unsplit_ring) s = 4;
                 if (s > 1 && d.tile == SEER_TILE_AUTO) d.tile = SEER_TILE_G64x64_3;
             }
         }
@@ -1208,7 +1213,10 @@ int resolve_tile(const seer_gemm_desc& d) {
         const int n128 = (d.N + 127) / 128 * 128;
         const bool n_fits_128 = (n128 - d.N) * 8 <= d.N;           // <= 12.5 % padded columns
         const long t128160 = (long)((d.M + 127) / 128) * ((d.N + 159) / 160) * d.batch;
-        if (d.N == 320 && nk >= 20 && t128160 >= 256 && !(d.epilogue & SEER_EPI_GEGLU)) {
+        if ((d.N == 320 || d.N == 960) && nk >= 5 && t128160 >= 256 && !(d.epilogue & SEER_EPI_GEGLU)) {
+            // (with the fast epilogue the 160-wide tiles also win at K = 320 .. 960, where the register-staged 64x64 tile used to:
+            //  projections of the 320-wide level 17.5 -> 15.6 / 14.4 -> 12.0 us, its 1x1 shortcuts 20.0 -> 16.2 / 26.5 -> 20.6, and
+            //  its q|k|v projection, N = 960 = 6 x 160, 32.7 (weight-stationary) -> 26.4: profiles/r02_tile_sweep_fastepi.log)
             // N = 320 in two 160-wide tiles: no padded columns, 0.45x the L2->LDS traffic of 64x64.  Rows per tile: whichever
             // of 128 / 96 leaves the last round of tiles fuller -- 24 576 rows (the 32x32 level at CFG batch 2) are 384 tiles
             // of 128 rows (1.5 per CU) but 512 of 96 rows (2 per CU): +13 % on the 320->320 conv (profiles/r01_tile96.log)
@@ -1218,6 +1226,7 @@ int resolve_tile(const seer_gemm_desc& d) {
         }
         else if (t128 >= 256 && n_fits_128 && d.N >= 640) tile = SEER_TILE_G128x128_2;
         else if (t12864 >= 256 && nk >= 10) tile = SEER_TILE_G128x64_3;
+        else if (nk >= 64) tile = SEER_TILE_G64x64_5;        // long K on few tiles: deeper ring (see prepare(), unsplit_ring)
         else if (nk >= 12) tile = SEER_TILE_G64x64_3;
         else tile = SEER_TILE_64x64;
     }

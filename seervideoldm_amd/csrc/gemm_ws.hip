@@ -341,7 +341,9 @@ bool seer_gemm_ws_eligible(const seer_gemm_desc& d) {
 // Is it also the faster kernel?  Measured on the shapes of a denoising step (profiles/r02_lab_gemm_ws8.log): yes for the wide
 // K = 320 projections (level-0 GEGLU ff.net.0 79 -> 60 us, q|k|v 37 -> 30 us); a tie at K = 640, where a wave covers only 32
 // columns; slower for N <= 640, where the 5-10 us it takes a CU to pull its W panel is not amortised over enough rows.
-bool seer_gemm_ws_profitable(const seer_gemm_desc& d) { return d.K == 320 && d.N >= 960 && d.M >= 8192; }
+// N = 960 (the q|k|v projection of the 320-wide level) went to the 160-wide tiles once their epilogue got cheap: 26.4 vs 32.7 us
+// (profiles/r02_tile_sweep_fastepi.log); the GEGLU projection (N = 2560) stays here, 58.7 vs 65.5
+bool seer_gemm_ws_profitable(const seer_gemm_desc& d) { return d.K == 320 && d.N >= 1280 && d.M >= 8192; }
 
 int seer_gemm_ws_launch(const seer_gemm_desc& d, hipStream_t st) {
     const bool geglu = (d.epilogue & SEER_EPI_GEGLU) != 0;

@@ -64,7 +64,8 @@ def test_gemm_plain(device, M, N, K, tile):
 
 
 @pytest.mark.parametrize("M,N,K,geglu,res,a2k,tile", [
-    (24576, 2560, 320, True, False, 0, 0), (24576, 960, 320, False, False, 0, 0),                  # AUTO routes these to it
+    (24576, 2560, 320, True, False, 0, 0), (24576, 1280, 320, False, False, 0, 0),                 # AUTO routes these to it
+    (24576, 960, 320, False, False, 0, 19),                                                        # (AUTO: 160-wide tiles)
     (6144, 5120, 640, True, False, 0, 19), (6144, 1920, 640, False, False, 0, 19), (24576, 320, 320, False, False, 0, 19),
     (24576, 320, 640, False, False, 320, 19), (6144, 640, 640, False, False, 320, 19),            # skip concat (two sources)
     (1000, 320, 320, False, False, 0, 19), (1283, 192, 640, False, False, 0, 19), (2049, 128, 320, True, False, 0, 19),   # row tails
