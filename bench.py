@@ -82,7 +82,7 @@ def gpu_busy(ms: float, device):
 
 def time_attention_block(device):
     """the north star's named kernel target: spatial self-attention of the 32x32 level, [B*F*heads = 192, 1024 tokens, d = 40]
-    out of the fused q|k|v projection; back-to-back launches between two HIP events on the launch stream"""
+    out of the fused q|k|v projection; back-to-back launches (one replayed HIP graph) between two HIP events on the launch stream"""
     from seervideoldm_amd import ops
     B, S, H, d = 24, 1024, 8, 40
     C = H * d
@@ -91,14 +91,23 @@ def time_attention_block(device):
     run = lambda: ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, batch=B, heads=H, head_dim=d, Sq=S, Sk=S)
     for _ in range(5):
         run()
+    torch.cuda.synchronize()
+    # 25 launches captured in one HIP graph and replayed, as the denoising step runs them: launched one by one from Python the
+    # loop is host-bound (the ctypes call costs more than the ~42 us kernel; rocprofv3 shows the kernel at 41.9 us while this
+    # function used to print 54)
+    per_graph, replays = 25, 4
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(per_graph):
+            run()
+    g.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n = 50
     e0.record()
-    for _ in range(n):
-        run()
+    for _ in range(replays):
+        g.replay()
     e1.record()
     torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) / n * 1e3
+    us = e0.elapsed_time(e1) / (per_graph * replays) * 1e3
     tf = 4.0 * B * H * S * S * d / us * 1e-6
     return dict(shape="[192, 1024, 40] bf16, non-causal", us_per_launch=round(us, 2), achieved=round(tf, 1), unit="TFLOP/s",
                 frac=round(tf / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), flops="4*BH*Sq*Sk*d")

@@ -492,6 +492,7 @@ __global__ void __launch_bounds__(256, 3) seer_attn40_kernel(const seer_attn_des
         const int qi = q0w + row;
         if (qi < p.Sq) {
             const u32x4 v = *reinterpret_cast<const u32x4*>(ost + i * 16);
+            // (plain store: the write-through form of seer_common.h measured +2-3 us on this kernel, profiles/r02_wt_stores.log)
             *reinterpret_cast<u32x4*>(Og + (int64_t)tok(qi) * p.o_ss + c * 8) = v;
         }
     }

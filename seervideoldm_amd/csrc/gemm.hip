@@ -629,7 +629,9 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
             for (int j = 0; j < TN; ++j) {
                 const int n = n0 + wn * WTN + j * 16 + fq * 4;
                 if (n >= p.N) continue;
-                *reinterpret_cast<f32x4*>(ws + (int64_t)m * p.N + n) = acc[i][j];
+                // write-through: up to 31 MB of partials per launch would otherwise sit dirty in L2 until the boundary in front
+                // of the reduce pass
+                store16_out(ws + (int64_t)m * p.N + n, __builtin_bit_cast(u32x4, acc[i][j]));
             }
         }
         PSTAMP();
@@ -884,6 +886,7 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
         __syncthreads();
         PSTAMP();
         constexpr int CPR = BNO / 8;                    // 16-byte chunks per staged row
+        const bool wt_store = p.K <= 3072;
         const int n0o = GEGLU ? (n0 >> 1) : n0;
         const int n_out = GEGLU ? (p.N >> 1) : p.N;
         // ---- column sums of the tile as stored (bf16-rounded): sum and sum of squares per output column over the tile's rows,
@@ -919,8 +922,13 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
             const int row = c / CPR, ch = c - row * CPR;
             const int m = m0 + row, n = n0o + ch * 8;
             if (((BM * CPR) % NT == 0 || c < BM * CPR) && m < p.M && n < n_out)
-                *reinterpret_cast<u32x4*>(Cb + crow(m) * p.ldc + n) =
-                    *reinterpret_cast<const u32x4*>(smem + row * CPITCH + (CSWZ ? (ch ^ (row & 15)) : ch) * 16);
+            {
+                // write-through below ~3000 of K, where the boundary write-back is a visible share of the launch (projections
+                // 11.3 -> 9.6 us, 1x1 shortcuts 15.8 -> 13.8); the long-K convs measured 1-3 % slower with it and keep plain stores
+                const u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * CPITCH + (CSWZ ? (ch ^ (row & 15)) : ch) * 16);
+                if (wt_store) store16_out(Cb + crow(m) * p.ldc + n, v);
+                else *reinterpret_cast<u32x4*>(Cb + crow(m) * p.ldc + n) = v;
+            }
         }
         if constexpr (COLSUM_OK) {
             if (p.colsum) {

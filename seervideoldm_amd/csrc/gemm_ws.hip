@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(512) seer_gemm_ws_kernel(const seer_gemm_desc 
                 if ((16 * CPR) % 64 == 0 || c < 16 * CPR) {
                     const u32x4 val = *reinterpret_cast<const u32x4*>(stg + row * SPITCH + ch * 16);
                     const unsigned voff = (unsigned)((i * 16 + row) * p.ldc + ch * 8) * 2u;
-                    if (mr < p.M && nc < n_out) *reinterpret_cast<u32x4*>(cbase + voff) = val;
+                    if (mr < p.M && nc < n_out) store16_out(cbase, voff, val);
                 }
             }
             if (full && (16 * CPR) % 64 == 0) issued += NST;

@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const bf16* __restrict__ 
                 if (silu) o = silu_f(o);
                 f[e] = o;
             }
-            *reinterpret_cast<u32x4*>(y + row * C + c0) = pack8(f);
+            store16_out(y + row * C + c0, pack8(f));
         }
     }
 }
@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const bf16* __restrict__
                 float o[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (f[i][e] - mean) * rstd * gm[i][e] + bt[i][e];
-                *reinterpret_cast<u32x4*>(y + r * ldy + ch * 8) = pack8(o);
+                store16_out(y + r * ldy + ch * 8, pack8(o));
             }
         }
     }
