@@ -312,6 +312,13 @@ def main():
         except (OSError, KeyError, ValueError) as e:
             traffic_note = str(e)[:200]
         attn_block = time_attention_block(device)
+        # the same kernel on the step's own activations (event-bracketed eager launches of the roofline passes above): the
+        # random-normal q|k|v of time_attention_block toggle more bits per MFMA operand than the synthetic-weight activations
+        # and the kernel runs at lower clocks on them (rocprofv3: 59 us in that loop, 42 us inside the step, same binary:
+        # profiles/r02_attn40_inputs.log)
+        for tag, calls, ms, _tf in timed.shape_summary():
+            if tag.startswith("attn b24 Sq1024 Sk1024 d40"):
+                attn_block["in_step_us"] = round(ms / calls * 1e3, 2)
         roofline = dict(bound="mfma", kernel="seer_gemm_kernel (bf16 MFMA GEMM / implicit-GEMM conv3x3, all tiles)",
                         achieved=round(gm["tflops"], 2), peak=MFMA_BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=round(gm["tflops"] / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), traffic=traffic,
