@@ -70,6 +70,10 @@ int main(int argc, char** argv) {
         }
         int first_round = 0;                       // blocks that entered before the first block left
         for (long long e : entries) if (e < x_lo) ++first_round;
+        if (getenv("LAB_SPAN_DUMP")) {            // one line per block: id, entry and exit relative to the first entry (10 ns ticks)
+            for (int b = 0; b < tiles; ++b)
+                if (sp[b * 2] && sp[b * 2 + 1]) printf("span %d %lld %lld\n", b, sp[b * 2] - e_lo, sp[b * 2 + 1] - e_lo);
+        }
         printf("blocks %d: first entry 0, last entry %lld, first exit %lld, last exit %lld; %d blocks entered before the first exit\n",
                nb, e_hi - e_lo, x_lo - e_lo, x_hi - e_lo, first_round);
     }

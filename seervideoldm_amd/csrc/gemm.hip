@@ -785,101 +785,101 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
         }
     } else {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * WTM + i * 16 + frow;
-        if (m >= p.M) continue;
-        const int rb = p.rowvec ? (m / p.rows_per_batch) : 0;
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * WTM + i * 16 + frow;
+            if (m >= p.M) continue;
+            const int rb = p.rowvec ? (m / p.rows_per_batch) : 0;
 #pragma unroll
-        for (int j = 0; j < TN; j += (GEGLU ? 2 : 1)) {
-            const int n = n0 + wn * WTN + j * 16 + fq * 4;   // first of 4 consecutive GEMM columns
-            if (n >= p.N) continue;
-            float v[4];
+            for (int j = 0; j < TN; j += (GEGLU ? 2 : 1)) {
+                const int n = n0 + wn * WTN + j * 16 + fq * 4;   // first of 4 consecutive GEMM columns
+                if (n >= p.N) continue;
+                float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
-            if (p.bias) {
-                f32x4 bv;
-                if constexpr (BIAS_PRE) bv = bpre[j];
-                else bv = *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += bv[r];
-            }
-            int nc = n;   // output column
-            if constexpr (GEGLU) {
-                float g[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) g[r] = acc[i][j + 1][r];
+                for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
                 if (p.bias) {
-                    f32x4 bg;
-                    if constexpr (BIAS_PRE) bg = bpre[j + 1];
-                    else bg = *reinterpret_cast<const f32x4*>(p.bias + n + 16);
+                    f32x4 bv;
+                    if constexpr (BIAS_PRE) bv = bpre[j];
+                    else bv = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) g[r] += bg[r];
+                    for (int r = 0; r < 4; ++r) v[r] += bv[r];
                 }
-                const f32x2 ge0 = gelu_erf_f2(f32x2{g[0], g[1]}), ge1 = gelu_erf_f2(f32x2{g[2], g[3]});
-                v[0] *= ge0[0]; v[1] *= ge0[1]; v[2] *= ge1[0]; v[3] *= ge1[1];
-                nc = ((n - fq * 4) >> 1) + fq * 4;
-            }
-            if (p.rowvec) {
-                f32x4 tv;
-                if (RV_PRE && rv_pre_ok) tv = rvpre[j];
-                else tv = *reinterpret_cast<const f32x4*>(p.rowvec + (int64_t)rb * p.rowvec_ld + nc);
+                int nc = n;   // output column
+                if constexpr (GEGLU) {
+                    float g[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += tv[r];
-            }
-            if (do_silu) {
+                    for (int r = 0; r < 4; ++r) g[r] = acc[i][j + 1][r];
+                    if (p.bias) {
+                        f32x4 bg;
+                        if constexpr (BIAS_PRE) bg = bpre[j + 1];
+                        else bg = *reinterpret_cast<const f32x4*>(p.bias + n + 16);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
-            }
-            if (do_rot && n < p.rot_cols) {
-                // rotary on q|k columns (attention.py:649-651): channel inside its head = n % head_dim; the lane's 4
-                // consecutive columns are two interleaved pairs (x0,x1) -> (x0 c - x1 s, x1 c + x0 s)
-                const int ch = n % p.rot_head_dim;
-                if (ch < p.rot_dim) {
-                    const int pos = m % p.rot_tokens_per_batch + p.rot_pos_offset;
-                    const f32x4 cs = *reinterpret_cast<const f32x4*>(p.rot_table + ((int64_t)pos * (p.rot_dim / 2) + ch / 2) * 2);
-                    const float a0 = v[0], b0 = v[1], a1 = v[2], b1 = v[3];
-                    v[0] = a0 * cs[0] - b0 * cs[1];
-                    v[1] = b0 * cs[0] + a0 * cs[1];
-                    v[2] = a1 * cs[2] - b1 * cs[3];
-                    v[3] = b1 * cs[2] + a1 * cs[3];
+                        for (int r = 0; r < 4; ++r) g[r] += bg[r];
+                    }
+                    const f32x2 ge0 = gelu_erf_f2(f32x2{g[0], g[1]}), ge1 = gelu_erf_f2(f32x2{g[2], g[3]});
+                    v[0] *= ge0[0]; v[1] *= ge0[1]; v[2] *= ge1[0]; v[3] *= ge1[1];
+                    nc = ((n - fq * 4) >> 1) + fq * 4;
                 }
-            }
-            if ((p.epilogue & SEER_EPI_COLSCALE) && n < p.col_scale_cols) {
+                if (p.rowvec) {
+                    f32x4 tv;
+                    if (RV_PRE && rv_pre_ok) tv = rvpre[j];
+                    else tv = *reinterpret_cast<const f32x4*>(p.rowvec + (int64_t)rb * p.rowvec_ld + nc);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= p.col_scale;
-            }
-            if (R) {
-                u32x2 rv;
-                if constexpr (RES_PRE) rv = rpre[i][j];
-                else rv = *reinterpret_cast<const u32x2*>(R + (int64_t)m * p.ldr + nc);
-                v[0] += __builtin_bit_cast(float, rv[0] << 16);
-                v[1] += __builtin_bit_cast(float, rv[0] & 0xffff0000u);
-                v[2] += __builtin_bit_cast(float, rv[1] << 16);
-                v[3] += __builtin_bit_cast(float, rv[1] & 0xffff0000u);
-            }
-            if (trans) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (out_f32) Cf[(int64_t)(nc + r) * p.ldc + m] = v[r];
-                    else Cb[(int64_t)(nc + r) * p.ldc + m] = (bf16)v[r];
+                    for (int r = 0; r < 4; ++r) v[r] += tv[r];
                 }
-            } else if (out_f32) {
-                *reinterpret_cast<f32x4*>(Cf + (int64_t)m * p.ldc + nc) = f32x4{v[0], v[1], v[2], v[3]};
-            } else {
-                u32x2 o;
-                o[0] = pack2(v[0], v[1]);
-                o[1] = pack2(v[2], v[3]);
-                if (staged) {
-                    const int row_l = wm * WTM + i * 16 + frow;
-                    const int col_l = nc - (GEGLU ? (n0 >> 1) : n0);
-                    const int cb = col_l * 2;
-                    *reinterpret_cast<u32x2*>(smem + row_l * CPITCH + (CSWZ ? (cb ^ ((row_l & 15) << 4)) : cb)) = o;
+                if (do_silu) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+                }
+                if (do_rot && n < p.rot_cols) {
+                    // rotary on q|k columns (attention.py:649-651): channel inside its head = n % head_dim; the lane's 4
+                    // consecutive columns are two interleaved pairs (x0,x1) -> (x0 c - x1 s, x1 c + x0 s)
+                    const int ch = n % p.rot_head_dim;
+                    if (ch < p.rot_dim) {
+                        const int pos = m % p.rot_tokens_per_batch + p.rot_pos_offset;
+                        const f32x4 cs = *reinterpret_cast<const f32x4*>(p.rot_table + ((int64_t)pos * (p.rot_dim / 2) + ch / 2) * 2);
+                        const float a0 = v[0], b0 = v[1], a1 = v[2], b1 = v[3];
+                        v[0] = a0 * cs[0] - b0 * cs[1];
+                        v[1] = b0 * cs[0] + a0 * cs[1];
+                        v[2] = a1 * cs[2] - b1 * cs[3];
+                        v[3] = b1 * cs[2] + a1 * cs[3];
+                    }
+                }
+                if ((p.epilogue & SEER_EPI_COLSCALE) && n < p.col_scale_cols) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= p.col_scale;
+                }
+                if (R) {
+                    u32x2 rv;
+                    if constexpr (RES_PRE) rv = rpre[i][j];
+                    else rv = *reinterpret_cast<const u32x2*>(R + (int64_t)m * p.ldr + nc);
+                    v[0] += __builtin_bit_cast(float, rv[0] << 16);
+                    v[1] += __builtin_bit_cast(float, rv[0] & 0xffff0000u);
+                    v[2] += __builtin_bit_cast(float, rv[1] << 16);
+                    v[3] += __builtin_bit_cast(float, rv[1] & 0xffff0000u);
+                }
+                if (trans) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (out_f32) Cf[(int64_t)(nc + r) * p.ldc + m] = v[r];
+                        else Cb[(int64_t)(nc + r) * p.ldc + m] = (bf16)v[r];
+                    }
+                } else if (out_f32) {
+                    *reinterpret_cast<f32x4*>(Cf + (int64_t)m * p.ldc + nc) = f32x4{v[0], v[1], v[2], v[3]};
                 } else {
-                    *reinterpret_cast<u32x2*>(Cb + crow(m) * p.ldc + nc) = o;
+                    u32x2 o;
+                    o[0] = pack2(v[0], v[1]);
+                    o[1] = pack2(v[2], v[3]);
+                    if (staged) {
+                        const int row_l = wm * WTM + i * 16 + frow;
+                        const int col_l = nc - (GEGLU ? (n0 >> 1) : n0);
+                        const int cb = col_l * 2;
+                        *reinterpret_cast<u32x2*>(smem + row_l * CPITCH + (CSWZ ? (cb ^ ((row_l & 15) << 4)) : cb)) = o;
+                    } else {
+                        *reinterpret_cast<u32x2*>(Cb + crow(m) * p.ldc + nc) = o;
+                    }
                 }
             }
         }
-    }
     }   // general epilogue
     PSTAMP();
     if (staged) {
