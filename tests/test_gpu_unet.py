@@ -221,6 +221,36 @@ def test_full_size_step_properties(device):
     assert (y2[1] - y[1]).abs().max() > 1e-3 and (y2[0] - y[0]).abs().max() <= 1e-3 * y.abs().max().item()
 
 
+def test_full_size_step_groupnorm_statistics_paths_agree(device):
+    """BASELINE config 2 shape: the step with GroupNorm statistics taken from the producers' column sums (75 of its 77
+    GroupNorms) against the same step with the two-stage pass over the activations everywhere.  Same sums in a different
+    fp32 order -- but ~300 dependent bf16 layers amplify ANY difference to the bf16 rounding floor: an input perturbed by 1e-7
+    (relative) moves the output by 1.8e-2, as far as the fp32 oracle is from either (profiles/r02_perturbation_floor.log).
+    So the two paths must agree to that floor, measured here with the two-stage path and a 1e-7 perturbation, not closer."""
+    cfg = dict(synth.SD15_UNET_CFG)
+    m = SeerUNet(**{k: v for k, v in cfg.items()})
+    sd = synth.synth_state_dict(synth.unet_param_shapes(cfg), device=device)
+    m = m.to(device)
+    m.load_state_dict(sd, strict=True)
+    del sd
+    x = _randn((2, 4, 12, 32, 32), 1).to(device)
+    c = _randn((2, 12, 77, 768), 2).to(device)
+    t = torch.tensor([981, 981], device=device)
+    y_cs = m(x, t, c, cond_frame=2)
+    eng = m._engine
+    assert eng.gn_colsums and eng.gn_from_colsums == eng.n_groupnorms() - 2, (eng.gn_from_colsums, eng.n_groupnorms())
+    eng.gn_colsums = False
+    y_two = m(x, t, c, cond_frame=2)
+    assert eng.gn_from_colsums == 0
+    floor = _rel(m(x * (1 + 1e-7 * _randn(x.shape, 9).to(device)), t, c, cond_frame=2), y_two.cpu())
+    eng.gn_colsums = True
+    rel = _rel(y_cs, y_two.cpu())
+    print(f"[property] column-sum vs two-stage GroupNorm statistics: rel_l2 {rel:.3g}; 1e-7 input perturbation: {floor:.3g}")
+    assert torch.isfinite(y_cs).all() and rel <= 1.2 * floor and floor <= REL_L2, (rel, floor)
+    del m
+    torch.cuda.empty_cache()
+
+
 def test_full_size_step_matches_oracle(device):
     """BASELINE config 2 end to end against the oracle: CFG batch 2 x 12 frames (2 conditioning) x 32^2, the full-width
     two-layers-per-block UNet (1.08 G parameters) -- the exact shape bench.py times (windows 8 / 4 / 4 / none, head dims
