@@ -91,6 +91,8 @@ int main(int argc, char** argv) {
     double total_ms = 0, total_flops = 0;
     for (const Shape& s0 : shapes) {
         Shape s = s0;
+        // LAB_MDIV=2|4: the same table for one CFG half / one CFG half of half the frames per rank (rows and images divided)
+        if (const char* md = getenv("LAB_MDIV")) { const int dv = atoi(md); if (dv > 1) { s.M /= dv; } }
         if (s.conv && s.up == 1) s.calls = 0;     // the engine runs the phase form of the three upsampler convs
         if (only && !strstr(s.name, only)) continue;
         seer_gemm_desc d;

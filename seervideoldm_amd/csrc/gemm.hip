@@ -1119,6 +1119,7 @@ int launch_split(const seer_gemm_desc& d, hipStream_t st) {
     if (d.tile == SEER_TILE_64x64) return launch_split_tile<64, 64, 0>(d, st);        // register-staged (A/B testing)
     if (d.tile == SEER_TILE_G64x64_3) return launch_split_tile<64, 64, 3>(d, st);
     if (d.tile == SEER_TILE_G128x128_2) return launch_split_tile<128, 128, 2>(d, st);
+    if (d.tile == SEER_TILE_G96x160_2) return launch_split_tile<96, 160, 2>(d, st);
     // auto: prepare() already wrote its tile choice into d.tile; anything else keeps the 64x64 ring
     return launch_split_tile<64, 64, 3>(d, st);
 }
@@ -1171,7 +1172,7 @@ int prepare(seer_gemm_desc& d, int* splits) {
     int s = 1;
     const bool can_split = d.batch == 1 && !geglu && !(d.epilogue & (SEER_EPI_TRANS_OUT | SEER_EPI_ROTARY)) &&
                            (d.tile == SEER_TILE_AUTO || d.tile == SEER_TILE_64x64 || d.tile == SEER_TILE_G64x64_3 ||
-                            d.tile == SEER_TILE_G128x128_2) &&
+                            d.tile == SEER_TILE_G128x128_2 || d.tile == SEER_TILE_G96x160_2) &&
                            d.splits != 1;
     if (can_split) {
         const int nk = d.K / BK;
@@ -1192,9 +1193,17 @@ int prepare(seer_gemm_desc& d, int* splits) {
             int s128 = 1;
             if (d.N % 128 == 0 && d.N >= 640 && d.M >= 256 && t128 < 256 && nk >= 64 && !unsplit_ring)
                 while (t128 * s128 < 400 && s128 < 16 && nk / (2 * s128) >= 11) s128 *= 2;
+            // N = 320 on half the rows (one CFG half per rank: 12 288 rows = 256 tiles of 96x160, one lone workgroup per CU, which
+            // runs a K tile no faster than two co-resident ones do): two K slices bring the second workgroup back.  3x3 convs only
+            // (K >= 2880): 47.1 -> 44.9, 84.4 -> 76.8, 128.0 -> 103.5 us; the K = 1280 GEMM loses (profiles/r02_half_rows.log)
+            const long t96160 = (long)((d.M + 95) / 96) * ((d.N + 159) / 160);
             if (s128 > 1 && t128 * s128 >= 200 && d.tile == SEER_TILE_AUTO) {
                 s = s128;
                 d.tile = SEER_TILE_G128x128_2;
+            } else if (d.N == 320 && d.mode == SEER_GEMM_CONV3X3 && t96160 >= 128 && t96160 <= 256 && nk >= 40 &&
+                       d.tile == SEER_TILE_AUTO) {
+                s = 2;
+                d.tile = SEER_TILE_G96x160_2;
             } else {
                 const long blocks = blocks64;
                 if (blocks <= 160 && nk >= 160) s = blocks <= 40 ? 16 : 8;      // 4x4 / 8x8 level convs of a frame shard
