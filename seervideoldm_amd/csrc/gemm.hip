@@ -1242,7 +1242,7 @@ int resolve_tile(const seer_gemm_desc& d) {
             tile = fill(t96160) > fill(t128160) + 0.05 ? SEER_TILE_G96x160_2 : SEER_TILE_G128x160_2;
         }
         else if (t128 >= 256 && n_fits_128 && d.N >= 640) tile = SEER_TILE_G128x128_2;
-        else if (t12864 >= 256 && nk >= 10) tile = SEER_TILE_G128x64_3;
+        else if (t12864 >= 256 && nk >= 5) tile = SEER_TILE_G128x64_3;   // (K = 320 too: 8.9 vs 9.7 us on 12 288 x 320, r02_half_rows.log)
         else if (nk >= 64) tile = SEER_TILE_G64x64_5;        // long K on few tiles: deeper ring (see prepare(), unsplit_ring)
         else if (nk >= 12) tile = SEER_TILE_G64x64_3;
         else tile = SEER_TILE_64x64;
