@@ -665,9 +665,9 @@ def _colsum_reference(y, B, groups):
 
 @pytest.mark.parametrize("kind,B,shape,tile", [
     ("conv", 2, (4, 32, 32, 320, 320, 1), 0),          # 96x160 / 128x160 tile, bias + row vector + residual
-    ("conv", 2, (6, 16, 16, 640, 640, 1), 0),          # split-K reduce with column sums
-    ("conv", 2, (4, 8, 8, 1280, 1280, 1), 0),          # split-K, 16-row partials over 64-row batch elements x frames
-    ("conv", 2, (4, 32, 32, 320, 320, 2), 0),          # stride 2 (downsampler)
+    ("conv", 2, (6, 16, 16, 640, 640, 1), 5),          # 128x128 tile, long K (AUTO would split K: no column sums there)
+    ("conv", 2, (4, 8, 8, 1280, 1280, 1), 8),          # 64x64 ring, 128 rows
+    ("conv", 2, (4, 32, 32, 320, 320, 2), 8),          # stride 2 (downsampler), 64x64 ring
     ("conv", 3, (3, 16, 16, 320, 640, 1), 5),          # 128x128 tile, batch of 3
     ("conv", 2, (4, 16, 16, 320, 320, 1), 2),          # register-staged 64x64
     ("gemm", 2, (4096, 320, 320), 0),                  # proj_out + residual, short K
@@ -693,7 +693,7 @@ def test_groupnorm_stats_from_colsums(device, kind, B, shape, tile):
         res = _rand((n_img * Ho * Ho, Co), device, 3).to(bf16) if stride == 1 else None
         temb = _rand((B, Co), device, 4)
         y = ops.conv3x3(x, w, n_img, H, W, stride=stride, bias=_rand((Co,), device, 5), residual=res, rowvec=temb,
-                        rows_per_batch=rows_pb, tile=tile, colsum_batch=B)
+                        rows_per_batch=rows_pb, tile=tile, splits=1 if tile else 0, colsum_batch=B)
     elif kind == "gemm":
         M, N, K = shape
         a = _rand((M, K), device, 1).to(bf16)
@@ -724,13 +724,13 @@ def test_groupnorm_stats_from_colsums(device, kind, B, shape, tile):
 
 
 def test_groupnorm_stats_from_colsums_concat(device):
-    """Two sources with different producers (a conv with 96-row tiles and a split-K conv) and a group that straddles the
+    """Two sources with different producers (a conv on 64x64 tiles and a GEMM on 96-row tiles) and a group that straddles the
     concat boundary: 640 + 320 channels in 32 groups of 30."""
     from seervideoldm_amd import ops
     B, n_img, H = 2, 4, 16
     xa = _rand((n_img * H * H, 320), device, 1).to(bf16)
     wa = (_rand((640, 9 * 320), device, 2) / math.sqrt(9 * 320)).to(bf16)
-    ya = ops.conv3x3(xa, wa, n_img, H, H, bias=_rand((640,), device, 3), colsum_batch=B)
+    ya = ops.conv3x3(xa, wa, n_img, H, H, bias=_rand((640,), device, 3), tile=8, splits=1, colsum_batch=B)   # (AUTO would split K)
     a = _rand((n_img * H * H, 320), device, 4).to(bf16)
     wb = (_rand((320, 320), device, 5) / math.sqrt(320)).to(bf16)
     yb = ops.gemm(a, wb, bias=_rand((320,), device, 6), residual=_rand((n_img * H * H, 320), device, 7).to(bf16), colsum_batch=B)
@@ -751,6 +751,11 @@ def test_colsums_refused_where_unsupported(device):
     w = (_rand((2560, 320), device, 2) / 18).to(bf16)
     y = ops.gemm(a, w, geglu=True, colsum_batch=2)
     assert y.colsums is None
+    # a split-K launch leaves none either (the reduce pass does not produce them)
+    xs = _rand((4 * 8 * 8, 1280), device, 7).to(bf16)
+    ws_ = (_rand((1280, 9 * 1280), device, 8) / 107).to(bf16)
+    ys = ops.conv3x3(xs, ws_, 4, 8, 8, colsum_batch=2)
+    assert ys.colsums is None
     y = ops.gemm(a, w[:320].contiguous(), out_f32=True, colsum_batch=2)
     assert y.colsums is None
     d = _lib.GemmDesc()

@@ -100,6 +100,8 @@ def test_segmented_graph_replay(device):
     x = _randn((2, 4, 3, 16, 16), 11).to(device)
     ctx = _randn((2, 3, 77, cfg["cross_attention_dim"]), 12).to(device)
     t = torch.tensor([301, 301], device=device)
+    m(x, t, ctx)                            # builds the engine
+    m._engine.gn_colsums = False            # a sharded engine keeps the two-stage GroupNorm statistics: same arithmetic here
     ref = m(x, t, ctx).clone()
     shard = parallel.attach(m, 1, 0)
     shard.debug_boundaries = True
@@ -222,8 +224,8 @@ def test_full_size_step_properties(device):
 
 
 def test_full_size_step_groupnorm_statistics_paths_agree(device):
-    """BASELINE config 2 shape: the step with GroupNorm statistics taken from the producers' column sums (75 of its 77
-    GroupNorms) against the same step with the two-stage pass over the activations everywhere.  Same sums in a different
+    """BASELINE config 2 shape: the step with GroupNorm statistics taken from the producers' column sums (where the producer is
+    an unsplit GEMM / conv) against the same step with the two-stage pass over the activations everywhere.  Same sums in a different
     fp32 order -- but ~300 dependent bf16 layers amplify ANY difference to the bf16 rounding floor: an input perturbed by 1e-7
     (relative) moves the output by 1.8e-2, as far as the fp32 oracle is from either (profiles/r02_perturbation_floor.log).
     So the two paths must agree to that floor, measured here with the two-stage path and a 1e-7 perturbation, not closer."""
@@ -238,7 +240,8 @@ def test_full_size_step_groupnorm_statistics_paths_agree(device):
     t = torch.tensor([981, 981], device=device)
     y_cs = m(x, t, c, cond_frame=2)
     eng = m._engine
-    assert eng.gn_colsums and eng.gn_from_colsums == eng.n_groupnorms() - 2, (eng.gn_from_colsums, eng.n_groupnorms())
+    # (not the GroupNorms behind conv_in or behind a split-K conv: those keep the two-stage pass)
+    assert eng.gn_colsums and eng.gn_from_colsums >= eng.n_groupnorms() // 3, (eng.gn_from_colsums, eng.n_groupnorms())
     eng.gn_colsums = False
     y_two = m(x, t, c, cond_frame=2)
     assert eng.gn_from_colsums == 0
