@@ -4,7 +4,7 @@ train.py saves, every `save_steps` optimizer steps,
 
     <output_dir>/learned_sdunet-steps-N/         accelerator.save_state(): pytorch_model.bin (SeerUNet), pytorch_model_1.bin
                                                  (FSTextTransformer), optimizer.bin (torch.optim.AdamW.state_dict()),
-                                                 scheduler.bin, random_states_0.pkl
+                                                 scheduler.bin, random_states_{rank}.pkl (torch.save, as accelerate writes it)
     <output_dir>/learned_sdunet-steps-N.pt       {"epoch", "global_step", "lr_meter", "losses_train"}  (the sidecar)
 
 and, on start, loads `learned_sdunet-steps-{saved_global_step}` + its sidecar when they exist.  `save_checkpoint` /
@@ -17,7 +17,6 @@ Host-side only: no kernels.
 from __future__ import annotations
 
 import os
-import pickle
 import random
 from typing import Dict, List, Optional
 
@@ -64,6 +63,11 @@ class RunningAverageMeter:
         if len(self.vals) > 0:
             self.val = self.vals[-1]
         self.avg, self.steps = d["avg"], d["steps"]
+
+
+def _rank() -> int:
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
 def reference_param_order(unet_trainable: List[str], fstext_names: List[str]) -> List[str]:
@@ -143,8 +147,8 @@ def save_checkpoint(tr: SeerTrainer, output_dir: str, global_step: int, epoch: i
            "torch_manual_seed": torch.get_rng_state()}
     if torch.cuda.is_available():
         rng["torch_cuda_manual_seed"] = torch.cuda.get_rng_state_all()
-    with open(os.path.join(save_path, "random_states_0.pkl"), "wb") as f:
-        pickle.dump(rng, f)
+    # accelerate's save_state writes this file with torch.save, one per process (random_states_{process_index}.pkl)
+    torch.save(rng, os.path.join(save_path, f"random_states_{_rank()}.pkl"))
     side = os.path.join(output_dir, f"learned_sdunet-steps-{global_step}.pt")
     torch.save({"epoch": epoch, "global_step": global_step, "lr_meter": lr_meter.ckpt(), "losses_train": losses_train.ckpt()}, side)
     return save_path, side
@@ -162,15 +166,20 @@ def load_checkpoint(tr: SeerTrainer, output_dir: str, saved_global_step: int, lr
         tr.fstext.load_state_dict(torch.load(os.path.join(load_path, "pytorch_model_1.bin"), map_location="cpu"), strict=True)
         tr.reload_from_modules()
         load_optimizer_state_dict(tr, torch.load(os.path.join(load_path, "optimizer.bin"), map_location="cpu", weights_only=False))
-        rp = os.path.join(load_path, "random_states_0.pkl")
+        rp = os.path.join(load_path, f"random_states_{_rank()}.pkl")
         if restore_rng and os.path.exists(rp):
-            with open(rp, "rb") as f:
-                rng = pickle.load(f)
-            random.setstate(rng["random_state"])
-            np.random.set_state(rng["numpy_random_seed"])
-            torch.set_rng_state(rng["torch_manual_seed"])
-            if torch.cuda.is_available() and "torch_cuda_manual_seed" in rng:
-                torch.cuda.set_rng_state_all(rng["torch_cuda_manual_seed"])
+            # as accelerate's load_state does: a generator state that does not fit this process (another device count, another
+            # library version) is skipped with a warning instead of failing the resume
+            try:
+                rng = torch.load(rp, map_location="cpu", weights_only=False)
+                random.setstate(rng["random_state"])
+                np.random.set_state(rng["numpy_random_seed"])
+                torch.set_rng_state(rng["torch_manual_seed"])
+                if torch.cuda.is_available() and "torch_cuda_manual_seed" in rng:
+                    torch.cuda.set_rng_state_all(rng["torch_cuda_manual_seed"])
+            except Exception as e:      # noqa: BLE001
+                import warnings
+                warnings.warn(f"could not restore the random states from {rp}: {type(e).__name__}: {e}")
     if os.path.exists(side):
         st = torch.load(side, map_location="cpu", weights_only=False)
         lr_meter.load(st["lr_meter"])

@@ -101,8 +101,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias=None, residual=None, rowvec=N
     d.tile = tile
     d.splits = splits
     cs = _launch_gemm(d, a.device, "seer_gemm_bf16", colsum_batch)
-    if colsum_batch:
-        out.colsums = cs
+    out.colsums = cs            # always assigned: a reused `out=` tensor must not keep the column sums of an earlier launch
     return out
 
 
@@ -193,8 +192,7 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, n_img: int, Hin: int, Win: int, *,
     d.tile = tile
     d.splits = splits
     cs = _launch_gemm(d, x.device, "seer_gemm_bf16(conv3x3)", colsum_batch)
-    if colsum_batch:
-        out.colsums = cs
+    out.colsums = cs            # always assigned: a reused `out=` tensor must not keep the column sums of an earlier launch
     return out
 
 
@@ -222,8 +220,7 @@ def conv_up2x(x: torch.Tensor, w4: torch.Tensor, n_img: int, Hin: int, Win: int,
     d.tile = tile
     d.splits = 1
     cs = _launch_gemm(d, x.device, "seer_gemm_bf16(conv_up2x)", colsum_batch)
-    if colsum_batch:
-        out.colsums = cs
+    out.colsums = cs            # always assigned: a reused `out=` tensor must not keep the column sums of an earlier launch
     return out
 
 

@@ -66,6 +66,10 @@ def test_resume_equals_the_uninterrupted_run(tmp_path):
     assert os.path.basename(path) == "learned_sdunet-steps-2" and os.path.basename(side) == "learned_sdunet-steps-2.pt"
     assert sorted(os.listdir(path)) == ["optimizer.bin", "pytorch_model.bin", "pytorch_model_1.bin", "random_states_0.pkl",
                                         "scheduler.bin"]
+    # accelerate's save_state / load_state write and read the random states with torch.save / torch.load: the file must be
+    # a torch archive (a plain pickle is rejected there with "Invalid magic number"), holding accelerate's four keys
+    rng = torch.load(os.path.join(path, "random_states_0.pkl"), map_location="cpu", weights_only=False)
+    assert {"random_state", "numpy_random_seed", "torch_manual_seed"} <= set(rng)
     sd = torch.load(side, weights_only=False)
     assert set(sd) == {"epoch", "global_step", "lr_meter", "losses_train"} and sd["global_step"] == 2
     assert set(sd["losses_train"]) == {"vals", "avg", "steps"} and sd["losses_train"]["steps"] == [1, 2]
@@ -79,6 +83,29 @@ def test_resume_equals_the_uninterrupted_run(tmp_path):
     for P_a, P_c in ((a.pu, c.pu), (a.pf, c.pf)):
         assert torch.equal(P_a.p, P_c.p) and torch.equal(P_a.m, P_c.m) and torch.equal(P_a.v, P_c.v)
     assert ls_c.vals == ls_a.vals and abs(ls_c.avg - ls_a.avg) < 1e-12
+
+
+def test_random_states_round_trip_and_tolerate_a_foreign_file(tmp_path):
+    """the generator states come back through torch.load; a file this process cannot use is skipped with a warning"""
+    import random
+    import warnings
+    out = str(tmp_path)
+    tr = _fresh()
+    lm, ls = RunningAverageMeter(), RunningAverageMeter()
+    torch.manual_seed(1234)
+    random.seed(99)
+    path, _ = save_checkpoint(tr, out, global_step=1, epoch=0, lr_meter=lm, losses_train=ls)
+    want_t, want_r = torch.rand(3), random.random()
+    torch.manual_seed(1)
+    random.seed(1)
+    load_checkpoint(tr, out, 1, lm, ls)
+    assert torch.equal(torch.rand(3), want_t) and random.random() == want_r
+    with open(os.path.join(path, "random_states_0.pkl"), "wb") as f:
+        f.write(b"not a torch archive")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert load_checkpoint(tr, out, 1, lm, ls) is not None
+    assert any("random states" in str(x.message) for x in w)
 
 
 def test_optimizer_bin_loads_into_torch_adamw(tmp_path):
