@@ -27,13 +27,28 @@ CFG_MINI = dict(block_out_channels=(320, 320, 320, 320), layers_per_block=1, cro
 class _Trace:
     """proxy of seervideoldm_amd.ops that keeps a clone of every tensor an op returns (or writes through out=)"""
 
-    def __init__(self, ops):
+    def __init__(self, ops, qkv_tile=0, mode=""):
         self._ops = ops
         self.rec = []
         self.on = False
+        self.qkv_tile = qkv_tile
+        self.mode = mode
 
     def __getattr__(self, name):
         f = getattr(self._ops, name)
+        if name == "gemm" and (self.qkv_tile or self.mode):
+            g, tile, mode = f, self.qkv_tile, self.mode
+
+            def f(a, w, **k):                      # the q|k|v projections on another tile kernel / with another epilogue
+                if w.shape[0] == 960 and tile:
+                    k["tile"] = tile
+                if mode == "nocs":                 # no column scale anywhere
+                    k.pop("col_scale", None)
+                elif mode == "allcs" and "col_scale" not in k and not k.get("geglu"):
+                    k["col_scale"] = (1.0, 64)     # x * 1.0f: same values, but every plain GEMM takes the column-scale pass
+                elif mode == "norot":
+                    k.pop("rotary", None)
+                return g(a, w, **k)
         if not callable(f) or name in ("ColSums", "qk_prescale") or not self.on:
             return f
         import torch
@@ -54,7 +69,6 @@ class _Trace:
 
 def worker_main(args):
     sys.path.insert(0, str(ROOT))
-    os.environ["SEER_GN_COLSUMS"] = str(args.colsums)
     import torch
     from seervideoldm_amd import SeerUNet, synth
     from seervideoldm_amd import ops as hip_ops
@@ -76,8 +90,9 @@ def worker_main(args):
     m = SeerUNet(**CFG_MINI).to(dev)
     m.load_state_dict(synth.synth_state_dict(synth.unet_param_shapes(CFG_MINI), device=dev), strict=True)
     m.eval()
-    tr = _Trace(hip_ops)
-    if args.trace:
+    m.gn_colsums = bool(args.colsums)
+    tr = _Trace(hip_ops, args.qkv_tile, args.mode)
+    if args.trace or args.qkv_tile or args.mode:
         m._ops_backend = tr
     g = torch.Generator().manual_seed(7)
     B, Fr, H = args.batch, args.frames, args.latent
@@ -93,8 +108,10 @@ def worker_main(args):
         torch.cuda.synchronize()
         return out
 
-    tr.on = bool(args.trace)
     m.use_graph = False
+    m(x, t, ctx, cond_frame=0)                     # fills the per-prompt caches (cross-attention K|V, rotary tables)
+    tr.on = bool(args.trace)
+    tr.rec = []
     ref = m(x, t, ctx, cond_frame=0).clone()
     torch.cuda.synchronize()
     ref_rec = tr.rec
@@ -135,6 +152,13 @@ def worker_main(args):
                             idx = [i for i, r in enumerate(rec) if r[2] is a][0]
                             d = (a.float() - b.float()).abs()
                             msg += f"; first differing op #{idx} {name}{shape}: {int((a != b).sum())} elements, max abs {float(d.max()):.3g}"
+                            if a.dim() == 2:
+                                nz = (a != b).nonzero()
+                                rows, cols = sorted(set(nz[:, 0].tolist())), sorted(set(nz[:, 1].tolist()))
+                                msg += f"\n        rows {rows} cols {cols}; ops around: " + \
+                                    " ".join(f"{r[0]}{r[1]}" for r in rec[max(idx - 3, 0):idx + 3])
+                                r0, c0 = int(nz[0, 0]), int(nz[0, 1])
+                                msg += f"\n        got  {a[r0, c0:c0 + 8].float().tolist()}\n        want {b[r0, c0:c0 + 8].float().tolist()}"
                             break
                 print(msg, flush=True)
     dt = time.time() - t0
@@ -147,7 +171,6 @@ def worker_main(args):
 
 def worker_noise(args):
     sys.path.insert(0, str(ROOT))
-    os.environ["SEER_GN_COLSUMS"] = str(args.colsums)
     import torch
     from seervideoldm_amd import SeerUNet, synth
     dev = torch.device("cuda:0")
@@ -161,8 +184,54 @@ def worker_noise(args):
     m.use_graph = bool(args.noise_graph)
     stop = Path(args.stop_file)
     n = 0
+    fn = lambda: m(x, t, ctx, cond_frame=0)
+    if args.noise_kind == "gemm":
+        from seervideoldm_amd import ops
+        a = torch.randn((4096, 1280), device=dev).to(torch.bfloat16)
+        w = torch.randn((1280, 1280), device=dev).to(torch.bfloat16)
+        o = torch.empty((4096, 1280), device=dev, dtype=torch.bfloat16)
+        fn = lambda: ops.gemm(a, w, out=o)
+    elif args.noise_kind == "copy":
+        a = torch.randn((64 << 20,), device=dev)
+        b = torch.empty_like(a)
+        fn = lambda: b.copy_(a)
+    elif args.noise_kind == "small":
+        a = torch.randn((1024,), device=dev)
+        fn = lambda: a.add_(1.0)
+    elif args.noise_kind in ("qkvgemm", "attn", "ln", "conv", "gn", "wattn"):
+        from seervideoldm_amd import ops
+        bf = torch.bfloat16
+        a = torch.randn((512, 320), device=dev).to(bf)
+        w = (torch.randn((960, 320), device=dev) * 0.05).to(bf)
+        w9 = (torch.randn((320, 2880), device=dev) * 0.02).to(bf)
+        gam, bet = torch.ones(320, device=dev), torch.zeros(320, device=dev)
+        qkv = torch.randn((512, 960), device=dev).to(bf)
+        att = torch.empty((512, 320), device=dev, dtype=bf)
+        stats = torch.empty((1, 32, 2), device=dev)
+        kinds = {
+            "qkvgemm": lambda: ops.gemm(a, w, col_scale=(0.228, 320)),
+            "attn": lambda: ops.attention(qkv[:, :320], qkv[:, 320:640], qkv[:, 640:], att, batch=2, heads=8, head_dim=40, Sq=256,
+                                          Sk=256, q_prescaled=True),
+            "wattn": lambda: ops.attention(qkv[:, :320], qkv[:, 320:640], qkv[:, 640:], att, batch=1, heads=8, head_dim=40,
+                                           Sq=2 * 16, Sk=2 * 16, causal=True, window=(4, 2, 16, 16), q_prescaled=True),
+            "ln": lambda: ops.layernorm(a, gam, bet),
+            "conv": lambda: ops.conv3x3(a, w9, 2, 16, 16),
+            "gn": lambda: ops.groupnorm_apply(a, None, 1, 32, ops.groupnorm_stats(a, None, 1, 32, stats), 512 * 10, 1e-5, gam, bet, True),
+        }
+        one = kinds[args.noise_kind]
+        one()
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for _ in range(50):
+                one()
+        fn = gr.replay if args.noise_graph else one
+    fn()
+    torch.cuda.synchronize()
+    if args.ready_file:
+        Path(args.ready_file).write_text("ready")
     while not stop.exists():
-        m(x, t, ctx, cond_frame=0)
+        fn()
         n += 1
         if n % 16 == 0:
             torch.cuda.synchronize()
@@ -182,6 +251,10 @@ def main():
     ap.add_argument("--frames", type=int, default=2)
     ap.add_argument("--latent", type=int, default=16)
     ap.add_argument("--noise-graph", type=int, default=1)
+    ap.add_argument("--qkv-tile", type=int, default=0)
+    ap.add_argument("--noise-kind", default="model")
+    ap.add_argument("--mode", default="")
+    ap.add_argument("--ready-file", default="")
     ap.add_argument("--stop-file", default="/tmp/exp_flake.stop")
     args = ap.parse_args()
     if args.role == "main":

@@ -1,8 +1,8 @@
-set -x
 cd $GRAFT_REPO_ROOT
-python scripts/exp_flake.py --colsums 1 --cotenant 1 --iters 1000 2>&1 | grep -v Warning | tail -40 > gpurun_out/flake_a.log
-python scripts/exp_flake.py --colsums 0 --cotenant 1 --iters 1000 2>&1 | tail -40 > gpurun_out/flake_b.log
-python scripts/exp_flake.py --colsums 1 --cotenant 0 --iters 1000 2>&1 | tail -40 > gpurun_out/flake_c.log
-python scripts/exp_flake.py --colsums 1 --cotenant 1 --trace 1 --iters 1000 2>&1 | tail -60 > gpurun_out/flake_d.log
-python scripts/exp_flake.py --colsums 1 --cotenant 1 --poison 1 --iters 300 2>&1 | tail -40 > gpurun_out/flake_e.log
-tail -n 8 gpurun_out/flake_*.log
+L=gpurun_out/flake9.log; : > $L
+F="RESULT\|first differing op ("
+python scripts/exp_flake.py --colsums 1 --cotenant 1 --trace 1 --iters 3000 2>&1 | grep "$F" >> $L
+python scripts/exp_flake.py --colsums 1 --cotenant 1 --trace 0 --iters 3000 2>&1 | grep "$F" >> $L
+python scripts/exp_flake.py --colsums 1 --cotenant 1 --trace 0 --iters 1500 --batch 2 --frames 3 --latent 32 2>&1 | grep "$F" >> $L
+cat $L
+python -m pytest tests/test_gpu_cotenant.py tests/test_gpu_kernels.py -x -q -k "cotenant or colsum or rotary" 2>&1 | tail -15

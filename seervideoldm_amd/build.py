@@ -56,8 +56,9 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     hipcc = _hipcc()
     objdir = LIBDIR / "obj"
     objdir.mkdir(exist_ok=True)
+    # -save-temps=obj: the device assembly of every source stays next to its object for asm_check (the other temporaries go)
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", f"-I{ROOT / 'include'}", f"-I{CSRC}",
-             "-fno-gpu-rdc", "-Wno-unused-result"]
+             "-fno-gpu-rdc", "-Wno-unused-result", "-save-temps=obj"]
 
     def compile_one(src: str) -> Path:
         obj = objdir / (src + ".o")
@@ -67,10 +68,22 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+        stem = src.split(".")[0]
+        for tmp in objdir.glob(f"{stem}-*"):
+            if not tmp.name.endswith("gfx950.s"):
+                tmp.unlink()
+        for tmp in objdir.glob(f"{src}-*"):
+            tmp.unlink()
         return obj
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, SOURCES))
+    # the assembly rules of asm_check.py: instruction forms that misbehaved on MI355X, and the register discipline of the
+    # inline-asm LDS reads in attention40.hip
+    from .asm_check import check_directory
+    problems = check_directory(objdir)
+    if problems:
+        raise RuntimeError("assembly check failed (seervideoldm_amd/asm_check.py):\n" + "\n".join(problems[:40]))
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

@@ -41,10 +41,10 @@ __global__ void __launch_bounds__(256) rotary_kernel(bf16* __restrict__ x, int64
         const float* t = cs + ((int64_t)pos * half + ch * 4) * 2;
 #pragma unroll
         for (int pi = 0; pi < 4; ++pi) {
-            const float c = t[2 * pi], s = t[2 * pi + 1];
-            const float a = f[2 * pi], b = f[2 * pi + 1];
-            f[2 * pi] = a * c - b * s;        // t*cos + rotate_half(t)*sin, rotate_half: (x0, x1) -> (-x1, x0)
-            f[2 * pi + 1] = b * c + a * s;
+            // t*cos + rotate_half(t)*sin, rotate_half: (x0, x1) -> (-x1, x0); rot_pair (seer_common.h) says why it is not written out
+            const f32x2 r = rot_pair(f32x2{f[2 * pi], f[2 * pi + 1]}, t[2 * pi], t[2 * pi + 1]);
+            f[2 * pi] = r[0];
+            f[2 * pi + 1] = r[1];
         }
         *reinterpret_cast<u32x4*>(ptr) = pack8(f);
     }

@@ -57,6 +57,7 @@ namespace {
 
 constexpr int BK = 64;
 
+
 #ifndef SEER_GEMM_EARLY_REFILL
 #define SEER_GEMM_EARLY_REFILL 1
 #endif
@@ -618,6 +619,10 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
         //  the burst, and spreading the pieces delays the next tile's arrival at the barrier.)
     }
 
+#ifdef SEER_GEMM_EPI_NOP
+    // bug-hunt build (scripts/exp_flake.py): a long pause between the last MFMA of the K loop and the first read of an accumulator
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#endif
     // ---- split-K: raw fp32 partial tile to the workspace slice of this K range; the reduce kernel does the epilogue
     if constexpr (SPLIT) {
         float* ws = reinterpret_cast<float*>(p.workspace) + (int64_t)blockIdx.z * p.M * p.N;
@@ -734,11 +739,9 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
                     for (int j = 0; j < TN; ++j) {
                         if (tj[j] >= 0) {
                             const f32x4 cs = *reinterpret_cast<const f32x4*>(trow + tj[j]);
-                            const float a0 = acc[i][j][0], b0 = acc[i][j][1], a1 = acc[i][j][2], b1 = acc[i][j][3];
-                            acc[i][j][0] = a0 * cs[0] - b0 * cs[1];
-                            acc[i][j][1] = b0 * cs[0] + a0 * cs[1];
-                            acc[i][j][2] = a1 * cs[2] - b1 * cs[3];
-                            acc[i][j][3] = b1 * cs[2] + a1 * cs[3];
+                            const f32x2 r01 = rot_pair(f32x2{acc[i][j][0], acc[i][j][1]}, cs[0], cs[1]);
+                            const f32x2 r23 = rot_pair(f32x2{acc[i][j][2], acc[i][j][3]}, cs[2], cs[3]);
+                            acc[i][j] = f32x4{r01[0], r01[1], r23[0], r23[1]};
                         }
                     }
                 }
@@ -837,11 +840,9 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
                     if (ch < p.rot_dim) {
                         const int pos = m % p.rot_tokens_per_batch + p.rot_pos_offset;
                         const f32x4 cs = *reinterpret_cast<const f32x4*>(p.rot_table + ((int64_t)pos * (p.rot_dim / 2) + ch / 2) * 2);
-                        const float a0 = v[0], b0 = v[1], a1 = v[2], b1 = v[3];
-                        v[0] = a0 * cs[0] - b0 * cs[1];
-                        v[1] = b0 * cs[0] + a0 * cs[1];
-                        v[2] = a1 * cs[2] - b1 * cs[3];
-                        v[3] = b1 * cs[2] + a1 * cs[3];
+                        const f32x2 r01 = rot_pair(f32x2{v[0], v[1]}, cs[0], cs[1]);
+                        const f32x2 r23 = rot_pair(f32x2{v[2], v[3]}, cs[2], cs[3]);
+                        v[0] = r01[0]; v[1] = r01[1]; v[2] = r23[0]; v[3] = r23[1];
                     }
                 }
                 if ((p.epilogue & SEER_EPI_COLSCALE) && n < p.col_scale_cols) {
@@ -1010,6 +1011,42 @@ __global__ void __launch_bounds__(256) seer_splitk_reduce_kernel(const seer_gemm
     (void)splitk_reduce_quad(p, m, n);
 }
 
+// the same pass with column sums (seer_gemm_desc::colsum): a block owns splitk_cs_rows(M) rows x 256 columns, thread -> (column
+// quad, row lane) with the rows of a lane added in order, the four row lanes of a column added in order by its thread;
+// colsum[ceil(M / rows)][N][2].  Few rows (the 4x4 / 8x8 levels): one row per thread, as many blocks as the plain reduce pass --
+// at 16 rows per block the 384-row convs ran 120 blocks of 64-deep load chains, +12 us (profiles/r02_gn_colsums.log).
+// (Round 2 took this kernel out when a two-process test differed in the last bits with column sums on; the cause was elsewhere --
+// a packed-fp32 instruction form in the rotary epilogue, profiles/r03_flake_root_cause.md -- and it is back.)
+__host__ __device__ inline int splitk_cs_rows(int M) { return M >= 2048 ? 16 : 4; }
+__global__ void __launch_bounds__(256) seer_splitk_reduce_colsum_kernel(const seer_gemm_desc p) {
+    __shared__ float part[4][64][8];
+    const int cq = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int n = (blockIdx.x * 64 + cq) * 4;
+    const int cs_rows = splitk_cs_rows(p.M);
+    const int mb = blockIdx.y * cs_rows;
+    float sm[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+    if (n < p.N) {
+        for (int m = mb + rl; m < min(mb + cs_rows, p.M); m += 4) {
+            const f32x4 v = splitk_reduce_quad(p, m, n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sm[r] += v[r]; sq[r] += v[r] * v[r]; }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { part[rl][cq][r * 2] = sm[r]; part[rl][cq][r * 2 + 1] = sq[r]; }
+    __syncthreads();
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col < p.N) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a += part[k][threadIdx.x >> 2][(threadIdx.x & 3) * 2];
+            b += part[k][threadIdx.x >> 2][(threadIdx.x & 3) * 2 + 1];
+        }
+        *reinterpret_cast<f32x2*>(p.colsum + ((int64_t)blockIdx.y * p.N + col) * 2) = f32x2{a, b};
+    }
+}
+
 // the kernel's `staged` condition, host side: column sums are taken from the staged bf16 tile
 bool colsum_store_ok(const seer_gemm_desc& d) {
     return !(d.epilogue & (SEER_EPI_OUT_F32 | SEER_EPI_TRANS_OUT | SEER_EPI_GEGLU)) && d.ldc % 8 == 0 && d.N % 8 == 0 &&
@@ -1060,10 +1097,6 @@ int launch_tile(const seer_gemm_desc& d, hipStream_t st) {
 
 template <int BM, int BN, int NS>
 int launch_split_tile(const seer_gemm_desc& d, hipStream_t st) {
-    // column sums come from the staged C tile of an unsplit launch only.  A reduce pass that also produced them was built and
-    // taken out again: with it the two-process replay test differed from eager in 5 of 61 runs and in 0 of 42 without it
-    // (profiles/r02_colsum_flake.log); the cause was not found, so the GroupNorms behind split-K launches keep the two-stage pass
-    if (d.colsum) return SEER_EINVAL;
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, 1, d.splits);
     const size_t lds = (size_t)(NS == 0 ? 2 : NS) * (BM + BN) * BK * sizeof(bf16);
@@ -1072,8 +1105,15 @@ int launch_split_tile(const seer_gemm_desc& d, hipStream_t st) {
     else
         hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, false, true, NS>), grid, dim3(256), lds, st, d);
     SEER_LAUNCH_CHECK();
-    const int64_t n = (int64_t)d.M * (d.N / 4);
-    hipLaunchKernelGGL(seer_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d);
+    if (d.colsum) {
+        if (d.epilogue & (SEER_EPI_OUT_F32 | SEER_EPI_TRANS_OUT | SEER_EPI_GEGLU)) return SEER_EINVAL;
+        const int cs_rows = splitk_cs_rows(d.M);
+        hipLaunchKernelGGL(seer_splitk_reduce_colsum_kernel, dim3((unsigned)((d.N + 255) / 256),
+                           (unsigned)((d.M + cs_rows - 1) / cs_rows)), dim3(256), 0, st, d);
+    } else {
+        const int64_t n = (int64_t)d.M * (d.N / 4);
+        hipLaunchKernelGGL(seer_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d);
+    }
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }
@@ -1261,7 +1301,8 @@ extern "C" int32_t seer_gemm_colsum_rows(const seer_gemm_desc* desc) {
     int s = 1;
     if (prepare(d, &s) != SEER_OK) return 0;
     if (!colsum_store_ok(d)) return 0;
-    if (s > 1 && d.workspace && d.workspace_bytes >= (int64_t)s * d.M * d.N * (int64_t)sizeof(float)) return 0;   // split-K
+    if (s > 1 && d.workspace && d.workspace_bytes >= (int64_t)s * d.M * d.N * (int64_t)sizeof(float))
+        return d.batch <= 1 ? splitk_cs_rows(d.M) : 0;          // split-K: the reduce pass leaves them
     d.splits = 1;
     d.tile = desc->tile;
     if (requested == SEER_TILE_WS || requested == SEER_TILE_AUTO_TILED) d.tile = SEER_TILE_AUTO;

@@ -68,6 +68,19 @@ __device__ __forceinline__ void store16_out(void* base, unsigned voff, const u32
 #endif
 }
 
+// One interleaved rotary pair (x0, x1) -> (x0 c - x1 s, x1 c + x0 s) as two WHOLE packed operations, fma(x, (c, c), swap(x) * (-s, s)),
+// with the roundings of the scalar form fma(x0, c, -(x1 s)), fma(x1, c, x0 s).  The scalar form is not just slower: hipcc's SLP
+// vectoriser turns four such lines into v_pk_fma_f32 instructions that use one half of a register pair, among them
+//     v_pk_fma_f32 v[36:37], v[76:77], v[36:37], v[84:85] op_sel:[0,1,0] op_sel_hi:[1,0,0]      (destination = the half-swapped source)
+// and on MI355X that instruction returned the ADDEND ALONE (product term lost) in lanes 48..63 about once per 1000 launches of the
+// rotary q|k|v projection whenever a second process ran the same network on the GPU, and never otherwise: 2 700 wrong launches in
+// 3.5 M against 0 in 3.5 M with this form (profiles/r03_flake_root_cause.md; scripts/check_asm.py fails the build if the in-place
+// half-swapped form appears in any kernel again).
+__device__ __forceinline__ f32x2 rot_pair(f32x2 x, float c, float s) {
+    const f32x2 t = f32x2{x[1], x[0]} * f32x2{-s, s};
+    return __builtin_elementwise_fma(x, f32x2{c, c}, t);
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // exact-erf GELU (F.gelu default, attention.py:785-793) without libm and with ONE transcendental:
 //     gelu(x) = relu(x) - |x| * Phi(-|x|),      Phi(-a) = 0.5 * erfc(a / sqrt 2) = 2^(a * R(a) - 1)

@@ -84,6 +84,7 @@ class SeerUNet(nn.Module):
         self._slice_size = None
         self.use_graph = False
         self._shard = None              # parallel.FrameShard when attached (seervideoldm_amd/parallel.py)
+        self.gn_colsums = True          # GroupNorm statistics from the producing GEMM's column sums (read by prepare())
         self._ops_backend = hip_ops     # tests may inject tests/torch_ops_backend.py to exercise the host logic on CPU
         self._ctx_slice = None
 
@@ -197,11 +198,10 @@ class _Engine:
         self.heads = self.cfg.attention_head_dim
         self.G = self.cfg.norm_num_groups
         self.eps = self.cfg.norm_eps
-        # GroupNorm statistics from the producers' column sums (ops.ColSums) instead of a pass over the activations;
-        # SEER_GN_COLSUMS=0 keeps the two-stage reduction everywhere (A/B runs).  Sharded engines (parallel.attach) always keep
-        # it: with column sums on, the two-process replay == eager test differed in 7 of ~100 runs (0 of 45 with them off); the
-        # cause was not found (profiles/r02_colsum_flake.log), the single-process engine never showed it
-        self.gn_colsums = os.environ.get("SEER_GN_COLSUMS", "1") != "0"
+        # GroupNorm statistics from the producers' column sums (ops.ColSums) instead of a pass over the activations, in every
+        # engine (single-process and sharded: a shard all-reduces the same (sum, sumsq) either way).  `model.gn_colsums = False`
+        # before prepare() keeps the two-stage reduction everywhere (A/B runs, tests).
+        self.gn_colsums = bool(getattr(model, "gn_colsums", True))
         self.gn_from_colsums = 0
         self.w: Dict[str, torch.Tensor] = {}
         self._pack(sd)
@@ -279,7 +279,7 @@ class _Engine:
         # has them: no pass over the activations; otherwise the two-stage reduction over x1 | x2
         cs1 = getattr(x1, "colsums", None)
         cs2 = getattr(x2, "colsums", None) if x2 is not None else None
-        if self.gn_colsums and self.shard is None and cs1 is not None and (x2 is None or cs2 is not None):
+        if self.gn_colsums and cs1 is not None and (x2 is None or cs2 is not None):
             ops.groupnorm_stats_from_colsums(cs1, cs2, B, self.G, stats)
             self.gn_from_colsums += 1
         else:
@@ -298,7 +298,7 @@ class _Engine:
         rows_pb = Fr * H * W
         off, n = self.temb_slices[p]
         temb = self._temb[:, off:off + n]
-        cb = B if (self.gn_colsums and self.shard is None) else 0   # outputs that feed a GroupNorm leave their column sums behind
+        cb = B if self.gn_colsums else 0   # outputs that feed a GroupNorm leave their column sums behind
         h = self._gn(x, skip, B, rows_pb, p + ".norm1", self.eps, True)
         h = ops.conv3x3(h, w[p + ".conv1.weight"], B * Fr, H, W, bias=w[p + ".conv1.bias"], rowvec=temb,
                         rows_per_batch=rows_pb, colsum_batch=cb)
@@ -348,7 +348,7 @@ class _Engine:
         ops.gemm(a, w[tb + ".attn2.to_out.0.weight"], bias=w[tb + ".attn2.to_out.0.bias"], residual=h, out=h)
         self._ff(tb, h)
         return ops.gemm(h, w[p + ".proj_out.weight"], bias=w[p + ".proj_out.bias"], residual=x,
-                        colsum_batch=B if (self.gn_colsums and self.shard is None) else 0)
+                        colsum_batch=B if self.gn_colsums else 0)
 
     def _rotary_table(self, tb, T):
         freqs = self.w[tb + ".attn1.rotary_emb.freqs"]
@@ -402,7 +402,7 @@ class _Engine:
             for b in range(B):
                 self._ff(tb, h[b * Fr * HW + skip_f * HW:(b + 1) * Fr * HW])
         return ops.gemm(h, w[p + ".proj_out.weight"], bias=w[p + ".proj_out.bias"], residual=x,
-                        colsum_batch=B if (self.gn_colsums and self.shard is None) else 0)
+                        colsum_batch=B if self.gn_colsums else 0)
 
     # ---- the schedule ---------------------------------------------------------------------------------------------
     def n_groupnorms(self):
@@ -436,7 +436,7 @@ class _Engine:
                 skips.append(x)
             if i < n - 1:
                 x = ops.conv3x3(x, w[f"{p}.downsamplers.0.conv.weight"], B * Fr, geo[2], geo[3], stride=2,
-                                bias=w[f"{p}.downsamplers.0.conv.bias"], colsum_batch=B if (self.gn_colsums and self.shard is None) else 0)
+                                bias=w[f"{p}.downsamplers.0.conv.bias"], colsum_batch=B if self.gn_colsums else 0)
                 geo = (B, Fr, (geo[2] - 1) // 2 + 1, (geo[3] - 1) // 2 + 1)
                 skips.append(x)
         x = self._resnet("mid_block.resnets.0", x, None, geo)
@@ -452,7 +452,7 @@ class _Engine:
                     x = self._temporal_transformer(f"{p}.temporal_attentions.{j}", x, geo, cond_frame)
             if i < n - 1:
                 x = ops.conv_up2x(x, w[f"{p}.upsamplers.0.conv.weight_up4"], B * Fr, geo[2], geo[3],
-                                  bias=w[f"{p}.upsamplers.0.conv.bias"], colsum_batch=B if (self.gn_colsums and self.shard is None) else 0)
+                                  bias=w[f"{p}.upsamplers.0.conv.bias"], colsum_batch=B if self.gn_colsums else 0)
                 geo = (B, Fr, geo[2] * 2, geo[3] * 2)
         x = self._gn(x, None, B, Fr * geo[2] * geo[3], "conv_norm_out", self.eps, True)
         return ops.conv_out(x, w["conv_out.weight"], w["conv_out.bias"], B, Fr, geo[2], geo[3])

@@ -676,6 +676,10 @@ def _colsum_reference(y, B, groups):
     ("gemm", 2, (6144, 640, 640), 7),                  # 128x64 ring
     ("up", 2, (4, 8, 8, 640, 640), 0),                 # four phase convs
     ("up", 2, (2, 16, 16, 320, 320), 0),
+    ("conv", 2, (24, 8, 8, 1280, 1280, 1), 0),         # AUTO: split-K (128x128 x 4 slices), sums from the reduce pass, 16-row partials
+    ("conv", 2, (24, 4, 4, 1280, 1280, 1), 0),         # AUTO: split-K on 384 rows, 4-row partials
+    ("conv", 2, (6, 16, 16, 640, 640, 1), 0),          # AUTO: split-K at the 16x16 level of a frame shard
+    ("gemm", 2, (384, 1280, 5120), 0),                 # AUTO: split-K plain GEMM (deep-level feed-forward output)
 ])
 def test_groupnorm_stats_from_colsums(device, kind, B, shape, tile):
     """The column sums a GEMM / conv leaves next to its output give the same GroupNorm statistics as the pass over the output
@@ -751,11 +755,13 @@ def test_colsums_refused_where_unsupported(device):
     w = (_rand((2560, 320), device, 2) / 18).to(bf16)
     y = ops.gemm(a, w, geglu=True, colsum_batch=2)
     assert y.colsums is None
-    # a split-K launch leaves none either (the reduce pass does not produce them)
+    # a split-K launch leaves them through its reduce pass; a reused `out=` tensor never keeps the sums of an earlier launch
     xs = _rand((4 * 8 * 8, 1280), device, 7).to(bf16)
     ws_ = (_rand((1280, 9 * 1280), device, 8) / 107).to(bf16)
     ys = ops.conv3x3(xs, ws_, 4, 8, 8, colsum_batch=2)
-    assert ys.colsums is None
+    assert ys.colsums is not None
+    ys2 = ops.conv3x3(xs, ws_, 4, 8, 8, out=ys)
+    assert ys2 is ys and ys.colsums is None
     y = ops.gemm(a, w[:320].contiguous(), out_f32=True, colsum_batch=2)
     assert y.colsums is None
     d = _lib.GemmDesc()
