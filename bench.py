@@ -41,6 +41,11 @@ WORKLOADS = {
     "sthv2": dict(WORKLOAD, name="Sthv2 config: CFG batch 2 x 12 frames (2 cond + 10 predicted) x 32x32 latent"),
     "bridge": dict(b=4, cond_frames=1, frames=16, latent=32, ddim_steps=50, scale=7.5,
                    name="Bridge config: CFG batch 8 x 16 frames (1 cond + 15 predicted) x 32x32 latent"),
+    # SURVEY 8(d)'s literal readings of "2 ref + 12 frames" and "1 ref + 16 frames"
+    "sthv2_14": dict(b=1, cond_frames=2, frames=14, latent=32, ddim_steps=50, scale=7.5,
+                     name="Sthv2 config, literal reading: CFG batch 2 x 14 frames (2 cond + 12 predicted) x 32x32 latent"),
+    "bridge_17": dict(b=4, cond_frames=1, frames=17, latent=32, ddim_steps=50, scale=7.5,
+                      name="Bridge config, literal reading: CFG batch 8 x 17 frames (1 cond + 16 predicted) x 32x32 latent"),
     "sthv2_512": dict(b=1, cond_frames=2, frames=12, latent=64, ddim_steps=50, scale=7.5,
                       name="Sthv2 512^2 config: CFG batch 2 x 12 frames x 64x64 latent (4096-token spatial attention)"),
 }
@@ -55,6 +60,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     ap.add_argument("--no-train", action="store_true", help="skip the extra fine-tuning step measurement (config 5)")
+    ap.add_argument("--no-capture-collectives", action="store_true",
+                    help="N > 1: keep the RCCL exchanges of the partitioned step eager between hipGraph segments")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="sthv2",
                     help="default = BASELINE.json's metric configuration; the others are extra measurements")
     return ap.parse_args()
@@ -267,10 +274,21 @@ def main():
         from seervideoldm_amd import parallel
         weak = {"value": round(world * 1e3 / ms_per_step, 3), "unit": "steps/s", "ms_per_step": round(ms_per_step, 3),
                 "scaling": "weak", "what": f"{world} independent samples, one CFG-batched sample per GPU, no data-path collective"}
-        shard = parallel.attach(model, world, rank)
-        ms_per_step = timed_steps()
-        parallelism = f"{shard.describe()} over {world} RCCL ranks"
-        graph_live = bool(model._engine._graphs and not getattr(model._engine, "_graph_broken", False))
+        shard = parallel.attach(model, world, rank, capture_collectives=False if args.no_capture_collectives else None)
+        # the sharded step must never cost the line: a failure that reaches every rank (capture refused, a partition the frame
+        # count does not allow) is reported in the JSON and the independent-samples number stands as `value`.  (A rank that dies
+        # or hangs inside a collective cannot be caught from here; the RCCL watchdog ends the job.)
+        sharded_error = None
+        try:
+            ms_sharded = timed_steps()
+        except Exception as e:      # noqa: BLE001
+            sharded_error = f"{type(e).__name__}: {e}"[:300]
+        if shard.agree(sharded_error is None, device):
+            ms_per_step = ms_sharded
+            parallelism = f"{shard.describe()} over {world} RCCL ranks"
+            graph_live = bool(model._engine._graphs and not getattr(model._engine, "_graph_broken", False))
+        else:
+            parallelism = f"{world} independent samples (the partitioned step failed: {sharded_error or 'on another rank'})"
         model._shard = None
         model._engine = None
 
@@ -420,9 +438,10 @@ def main():
         line = {
             "metric": "UNet denoising steps/sec (12-frame 256^2 latent, 50-step DDIM)" if args.workload == "sthv2"
                       else f"UNet denoising steps/sec ({args.workload} workload, 50-step DDIM)",
-            "value": round(1e3 / ms_per_step, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "value": round((world if "independent samples" in parallelism else 1) * 1e3 / ms_per_step, 3), "unit": "steps/s",
+            "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "strong" if (world > 1 and "independent samples" not in parallelism) else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload]["name"] + ", "
                                    "full-width SeerUNet 1.08G params, 50-step DDIM, scale 7.5",
                        "global_batch": WORKLOADS[args.workload]["b"], "parallelism": parallelism,

@@ -89,11 +89,16 @@ def _unheads(x, heads):  # [B*heads, S, d] -> [B, S, C]   (attention.py:499-504)
     return x.reshape(BH // heads, heads, S, d).permute(0, 2, 1, 3).reshape(BH // heads, S, heads * d)
 
 
-def cross_attention(sd: SD, p: str, x, context, heads):
-    """CrossAttention.forward, xformers path, non-temporal (attention.py:512-554)."""
+def cross_attention(sd: SD, p: str, x, context, heads, return_attn=False):
+    """CrossAttention.forward, xformers path, non-temporal (attention.py:512-554).  return_attn: the call takes the plain
+    `_attention` branch (attention.py:534-541, 556-584) -- same softmax(QK^T scale)V -- and also returns its
+    `attention_scores` = scale * QK^T BEFORE the softmax, [B*heads, Sq, Sk]."""
     ctx = x if context is None else context
     q, k, v = _lin(sd, p + ".to_q", x), _lin(sd, p + ".to_k", ctx), _lin(sd, p + ".to_v", ctx)
-    o = _unheads(mea(_heads(q, heads), _heads(k, heads), _heads(v, heads), False), heads)
+    qh, kh = _heads(q, heads), _heads(k, heads)
+    o = _unheads(mea(qh, kh, _heads(v, heads), False), heads)
+    if return_attn:
+        return _lin(sd, p + ".to_out.0", o), torch.einsum("bqd,bkd->bqk", qh, kh) * qh.shape[-1] ** -0.5
     return _lin(sd, p + ".to_out.0", o)
 
 
@@ -140,11 +145,13 @@ def _ln(sd: SD, p: str, x):
     return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], 1e-5)
 
 
-def spatial_transformer(sd: SD, p: str, x, context, heads, temporal, cond_frame, groups):
+def spatial_transformer(sd: SD, p: str, x, context, heads, temporal, cond_frame, groups, return_attn=False):
     """SpatialTransformer3D.forward (attention.py:129-145) with its single transformer block:
-    text: BasicTextTransformerBlock3D (attention.py:308-327); temporal: BasicTransformerBlock3D (attention.py:231-248)."""
+    text: BasicTextTransformerBlock3D (attention.py:308-327); temporal: BasicTransformerBlock3D (attention.py:231-248).
+    return_attn (text blocks): also the text cross-attention's scores as [b, heads, f, h, w, L] (attention.py:316-320)."""
     b, c, f, h, w = x.shape
     x_in = x
+    attn = None
     x = group_norm5d(sd, p + ".norm", x, groups, 1e-6)
     x = conv_frames(sd, p + ".proj_in", x, padding=0)
     tb = p + ".transformer_blocks.0"
@@ -153,7 +160,12 @@ def spatial_transformer(sd: SD, p: str, x, context, heads, temporal, cond_frame,
         t = cross_attention(sd, tb + ".attn1", _ln(sd, tb + ".norm1", t), None, heads) + t
         if context is not None:
             ctx = context.reshape(b * f, -1, context.shape[-1])
-            t = cross_attention(sd, tb + ".attn2", _ln(sd, tb + ".norm2", t), ctx, heads) + t
+            if return_attn:
+                o, attn = cross_attention(sd, tb + ".attn2", _ln(sd, tb + ".norm2", t), ctx, heads, True)
+                t = o + t
+                attn = attn.reshape(b, f, -1, h, w, ctx.shape[-2]).permute(0, 2, 1, 3, 4, 5)
+            else:
+                t = cross_attention(sd, tb + ".attn2", _ln(sd, tb + ".norm2", t), ctx, heads) + t
         t = feed_forward(sd, tb + ".ff", _ln(sd, tb + ".norm3", t)) + t
     else:
         t = x.permute(0, 2, 3, 4, 1).reshape(b, f * h * w, c)
@@ -164,7 +176,8 @@ def spatial_transformer(sd: SD, p: str, x, context, heads, temporal, cond_frame,
         if cond_frame > 0:
             t = torch.cat([t0, t], dim=1)
     x = t.reshape(b, f, h, w, c).permute(0, 4, 1, 2, 3)
-    return conv_frames(sd, p + ".proj_out", x, padding=0) + x_in
+    x = conv_frames(sd, p + ".proj_out", x, padding=0) + x_in
+    return (x, attn) if return_attn else x
 
 
 def resnet_block(sd: SD, p: str, x, temb, groups, eps):
@@ -186,9 +199,21 @@ def upsample(sd: SD, p: str, x):
 
 
 # ------------------------------------------------------------------------------------------------ UNet
-def unet_forward(sd: SD, cfg: dict, sample, timestep, context, cond_frame: int = 0):
+def unet_forward(sd: SD, cfg: dict, sample, timestep, context, cond_frame: int = 0, return_attn: bool = False):
     """SeerUNet.forward (seer/models/unet_3d_condition.py:283-376) incl. block wiring of unet_3d_blocks.py
-    (:210-279 mid, :364-431 down, :484-508, :590-658 up, :707-728)."""
+    (:210-279 mid, :364-431 down, :484-508, :590-658 up, :707-728).  return_attn: `(out, attn_list)` with one entry per
+    attention-bearing container -- 3 down, mid, 3 up -- holding the text cross-attention scores of the container's LAST text
+    block (each container overwrites `attn_map` layer by layer: unet_3d_blocks.py:412-413,267-268,642-643)."""
+    attn_list = []
+
+    def text_block(path, x_, last):
+        if return_attn:
+            x_, a = spatial_transformer(sd, path, x_, context, heads, False, cond_frame, G, True)
+            if last:
+                attn_list.append(a)
+            return x_
+        return spatial_transformer(sd, path, x_, context, heads, False, cond_frame, G)
+
     c = dict(DEFAULT_CFG); c.update(cfg)
     boc, lpb, heads = tuple(c["block_out_channels"]), c["layers_per_block"], c["attention_head_dim"]
     G, eps = c["norm_num_groups"], c["norm_eps"]
@@ -212,14 +237,14 @@ def unet_forward(sd: SD, cfg: dict, sample, timestep, context, cond_frame: int =
             p = f"down_blocks.{i}"
             x = resnet_block(sd, f"{p}.resnets.{j}", x, emb, G, eps)
             if has_attn:
-                x = spatial_transformer(sd, f"{p}.attentions.{j}", x, context, heads, False, cond_frame, G)
+                x = text_block(f"{p}.attentions.{j}", x, j == lpb - 1)
                 x = spatial_transformer(sd, f"{p}.temporal_attentions.{j}", x, None, heads, True, cond_frame, G)
             skips.append(x)
         if i < nlev - 1:
             x = conv_frames(sd, f"down_blocks.{i}.downsamplers.0.conv", x, stride=2, padding=1)
             skips.append(x)
     x = resnet_block(sd, "mid_block.resnets.0", x, emb, G, eps)
-    x = spatial_transformer(sd, "mid_block.attentions.0", x, context, heads, False, cond_frame, G)
+    x = text_block("mid_block.attentions.0", x, True)
     x = spatial_transformer(sd, "mid_block.temporal_attentions.0", x, None, heads, True, cond_frame, G)
     x = resnet_block(sd, "mid_block.resnets.1", x, emb, G, eps)
     for i in range(nlev):
@@ -229,12 +254,13 @@ def unet_forward(sd: SD, cfg: dict, sample, timestep, context, cond_frame: int =
             x = torch.cat([x, skips.pop()], dim=1)
             x = resnet_block(sd, f"{p}.resnets.{j}", x, emb, G, eps)
             if has_attn:
-                x = spatial_transformer(sd, f"{p}.attentions.{j}", x, context, heads, False, cond_frame, G)
+                x = text_block(f"{p}.attentions.{j}", x, j == lpb)
                 x = spatial_transformer(sd, f"{p}.temporal_attentions.{j}", x, None, heads, True, cond_frame, G)
         if i < nlev - 1:
             x = upsample(sd, f"{p}.upsamplers.0", x)
     x = F.silu(group_norm5d(sd, "conv_norm_out", x, G, eps))
-    return conv_frames(sd, "conv_out", x)
+    out = conv_frames(sd, "conv_out", x)
+    return (out, attn_list) if return_attn else out
 
 
 # ------------------------------------------------------------------------------------------------ DDIM

@@ -129,8 +129,9 @@ def _launch_gemm(d: GemmDesc, device, what: str, colsum_batch: int = 0) -> Optio
 
 
 def gemm_batched(a: torch.Tensor, w: torch.Tensor, *, trans_out=False, out: Optional[torch.Tensor] = None,
-                 bias: Optional[torch.Tensor] = None, out_f32=False, tile=0) -> torch.Tensor:
-    """a [Bt, M, K], w [Bt, N, K] (or [N, K] shared) -> out [Bt, M, N] (or [Bt, N, M] with trans_out)."""
+                 bias: Optional[torch.Tensor] = None, out_f32=False, tile=0, col_scale=None) -> torch.Tensor:
+    """a [Bt, M, K], w [Bt, N, K] (or [N, K] shared) -> out [Bt, M, N] (or [Bt, N, M] with trans_out).
+    col_scale = (factor, cols) as in gemm()."""
     _req(a, bf16, "a"); _req(w, bf16, "w")
     assert a.dim() == 3 and a.is_contiguous() and w.is_contiguous()
     Bt, M, K = a.shape
@@ -151,6 +152,9 @@ def gemm_batched(a: torch.Tensor, w: torch.Tensor, *, trans_out=False, out: Opti
     d.strideW = N * K if w.dim() == 3 else 0
     d.strideC = M * N
     d.epilogue = (_lib.SEER_EPI_TRANS_OUT if trans_out else 0) | (_lib.SEER_EPI_OUT_F32 if out.dtype == torch.float32 else 0)
+    if col_scale is not None:
+        d.epilogue |= _lib.SEER_EPI_COLSCALE
+        d.col_scale, d.col_scale_cols = float(col_scale[0]), int(col_scale[1])
     d.tile = tile
     check(_lib.load().seer_gemm_bf16(C.byref(d), _stream()), "seer_gemm_bf16(batched)")
     return out

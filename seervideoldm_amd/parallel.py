@@ -38,24 +38,29 @@ def choose_groups(world: int, batch: int) -> Tuple[int, int]:
 
 
 class FrameShard:
-    def __init__(self, world: int, rank: int, batch_groups: Optional[int] = None):
+    def __init__(self, world: int, rank: int, batch_groups: Optional[int] = None, capture_collectives: Optional[bool] = None):
         self.world, self.rank = world, rank
         self.forced_G = batch_groups
         self._pgs = {}
+        self._probed = set()
         self.G = self.P = None
         self.total_frames = self.frame_offset = self.local_frames = 0
         self.debug_boundaries = False   # tests: hit every sync point (with a no-op exchange) even when P == 1
         # RCCL collectives can be captured into the step's hipGraph (scripts/exp_nccl_capture.py: capture + replay of
         # all_reduce / all_gather_into_tensor verified on torch 2.10 + RCCL 2.26): the whole sharded step then replays as
         # ONE graph instead of ~94 segments with an eager exchange and a host round trip between each pair.  gloo (CPU tests,
-        # several ranks on one device) cannot be captured and keeps the segmented replay.
+        # several ranks on one device) cannot be captured and keeps the segmented replay.  The choice is made for all ranks
+        # together and can only fall back, never diverge: the capturability probe runs on the WORLD communicator at attach()
+        # and on the frame group at the first plan(), the verdicts are combined by a MIN all-reduce, and a capture that fails
+        # on any rank sends every rank to the segmented replay (unet._Engine._run_graph).
+        # capture_collectives: None = capture when the backend is RCCL and the probes pass; False = always segmented.
         self.capture_collectives = False
-        try:
-            import os
-            if dist.is_available() and dist.is_initialized() and os.environ.get("SEER_CAPTURE_COLLECTIVES", "1") != "0":
-                self.capture_collectives = dist.get_backend() == "nccl"
-        except Exception:       # noqa: BLE001  (no default group yet: decided again in plan())
-            pass
+        if capture_collectives is not False:
+            try:
+                if dist.is_available() and dist.is_initialized():
+                    self.capture_collectives = dist.get_backend() == "nccl"
+            except Exception:       # noqa: BLE001  (no default group yet)
+                pass
 
     # ---- geometry --------------------------------------------------------------------------------------------
     def plan(self, B: int, F: int):
@@ -83,6 +88,24 @@ class FrameShard:
             groups = [dist.new_group(list(range(g * self.P, (g + 1) * self.P))) for g in range(self.G)]
             self._pgs[key] = groups
         return self._pgs[key][self.g]
+
+    def probe_frame_group(self, device) -> None:
+        """the capturability probe on THIS partition's frame-group communicator (attach() only saw WORLD); all ranks call it
+        at the same point (first sharded step of a partition), the verdict is the minimum over all ranks"""
+        key = (self.G, self.P)
+        if not self.capture_collectives or self.P == 1 or key in self._probed:
+            return
+        self._probed.add(key)
+        if not probe_capture(device, group=self.frame_group()):
+            self.capture_collectives = False
+
+    def agree(self, ok: bool, device) -> bool:
+        """True iff `ok` on every rank (eager MIN all-reduce over WORLD): how the ranks take a fallback together"""
+        if self.world == 1 or not (dist.is_available() and dist.is_initialized()):
+            return ok
+        flag = torch.tensor([1.0 if ok else 0.0], device=device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item() > 0.5)
 
     def describe(self) -> str:
         if not self.G:
@@ -175,17 +198,18 @@ class FrameShard:
         return full
 
 
-def probe_capture(device) -> bool:
-    """Can this process group's collectives be recorded into a hipGraph and replayed?  One tiny all-reduce + all-gather is
-    captured and replayed on every rank; the verdicts are combined by an (eager) MIN all-reduce so that all ranks take the
-    same path.  A stack that cannot capture falls back to eager exchanges between graph segments instead of failing the step."""
+def probe_capture(device, group=None) -> bool:
+    """Can collectives of `group` (default: WORLD) be recorded into a hipGraph and replayed?  One tiny all-reduce + all-gather
+    is captured and replayed by every rank of the group; the verdicts of ALL ranks are combined by an (eager) MIN all-reduce
+    over WORLD so that everybody takes the same path.  A stack that cannot capture falls back to eager exchanges between graph
+    segments instead of failing the step."""
     ok = 1.0
     try:
-        world = dist.get_world_size()
+        n = dist.get_world_size(group)
         x = torch.ones(64, device=device)
-        out = torch.empty(64 * world, device=device)
-        dist.all_reduce(x)                      # communicator creation must not happen under capture
-        dist.all_gather_into_tensor(out, x)
+        out = torch.empty(64 * n, device=device)
+        dist.all_reduce(x, group=group)         # communicator creation must not happen under capture
+        dist.all_gather_into_tensor(out, x, group=group)
         torch.cuda.synchronize(device)
         s = torch.cuda.Stream(device=device)
         s.wait_stream(torch.cuda.current_stream(device))
@@ -193,13 +217,13 @@ def probe_capture(device) -> bool:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 y = x * 2
-                dist.all_reduce(y)
-                dist.all_gather_into_tensor(out, y)
+                dist.all_reduce(y, group=group)
+                dist.all_gather_into_tensor(out, y, group=group)
         torch.cuda.current_stream(device).wait_stream(s)
         x.fill_(1.0)
         g.replay()
         torch.cuda.synchronize(device)
-        ok = 1.0 if bool((out == 2.0 * world).all()) else 0.0
+        ok = 1.0 if bool((out == 2.0 * n).all()) else 0.0
     except Exception:       # noqa: BLE001  (capture unsupported / refused: every failure mode means "do not capture")
         ok = 0.0
     flag = torch.tensor([ok], device=device)
@@ -207,9 +231,10 @@ def probe_capture(device) -> bool:
     return bool(flag.item() > 0.5)
 
 
-def attach(model, world: int, rank: int, batch_groups: Optional[int] = None) -> FrameShard:
-    """make `model.forward` run sharded: every rank passes the FULL (sample, timestep, context) and gets the FULL output."""
-    shard = FrameShard(world, rank, batch_groups)
+def attach(model, world: int, rank: int, batch_groups: Optional[int] = None, capture_collectives: Optional[bool] = None) -> FrameShard:
+    """make `model.forward` run sharded: every rank passes the FULL (sample, timestep, context) and gets the FULL output.
+    capture_collectives=False keeps the eager exchanges between hipGraph segments (the conservative replay)."""
+    shard = FrameShard(world, rank, batch_groups, capture_collectives)
     if shard.capture_collectives:
         dev = next(model.parameters()).device
         if dev.type != "cuda" or not probe_capture(dev):

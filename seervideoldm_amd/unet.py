@@ -150,8 +150,6 @@ class SeerUNet(nn.Module):
     @torch.no_grad()
     def forward(self, sample: torch.Tensor, timestep: Union[torch.Tensor, float, int], context: torch.Tensor,
                 cond_frame: int = 0, return_attn: bool = False) -> torch.Tensor:
-        if return_attn:
-            raise NotImplementedError("return_attn materialises attention maps; not on the inference hot path")
         if not sample.is_cuda and self._ops_backend is hip_ops:
             raise hip_ops._lib.SeerHipError("SeerUNet.forward needs ROCm tensors: the HIP kernels are the only compute path")
         if self._engine is None or self._engine.device != sample.device:
@@ -164,6 +162,13 @@ class SeerUNet(nn.Module):
         elif t.dim() == 0:
             t = t[None].to(sample.device)
         t = t.to(torch.long).broadcast_to((sample.shape[0],)).contiguous()
+        if return_attn:
+            # (out, attn_list): the text cross-attention scores of the last text block of every attention-bearing container
+            # (unet_3d_condition.py:291-292,317-323,372-374) -- an analysis path: eager launches, one process
+            if self._shard is not None:
+                raise NotImplementedError("return_attn is not available on a sharded model")
+            out, attn = self._engine.run(sample.float().contiguous(), t, context, int(cond_frame), return_attn=True)
+            return out.to(sample.dtype), [a.to(sample.dtype) for a in attn]
         if self._shard is None:
             out = self._engine.run(sample.float().contiguous(), t, context, int(cond_frame), use_graph=self.use_graph)
             return out.to(sample.dtype)
@@ -173,6 +178,7 @@ class SeerUNet(nn.Module):
         if context.dim() == 3:
             context = context[:, None].expand(-1, Fr, -1, -1)
         (b0, b1), (f0, f1) = sh.plan(B, Fr)
+        sh.probe_frame_group(sample.device)
         key = (context.data_ptr(), context._version, tuple(context.shape), b0, b1, f0, f1)
         if self._ctx_slice is None or self._ctx_slice[0] != key:
             # the keyed tensor is kept alive with the slice: a recycled address must not look like the same context
@@ -210,6 +216,8 @@ class _Engine:
         self._kv_key = None
         self._graphs: Dict[Tuple, object] = {}
         self._rec = None                # _SegmentRecorder while a segmented capture is running
+        self._attn_list = None          # list that collects the text cross-attention scores of a return_attn forward
+        self._attn_wanted = ()
 
     # ---- weight packing ---------------------------------------------------------------------------------------
     def _pack(self, sd):
@@ -344,11 +352,26 @@ class _Engine:
             kv = ops.gemm(self._ctx, w[tb + ".attn2.kv"])
             self._kv_cache[tb] = kv
         L = self._ctx_len
+        if self._attn_list is not None and p in self._attn_wanted:
+            self._attn_list.append(self._cross_scores(q, kv[:, :C], B, Fr, H, W, heads, d, L))
         ops.attention(q, kv[:, :C], kv[:, C:], a, batch=B * Fr, heads=heads, head_dim=d, Sq=HW, Sk=L, q_prescaled=True)
         ops.gemm(a, w[tb + ".attn2.to_out.0.weight"], bias=w[tb + ".attn2.to_out.0.bias"], residual=h, out=h)
         self._ff(tb, h)
         return ops.gemm(h, w[p + ".proj_out.weight"], bias=w[p + ".proj_out.bias"], residual=x,
                         colsum_batch=B if self.gn_colsums else 0)
+
+    def _cross_scores(self, q, k, B, Fr, H, W, heads, d, L):
+        """`attention_scores` of the text cross attention (attention.py:556-584: scale * Q K^T before the softmax) as
+        [b, heads, f, h, w, L] (attention.py:320).  q carries scale * log2(e) (one bf16 rounding, as the attention kernel reads
+        it): the scores are one batched MFMA GEMM over the head-split, zero-padded operands with 1 / log2(e) in its epilogue."""
+        HW, Bt = H * W, B * Fr * heads
+        dp, Lp = (d + 63) // 64 * 64, (L + 3) // 4 * 4
+        qh = torch.zeros((Bt, HW, dp), device=q.device, dtype=bf16)
+        kh = torch.zeros((Bt, Lp, dp), device=q.device, dtype=bf16)
+        qh[:, :, :d] = q.reshape(B * Fr, HW, heads, d).permute(0, 2, 1, 3).reshape(Bt, HW, d)
+        kh[:, :L, :d] = k.reshape(B * Fr, L, heads, d).permute(0, 2, 1, 3).reshape(Bt, L, d)
+        s = self.ops.gemm_batched(qh, kh, out_f32=True, col_scale=(1.0 / self.ops.LOG2E, Lp))
+        return s[:, :, :L].reshape(B, Fr, heads, H, W, L).permute(0, 2, 1, 3, 4, 5).contiguous()
 
     def _rotary_table(self, tb, T):
         freqs = self.w[tb + ".attn1.rotary_emb.freqs"]
@@ -410,10 +433,14 @@ class _Engine:
                    (k.endswith("norm1.weight") or k.endswith("norm2.weight") or k.endswith(".norm.weight") or
                     k == "conv_norm_out.weight") and "transformer_blocks" not in k)
 
-    def _forward(self, sample, t, ctx_bf16, ctx_len, cond_frame):
+    def _forward(self, sample, t, ctx_bf16, ctx_len, cond_frame, return_attn=False):
         ops, w = self.ops, self.w
         B, Cin, Fr, H, W = sample.shape
         boc, lpb, n = self.boc, self.lpb, len(self.boc)
+        self._attn_list = [] if return_attn else None
+        # the last text block of each container: the reference's containers overwrite attn_map layer by layer
+        self._attn_wanted = {f"down_blocks.{i}.attentions.{lpb - 1}" for i in range(n - 1)} | {"mid_block.attentions.0"} | \
+                            {f"up_blocks.{i}.attentions.{lpb}" for i in range(1, n)}
         self._ctx, self._ctx_len = ctx_bf16, ctx_len
         self._stats_arena = torch.empty((self.n_groupnorms(), B, self.G, 2), device=sample.device, dtype=torch.float32)
         self._stats_i = 0
@@ -455,7 +482,11 @@ class _Engine:
                                   bias=w[f"{p}.upsamplers.0.conv.bias"], colsum_batch=B if self.gn_colsums else 0)
                 geo = (B, Fr, geo[2] * 2, geo[3] * 2)
         x = self._gn(x, None, B, Fr * geo[2] * geo[3], "conv_norm_out", self.eps, True)
-        return ops.conv_out(x, w["conv_out.weight"], w["conv_out.bias"], B, Fr, geo[2], geo[3])
+        out = ops.conv_out(x, w["conv_out.weight"], w["conv_out.bias"], B, Fr, geo[2], geo[3])
+        if return_attn:
+            attn, self._attn_list = self._attn_list, None
+            return out, attn
+        return out
 
     # ---- entry ---------------------------------------------------------------------------------------------------------
     def _context(self, context: torch.Tensor):
@@ -482,7 +513,7 @@ class _Engine:
             self._kv_ctx_ref = context
         return self._ctx_bf16, context.shape[-2]
 
-    def run(self, sample, t, context, cond_frame, use_graph=False):
+    def run(self, sample, t, context, cond_frame, use_graph=False, return_attn=False):
         if context.dim() == 3:      # [B, L, Dc] -> same text for every frame
             context = context[:, None].expand(-1, sample.shape[2], -1, -1)
         assert context.shape[0] == sample.shape[0] and context.shape[1] == sample.shape[2], \
@@ -491,6 +522,8 @@ class _Engine:
         if H % 8 or W % 8:
             raise ValueError("latent height/width must be multiples of 8 (three stride-2 levels + 4/8 windows)")
         ctx, L = self._context(context)
+        if return_attn:
+            return self._forward(sample, t, ctx, L, cond_frame, return_attn=True)
         if not use_graph or getattr(self, "_graph_broken", False):
             return self._forward(sample, t, ctx, L, cond_frame)
         return self._run_graph(sample, t, ctx, L, cond_frame)
@@ -520,25 +553,40 @@ class _Engine:
             s_in, t_in = sample.clone(), t.clone()
             self._forward(s_in, t_in, ctx, L, cond_frame)
             torch.cuda.synchronize()
-            rec = _SegmentRecorder()
-            self._rec = rec
-            try:
-                rec.begin_segment()
-                out = self._forward(s_in, t_in, ctx, L, cond_frame)
-                rec.end_segment()
-            except Exception as e:                       # capture refused (driver / RCCL state): stay correct, run eagerly
-                rec.abort()
-                self._rec = None
-                if self.shard is not None and self.shard.world > 1:
-                    # this rank has already issued some of the step's collectives: an eager re-run here would put the ranks
-                    # out of step with each other -- surface the failure instead of hanging the group
-                    raise
+            sharded = self.shard is not None and self.shard.world > 1
+            err = None
+            for attempt in range(2):
+                rec = _SegmentRecorder()
+                self._rec = rec
+                try:
+                    rec.begin_segment()
+                    out = self._forward(s_in, t_in, ctx, L, cond_frame)
+                    rec.end_segment()
+                    err = None
+                except Exception as e:      # noqa: BLE001  capture refused (driver / RCCL state)
+                    rec.abort()
+                    err = e
+                finally:
+                    self._rec = None
+                if not sharded:
+                    break
+                # Sharded: the ranks decide TOGETHER.  While collectives are captured nothing is exchanged during capture, so a
+                # rank whose capture failed has not left its peers waiting; everybody learns of the failure here and repeats
+                # the capture with eager exchanges between graph segments (where a failure can only be symmetric).
+                if self.shard.agree(err is None, self.device):
+                    break
+                if not self.shard.capture_collectives or attempt == 1:
+                    raise err if err is not None else RuntimeError("hipGraph capture of the sharded step failed on another rank")
+                self.shard.capture_collectives = False
+                import warnings
+                warnings.warn("capturing the RCCL exchanges into the step graph failed on at least one rank"
+                              + (f" ({type(err).__name__}: {err})" if err is not None else "")
+                              + "; all ranks fall back to eager exchanges between graph segments")
+            if err is not None:             # single process: stay correct, run eagerly
                 self._graph_broken = True
                 import warnings
-                warnings.warn(f"hipGraph capture of the denoising step failed ({type(e).__name__}: {e}); running eagerly")
+                warnings.warn(f"hipGraph capture of the denoising step failed ({type(err).__name__}: {err}); running eagerly")
                 return self._forward(sample, t, ctx, L, cond_frame)
-            finally:
-                self._rec = None
             g = (rec, s_in, t_in, out)
             if len(self._graphs) > 4:
                 self._graphs.clear()

@@ -171,3 +171,30 @@ def test_partition_choice_per_config():
     sh = FrameShard(8, 5)
     assert sh.plan(2, 12) == ((1, 2), (3, 6)) and (sh.G, sh.P) == (2, 4)
     assert sh.describe().startswith("batch_groups2xframe_shards4, eager collectives")
+
+
+def _agree_worker(rank, world, port, out_path):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from seervideoldm_amd.parallel import FrameShard
+        sh = FrameShard(world, rank)
+        cpu = torch.device("cpu")
+        res = [sh.agree(True, cpu),                  # everybody fine
+               sh.agree(rank != 1, cpu),             # rank 1 failed: EVERY rank must learn of it
+               sh.agree(False, cpu)]
+        explicit = FrameShard(world, rank, capture_collectives=False)
+        torch.save(dict(res=res, cap=sh.capture_collectives, cap_off=explicit.capture_collectives), f"{out_path}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_take_a_fallback_together(tmp_path):
+    """a hipGraph capture that fails on ONE rank must send every rank to the segmented replay (unet._Engine._run_graph decides
+    through FrameShard.agree): the verdict is the minimum over the ranks, identical everywhere"""
+    out = tmp_path / "agree"
+    _spawn(_agree_worker, 2, str(out))
+    r0, r1 = torch.load(f"{out}.0"), torch.load(f"{out}.1")
+    assert r0["res"] == r1["res"] == [True, False, False]
+    assert not r0["cap"] and not r0["cap_off"]           # gloo: never captured

@@ -49,3 +49,20 @@ def test_engine_counts_groupnorms(mini):
     n = sum(1 for k in full if k.endswith(".weight") and (k.endswith("norm1.weight") or k.endswith("norm2.weight")
             or k.endswith(".norm.weight") or k == "conv_norm_out.weight") and "transformer_blocks" not in k)
     assert n == 77          # SURVEY finding 3: 77 cross-frame GroupNorms per forward
+
+
+def test_engine_return_attn_matches_oracle(mini):
+    """`return_attn=True`: 7 score tensors [b, heads, f, h, w, L] from the LAST text block of each attention-bearing container
+    (unet_3d_condition.py:291-292,317-323,372-374), and the same epsilon as the plain forward"""
+    sd, m = mini
+    eng = _Engine(m, ops=tob)
+    B, Fr, H = 1, 2, 16
+    x, ctx, t = _randn((B, 4, Fr, H, H), 1), _randn((B, Fr, 77, 256), 2), torch.tensor([501])
+    with torch.no_grad():
+        got, attn = eng.run(x, t, ctx, 0, return_attn=True)
+        plain = eng.run(x, t, ctx, 0)
+        ref, ref_attn = O.unet_forward(sd, CFG_MINI, x, t, ctx, cond_frame=0, return_attn=True)
+    assert torch.equal(got, plain) and len(attn) == len(ref_attn) == 7
+    for a, r in zip(attn, ref_attn):
+        assert a.shape == r.shape and a.dtype == torch.float32
+        assert ((a - r).norm() / r.norm()).item() < 3e-2

@@ -179,6 +179,62 @@ def test_vae_decode_matches_oracle(device):
     _check(got, ref, "vae decode")
 
 
+def test_vae_decode_full_size_matches_oracle(device):
+    """The decoder bench.py times and ddim_sample calls: the FULL SD-v1-5 VAE decoder (ch 128, ch_mult (1,2,4,4), two ResNets per
+    level, 49.5 M parameters), one 32x32 latent -> 256x256 frame, against the fp32 oracle (622 GFLOP on the host cores).
+    Precision: the reference never autocasts its VAE (inference_img.py:118: the VAE is not `prepare`d, it decodes in fp32);
+    this path keeps activations in bf16 with fp32 accumulation like the UNet.  The bound is the UNet's calibrated one --
+    rel-L2 <= 3.0e-2 against fp32 -- and for the image itself, after ddim_sample's clamp((x+1)/2, 0, 1): mean |pixel error|
+    <= 2/255 of full scale (measured ~0.5/255)."""
+    vsd = synth.synth_state_dict(synth.vae_param_shapes())
+    vae = AutoencoderKL()
+    vae.load_state_dict(ldm_to_diffusers_vae(vsd, 4), strict=True)
+    vae = vae.to(device)
+    z = _randn((1, 4, 32, 32), 19)
+    ref = O.vae_decode(vsd, z)
+    got = vae.decode(z.to(device)).sample
+    assert got.shape == (1, 3, 256, 256)
+    _check(got, ref, "vae decode, full SD decoder 32x32 -> 256x256")
+    px = (torch.clamp((got.cpu() + 1) / 2, 0, 1) - torch.clamp((ref + 1) / 2, 0, 1)).abs()
+    print(f"[parity] full-size VAE decode: mean |pixel error| {px.mean().item() * 255:.3f}/255, max {px.max().item() * 255:.2f}/255")
+    assert px.mean().item() <= 2 / 255
+
+
+def test_return_attn_matches_oracle(device):
+    """unet(..., return_attn=True) -> (out, attn_list): the pre-softmax text cross-attention scores [b, heads, f, h, w, L] of the
+    last text block of each of the 7 attention-bearing containers (unet_3d_condition.py:291-292,317-323,372-374), and the
+    epsilon of the plain forward, bit for bit"""
+    cfg, sd, m = _model("mini", device)
+    x, ctx, t = _randn((2, 4, 2, 16, 16), 41), _randn((2, 2, 77, cfg["cross_attention_dim"]), 42), torch.tensor([501, 77])
+    got, attn = m(x.to(device), t.to(device), ctx.to(device), cond_frame=1, return_attn=True)
+    plain = m(x.to(device), t.to(device), ctx.to(device), cond_frame=1)
+    ref, ref_attn = O.unet_forward(sd, cfg, x, t, ctx, cond_frame=1, return_attn=True)
+    assert torch.equal(got, plain) and len(attn) == len(ref_attn) == 7
+    _check(got, ref, "return_attn epsilon")
+    for i, (a, r) in enumerate(zip(attn, ref_attn)):
+        assert a.shape == r.shape == (2, 8, 2, 16 >> min(i, 6 - i), 16 >> min(i, 6 - i), 77)
+        rel = _rel(a, r)
+        assert rel < REL_L2, (i, rel)
+
+
+@pytest.mark.parametrize("Fr,cond", [(14, 2), (17, 1)])
+def test_alternate_frame_counts_match_oracle(device, Fr, cond):
+    """SURVEY 8(d)'s alternate readings of the configs: "2 ref + 12 frames" = 14 frames, "1 ref + 16 frames" = 17.  17 frames x 64
+    window tokens = 1088 keys per temporal window at the 32x32 level: not a multiple of the 128-key stage of the d = 40 kernel
+    (the partial-tile path at full width); 14 x 64 = 896 is.  Full channel widths, one layer per block (the oracle's share of the
+    test stays ~20 s)."""
+    cfg, sd, m = _model("wide", device)
+    x, ctx, t = _randn((2, 4, Fr, 32, 32), 51), _randn((2, Fr, 77, cfg["cross_attention_dim"]), 52), torch.tensor([981, 981])
+    got = m(x.to(device), t.to(device), ctx.to(device), cond_frame=cond)
+    ref = O.unet_forward(sd, cfg, x, t, ctx, cond_frame=cond)
+    _check(got, ref, f"F={Fr} (cond {cond}) at 32x32, full widths")
+    m.use_graph = True
+    try:
+        assert torch.equal(m(x.to(device), t.to(device), ctx.to(device), cond_frame=cond), got)
+    finally:
+        m.use_graph = False
+
+
 def test_config4_64x64_latent_step(device):
     """BASELINE config 4 (512^2 pixels: 64x64 latent, spatial attention over 4096 tokens, windows ws=8 at two levels):
     finite, deterministic, identical batch elements agree bit for bit."""

@@ -41,6 +41,27 @@ def test_unet_forward(ref, cond_frame, Fr, H):
     torch.testing.assert_close(O.unet_forward(sd, cfg, x, t, ctx, cond_frame=cond_frame), unet(x, t, ctx, cond_frame=cond_frame), **TOL)
 
 
+@torch.no_grad()
+def test_unet_forward_return_attn(ref):
+    """`unet(..., return_attn=True)` -> (out, attn_list): 7 entries (3 down, mid, 3 up) of pre-softmax text cross-attention
+    scores [b, heads, f, h, w, L] from the LAST text block of each container (unet_3d_condition.py:291-292,317-323,372-374)"""
+    cfg = dict(sample_size=16, in_channels=4, out_channels=4, block_out_channels=(32, 32, 64, 96), cross_attention_dim=48,
+               attention_head_dim=8, layers_per_block=2)
+    unet = ref.unet.SeerUNet(**cfg).eval()
+    ref_import.enable_xformers_path(unet)
+    sd = synth.synth_state_dict(synth.unet_param_shapes(cfg))
+    unet.load_state_dict(sd, strict=True)
+    x, ctx, t = _randn((2, 4, 3, 16, 16), 31), _randn((2, 3, 77, 48), 32), torch.tensor([13, 977])
+    want, want_attn = unet(x, t, ctx, cond_frame=1, return_attn=True)
+    got, got_attn = O.unet_forward(sd, cfg, x, t, ctx, cond_frame=1, return_attn=True)
+    torch.testing.assert_close(got, want, **TOL)
+    assert len(got_attn) == len(want_attn) == 7
+    for a, b in zip(got_attn, want_attn):
+        assert a.shape == b.shape and a.shape[:3] == (2, 8, 3) and a.shape[-1] == 77
+        torch.testing.assert_close(a, b, **TOL)
+    torch.testing.assert_close(got, O.unet_forward(sd, cfg, x, t, ctx, cond_frame=1), rtol=0, atol=0)
+
+
 @pytest.mark.parametrize("H,W", [(16, 32), (32, 16), (8, 24)])
 @torch.no_grad()
 def test_unet_forward_non_square(ref, H, W):

@@ -62,10 +62,12 @@ def gemm(a, w, *, bias=None, residual=None, rowvec=None, rows_per_batch=0, a2=No
     return _epilogue(acc, bias, geglu, rowvec, rows_per_batch, silu, residual, out_f32, out)
 
 
-def gemm_batched(a, w, *, trans_out=False, out=None, bias=None, out_f32=False, tile=0):
+def gemm_batched(a, w, *, trans_out=False, out=None, bias=None, out_f32=False, tile=0, col_scale=None):
     acc = torch.einsum("bmk,bnk->bmn" if w.dim() == 3 else "bmk,nk->bmn", a.float(), w.float())
     if bias is not None:
         acc = acc + bias
+    if col_scale is not None:
+        acc[..., :col_scale[1]] = acc[..., :col_scale[1]] * col_scale[0]
     if trans_out:
         acc = acc.transpose(1, 2).contiguous()
     return acc if out_f32 else acc.to(bf16)
