@@ -232,6 +232,9 @@ def main():
     sampler = DDIMSampler(device)
     sampler.make_schedule(ddim_num_steps=w["ddim_steps"], ddim_eta=0.0, verbose=False)
     nidx = len(sampler.ddim_timesteps)
+    # as inside DDIMSampler.ddim_sampling: a step hands the next one its latent without a copy (the loops below keep no step's
+    # output past the next step)
+    sampler.static_step_outputs = True
 
     def step(i, x):
         index = nidx - 1 - (i % nidx)

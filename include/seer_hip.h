@@ -182,6 +182,13 @@ typedef struct seer_attn_desc {
      * buffer; 6 = generic kernel, ping-pong buffers; head_dim 40 only: 3 = the d = 40 kernel (fast path with the in-launch
      * fallback), 5 = the same kernel running its tracked-reference form directly (what lse != NULL selects) */
     int32_t variant;
+    /* head strides (elements): head h of Q / K / V starts h * q_hs / k_hs / v_hs elements after the batch element's base.
+     * 0 = head_dim: the heads are adjacent column groups of token-major rows (the layout of a fused [tokens, 3C] projection).
+     * A HEAD-MAJOR operand -- [batch][head][token][head_dim], token stride = head_dim, head stride = tokens * head_dim, what
+     * seer_gemm_bf16 writes with SEER_EPI_HEADMAJOR -- makes every K / V tile of a head one dense run of memory: at head_dim 40
+     * the LDS-DMA of a 128-key tile then moves 80 whole 128-byte lines instead of ~200 partial ones (80-byte pieces at a
+     * 1920-byte pitch), which is what bounds the d = 40 kernel on token-major operands.  O is always token-major. */
+    int64_t q_hs, k_hs, v_hs;
 } seer_attn_desc;
 
 /* Q already holds q * scale * log2(e) (the producing GEMM's epilogue multiplied it in, SEER_EPI_COLSCALE): the kernel takes
@@ -290,6 +297,22 @@ int seer_nhwc_bf16_to_nchw_f32(const void* x, int32_t N, int32_t C, int32_t HW, 
 int seer_cfg_ddim_step(const float* eps, int32_t cfg, int32_t b, int32_t C, int32_t F_total, int32_t cond_f,
                        int32_t HW, float scale, const float* coef, int32_t index, const float* x,
                        const float* noise /* may be NULL when sigma==0 */, float* x_prev, float* pred_x0, void* stream);
+
+/* The same step with its schedule index in device memory, for a p_sample_ddim that is captured WHOLE in one hipGraph (kernel
+ * arguments are frozen at capture, the step counter must not be).  step: int32[2]; step[0] = index of the next step to run,
+ * step[1] = index of the step in flight.
+ *   seer_ddim_step_begin    (ddim_video.py:189,201-203) first kernel of a step: sample[reps*b, C, f1 + F_pred, HW] =
+ *                           cat([x0_emb, x], frames) repeated `reps` times (2 = the [uc, c] CFG pair), t_out[reps*b] =
+ *                           t_table[step[0]], and step[1] = step[0];
+ *   seer_cfg_ddim_step_dev  last kernel: seer_cfg_ddim_step with index = step[1]; then step[0] = index - 1.  x_prev may be x.
+ * No kernel reads and writes the same word, so replays of the captured step walk the schedule downwards on their own; the host
+ * writes step[0] only to start a chain. */
+int seer_ddim_step_begin(const float* x0_emb /* NULL iff f1 == 0 */, const float* x, int32_t b, int32_t reps, int32_t C,
+                         int32_t f1, int32_t F_pred, int32_t HW, const int64_t* t_table, int32_t* step, float* sample,
+                         int64_t* t_out, void* stream);
+int seer_cfg_ddim_step_dev(const float* eps, int32_t cfg, int32_t b, int32_t C, int32_t F_total, int32_t cond_f, int32_t HW,
+                           float scale, const float* coef, int32_t* step, const float* x, const float* noise, float* x_prev,
+                           float* pred_x0, void* stream);
 
 /* decoded image post-process of ddim_sample (utils/ddim_sampling_utils.py:41): clamp((x+1)/2, 0, 1) in place */
 int seer_clamp01(float* x, int64_t n, void* stream);

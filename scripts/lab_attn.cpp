@@ -186,6 +186,33 @@ int main(int argc, char** argv) {
         ad.Q = Qp; ad.K = Kp; ad.V = Vp; ad.O = dout;
         ad.q_ss = ld; ad.k_ss = ld; ad.v_ss = ld; ad.o_ss = C;
         ad.q_bs = (int64_t)tq * ld; ad.k_bs = (int64_t)tk * ld; ad.v_bs = (int64_t)tk * ld; ad.o_bs = (int64_t)tq * C;
+        uint16_t* dhm = nullptr;
+        if (getenv("LAB_HEADMAJOR")) {
+            // the same q | k | v values as HEAD-MAJOR operands [batch][head][token][d] (seer_attn_desc::q_hs / k_hs / v_hs): which
+            // LAB_HEADMAJOR digit selects: 1 = K and V, 2 = Q too
+            const int mode = atoi(getenv("LAB_HEADMAJOR"));
+            const uint16_t* src_q = hq.data();
+            const uint16_t* src_kv = self ? hq.data() : hkv.data();
+            std::vector<uint16_t> hm((rows_q + 2 * rows_k) * C);
+            uint16_t* hmq = hm.data();
+            uint16_t* hmk = hmq + rows_q * C;
+            uint16_t* hmv = hmk + rows_k * C;
+            for (int b = 0; b < c.batch; ++b)
+                for (int h = 0; h < heads; ++h) {
+                    for (int t = 0; t < tq; ++t)
+                        memcpy(hmq + (((long)b * heads + h) * tq + t) * d, src_q + ((long)b * tq + t) * ld + h * d, d * 2);
+                    for (int t = 0; t < tk; ++t) {
+                        memcpy(hmk + (((long)b * heads + h) * tk + t) * d, src_kv + ((long)b * tk + t) * ld + C + h * d, d * 2);
+                        memcpy(hmv + (((long)b * heads + h) * tk + t) * d, src_kv + ((long)b * tk + t) * ld + 2 * C + h * d, d * 2);
+                    }
+                }
+            CK(hipMalloc(&dhm, hm.size() * 2));
+            CK(hipMemcpy(dhm, hm.data(), hm.size() * 2, hipMemcpyHostToDevice));
+            ad.K = dhm + rows_q * C; ad.V = dhm + (rows_q + rows_k) * C;
+            ad.k_ss = ad.v_ss = d; ad.k_hs = ad.v_hs = (int64_t)tk * d; ad.k_bs = ad.v_bs = (int64_t)heads * tk * d;
+            if (mode >= 2) { ad.Q = dhm; ad.q_ss = d; ad.q_hs = (int64_t)tq * d; ad.q_bs = (int64_t)heads * tq * d; }
+            printf("   [head-major %s operands]\n", mode >= 2 ? "Q, K, V" : "K, V");
+        }
         ad.batch = c.batch; ad.heads = heads; ad.head_dim = d; ad.Sq = c.Sq; ad.Sk = c.Sk; ad.causal = c.causal;
         ad.scale = scale;
         if (c.ws) { ad.window_ws = c.ws; ad.F = c.F; ad.H = c.H; ad.W = c.W; ad.Fq = c.F; }

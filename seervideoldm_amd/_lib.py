@@ -13,7 +13,7 @@ _PKG = Path(__file__).resolve().parent
 _LIB_PATH = _PKG / "lib" / "libseer_hip.so"
 _lib = None
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 SEER_GEMM_PLAIN = 0
 SEER_GEMM_CONV3X3 = 1
@@ -63,6 +63,7 @@ class AttnDesc(C.Structure):
         ("Fq", C.c_int32), ("causal_offset", C.c_int32),
         ("lse", C.c_void_p),
         ("flags", C.c_uint32), ("variant", C.c_int32),
+        ("q_hs", C.c_int64), ("k_hs", C.c_int64), ("v_hs", C.c_int64),
     ]
 
 
@@ -104,6 +105,8 @@ SIGNATURES = {
     "seer_nchw_f32_to_nhwc_bf16": ([_vp, _i32, _i32, _i32, _vp, _vp], C.c_int),
     "seer_nhwc_bf16_to_nchw_f32": ([_vp, _i32, _i32, _i32, _vp, _vp], C.c_int),
     "seer_cfg_ddim_step": ([_vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i32, _vp, _vp, _vp, _vp, _vp], C.c_int),
+    "seer_ddim_step_begin": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp], C.c_int),
+    "seer_cfg_ddim_step_dev": ([_vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp], C.c_int),
     "seer_clamp01": ([_vp, _i64, _vp], C.c_int),
     "seer_gaussian_sample": ([_vp, _i32, _i32, _i32, _vp, _vp, _vp], C.c_int),
     # training step

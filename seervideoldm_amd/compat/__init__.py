@@ -54,6 +54,10 @@ class _AliasFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
         mod = types.ModuleType(spec.name)
         rel = spec.name.replace(".", os.sep)
         mod.__path__ = [os.path.join(p or os.getcwd(), rel) for p in sys.path if os.path.isdir(os.path.join(p or os.getcwd(), rel))]
+        # submodules that were imported before install() stay importable as attributes of the new package object
+        for name, sub in list(sys.modules.items()):
+            if name.startswith(spec.name + ".") and "." not in name[len(spec.name) + 1:] and name not in ALIASES and name not in _PARENTS:
+                setattr(mod, name.rsplit(".", 1)[1], sub)
         return mod
 
     def exec_module(self, module):

@@ -117,9 +117,9 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
         tok.wy0 = (win / nwx) << ws_log2;
         tok.wx0 = (win % nwx) << ws_log2;
     }
-    const bf16* __restrict__ Qg = reinterpret_cast<const bf16*>(p.Q) + (int64_t)b * p.q_bs + head * D;
-    const bf16* __restrict__ Kg = reinterpret_cast<const bf16*>(p.K) + (int64_t)b * p.k_bs + head * D;
-    const bf16* __restrict__ Vg = reinterpret_cast<const bf16*>(p.V) + (int64_t)b * p.v_bs + head * D;
+    const bf16* __restrict__ Qg = reinterpret_cast<const bf16*>(p.Q) + (int64_t)b * p.q_bs + head * (p.q_hs ? p.q_hs : D);
+    const bf16* __restrict__ Kg = reinterpret_cast<const bf16*>(p.K) + (int64_t)b * p.k_bs + head * (p.k_hs ? p.k_hs : D);
+    const bf16* __restrict__ Vg = reinterpret_cast<const bf16*>(p.V) + (int64_t)b * p.v_bs + head * (p.v_hs ? p.v_hs : D);
     bf16* __restrict__ Og = reinterpret_cast<bf16*>(p.O) + (int64_t)b * p.o_bs + head * D;
 
     const int qblk0 = blockIdx.x * 128;
@@ -419,6 +419,7 @@ extern "C" int seer_attn_fwd(const seer_attn_desc* desc, void* stream) {
     if (d.batch <= 0 || d.heads <= 0 || d.Sq <= 0 || d.Sk <= 0) return SEER_EINVAL;
     if ((d.q_ss | d.k_ss | d.v_ss) % 8 || d.o_ss % 4) return SEER_EINVAL;
     if ((d.q_bs | d.k_bs | d.v_bs) % 8 || d.o_bs % 4) return SEER_EINVAL;
+    if ((d.q_hs | d.k_hs | d.v_hs) % 8 || d.q_hs < 0 || d.k_hs < 0 || d.v_hs < 0) return SEER_EINVAL;
     int ws_log2 = -1;
     if (d.window_ws > 0) {
         if (d.window_ws != 4 && d.window_ws != 8) return SEER_EINVAL;

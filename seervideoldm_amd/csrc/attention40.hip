@@ -158,8 +158,13 @@ extern "C" long long* seer_lab_a40_stamps() {
 #define A40_STAMP() do {} while (0)
 #endif
 
-template <int QB, bool TRACK_ONLY>
-__global__ void __launch_bounds__(256, 3) seer_attn40_kernel(const seer_attn_desc p, const int ws_log2, const int nqb) {
+// PLAIN: not causal, not windowed (the spatial self-attention and text cross-attention blocks): the window / diagonal
+// arithmetic folds away -- and the two uses of the kernel carry different names in a profile (the spatial [192,1024,40] block is
+// the north star's kernel target; the causal window form serves the temporal blocks at 36 us, and one name for both reads 43)
+template <int QB, bool TRACK_ONLY, bool PLAIN>
+__global__ void __launch_bounds__(256, 3) seer_attn40_kernel(const seer_attn_desc p, const int ws_log2_arg, const int nqb) {
+    const int ws_log2 = PLAIN ? -1 : ws_log2_arg;
+    const bool causal = PLAIN ? false : (p.causal != 0);
     constexpr int D = A40_D;
     constexpr int QW = 32 * QB;                      // queries per wave
     // two K|V stages + the constant region
@@ -197,14 +202,14 @@ __global__ void __launch_bounds__(256, 3) seer_attn40_kernel(const seer_attn_des
         tok.wy0 = (win / nwx) << ws_log2;
         tok.wx0 = (win % nwx) << ws_log2;
     }
-    const bf16* __restrict__ Qg = reinterpret_cast<const bf16*>(p.Q) + (int64_t)b * p.q_bs + head * D;
-    const bf16* __restrict__ Kg = reinterpret_cast<const bf16*>(p.K) + (int64_t)b * p.k_bs + head * D;
-    const bf16* __restrict__ Vg = reinterpret_cast<const bf16*>(p.V) + (int64_t)b * p.v_bs + head * D;
+    const bf16* __restrict__ Qg = reinterpret_cast<const bf16*>(p.Q) + (int64_t)b * p.q_bs + head * (p.q_hs ? p.q_hs : D);
+    const bf16* __restrict__ Kg = reinterpret_cast<const bf16*>(p.K) + (int64_t)b * p.k_bs + head * (p.k_hs ? p.k_hs : D);
+    const bf16* __restrict__ Vg = reinterpret_cast<const bf16*>(p.V) + (int64_t)b * p.v_bs + head * (p.v_hs ? p.v_hs : D);
     bf16* __restrict__ Og = reinterpret_cast<bf16*>(p.O) + (int64_t)b * p.o_bs + head * D;
 
     const int qblk0 = qblk * (4 * QW);
     const int q0w = qblk0 + wave * QW;               // first query of this wave
-    const int q_off = p.causal_offset;
+    const int q_off = PLAIN ? 0 : p.causal_offset;
 
     // ---- constant region: zeros, with {1.0, 0, 0, 0} at the four offsets a padding lane's reads land on.
     //      K' column 40.. = {1, 0 x7} = its first 16 bytes; V' columns 40..43 = {1, 0, 0, 0} = zreg + 0 (+160, +1280, +1440),
@@ -217,7 +222,7 @@ __global__ void __launch_bounds__(256, 3) seer_attn40_kernel(const seer_attn_des
 
     // ---- keys this block needs
     int k_end = p.Sk;
-    if (p.causal) k_end = min(p.Sk, min(qblk0 + 4 * QW, p.Sq) + q_off);
+    if (causal) k_end = min(p.Sk, min(qblk0 + 4 * QW, p.Sq) + q_off);
     const int ntiles = (k_end + A40_KT - 1) / A40_KT;
 
     // ---- LDS-DMA plan: 20 wave instructions per tile (10 K + 10 V, 1 KiB each), wave w issues e = w + 4 i.
@@ -316,7 +321,7 @@ __global__ void __launch_bounds__(256, 3) seer_attn40_kernel(const seer_attn_des
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const bool ok = (key < p.Sk) && (!p.causal || key <= qi + q_off);
+            const bool ok = (key < p.Sk) && (!causal || key <= qi + q_off);
             s[r] = ok ? s[r] : A40_NEG_INF;
         }
     };
@@ -358,7 +363,7 @@ __global__ void __launch_bounds__(256, 3) seer_attn40_kernel(const seer_attn_des
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) {
                     f32x16 s = qk(kf, qb);
-                    if ((31 >= p.Sk) || (p.causal && 31 > q0w + 32 * qb + q_off)) mask_scores(s, 0, qb);
+                    if ((31 >= p.Sk) || (causal && 31 > q0w + 32 * qb + q_off)) mask_scores(s, 0, qb);
                     float mx = s[0];
 #pragma unroll
                     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
@@ -371,7 +376,7 @@ __global__ void __launch_bounds__(256, 3) seer_attn40_kernel(const seer_attn_des
             for (int sub = 0; sub < 4; ++sub) {
                 const int kb = kt0 + 32 * sub;
                 // wave-uniform: past the last key, or above the causal diagonal of every query of the wave
-                if (kb >= k_end || q0w >= p.Sq || (p.causal && kb > q0w + QW - 1 + q_off)) continue;
+                if (kb >= k_end || q0w >= p.Sq || (causal && kb > q0w + QW - 1 + q_off)) continue;
                 const unsigned kst = st_a + sub * 32 * A40_ROWB;
                 bf16x8 kf[3];
                 VRegs vraw;
@@ -383,9 +388,9 @@ __global__ void __launch_bounds__(256, 3) seer_attn40_kernel(const seer_attn_des
                 bool v_ready = false;
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) {
-                    if (p.causal && kb > q0w + 32 * qb + 31 + q_off) continue;      // this query block is above the diagonal
+                    if (causal && kb > q0w + 32 * qb + 31 + q_off) continue;      // this query block is above the diagonal
                     f32x16 s = qk(kf, qb);                                          // S' = s - m, exp2 domain
-                    if ((kb + 31 >= p.Sk) || (p.causal && kb + 31 > q0w + 32 * qb + q_off)) mask_scores(s, kb, qb);
+                    if ((kb + 31 >= p.Sk) || (causal && kb + 31 > q0w + 32 * qb + q_off)) mask_scores(s, kb, qb);
                     if constexpr (TRACK) {
                         float mx = s[0];
 #pragma unroll
@@ -509,8 +514,11 @@ int seer_attn40_launch(const seer_attn_desc& d, int ws_log2, hipStream_t st) {
     const bool track = d.variant == 5 || d.lse != nullptr;
     const int nqb = (d.Sq + 127) / 128;
     dim3 grid((unsigned)(nqb * nbatch * d.heads));
-    if (track) hipLaunchKernelGGL((seer_attn40_kernel<1, true>), grid, dim3(256), 0, st, d, ws_log2, nqb);
-    else hipLaunchKernelGGL((seer_attn40_kernel<1, false>), grid, dim3(256), 0, st, d, ws_log2, nqb);
+    const bool plain = ws_log2 < 0 && !d.causal && d.causal_offset == 0;
+    if (track && plain) hipLaunchKernelGGL((seer_attn40_kernel<1, true, true>), grid, dim3(256), 0, st, d, ws_log2, nqb);
+    else if (track) hipLaunchKernelGGL((seer_attn40_kernel<1, true, false>), grid, dim3(256), 0, st, d, ws_log2, nqb);
+    else if (plain) hipLaunchKernelGGL((seer_attn40_kernel<1, false, true>), grid, dim3(256), 0, st, d, ws_log2, nqb);
+    else hipLaunchKernelGGL((seer_attn40_kernel<1, false, false>), grid, dim3(256), 0, st, d, ws_log2, nqb);
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }

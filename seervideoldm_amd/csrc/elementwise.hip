@@ -313,6 +313,63 @@ __global__ void cfg_ddim_kernel(const float* __restrict__ eps, int cfg, int b, i
     if (pred_x0) pred_x0[i] = x0;
 }
 
+// ---- the same step with its schedule index in DEVICE memory (a whole p_sample_ddim captured in one hipGraph: the kernel
+// arguments of a replay are frozen, the step counter is not).  step[0] = index of the NEXT step to run, step[1] = index of the
+// step in flight.  seer_ddim_step_begin (first kernel of a step) reads step[0] everywhere and one thread copies it to step[1];
+// seer_cfg_ddim_step_dev (last kernel) reads step[1] everywhere and one thread writes step[0] = index - 1: no kernel both reads
+// and writes a word, so a chain of replays walks the schedule downwards without the host touching device memory.
+// Input assembly of ddim_video.py:189,201-203: the UNet input [reps*b, C, F, HW] = cat([x0_emb, x], frames), repeated for the CFG
+// pair, and t[reps*b] = timesteps[index].
+__global__ void ddim_assemble_kernel(const float* __restrict__ x0_emb, const float* __restrict__ x, int b, int reps, int C, int f1,
+                                     int Fp, int HW, const int64_t* __restrict__ t_table, int* __restrict__ step,
+                                     float* __restrict__ sample, int64_t* __restrict__ t_out) {
+    const int F = f1 + Fp;
+    const int64_t per = (int64_t)b * C * F * HW;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int index = step[0];
+    if (i == 0) step[1] = index;
+    if (i < reps * b) t_out[i] = t_table[index];
+    if (i >= per) return;
+    const int hw = (int)(i % HW);
+    const int f = (int)((i / HW) % F);
+    const int64_t bc = i / ((int64_t)HW * F);            // bi * C + c
+    const float v = f < f1 ? x0_emb[(bc * f1 + f) * HW + hw] : x[(bc * Fp + (f - f1)) * HW + hw];
+    for (int r = 0; r < reps; ++r) sample[i + r * per] = v;
+}
+
+// x may alias x_prev (the captured step updates its latent in place): every thread reads its element before it writes it
+__global__ void cfg_ddim_dev_kernel(const float* __restrict__ eps, int cfg, int b, int C, int Ft, int cond_f, int HW, float scale,
+                                    const float* __restrict__ coef, int* __restrict__ step, const float* x,
+                                    const float* __restrict__ noise, float* x_prev, float* __restrict__ pred_x0) {
+    const int Fp = Ft - cond_f;
+    const int64_t n = (int64_t)b * C * Fp * HW;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int index = step[1];
+    if (i == 0) step[0] = index - 1;
+    if (i >= n) return;
+    const int hw = (int)(i % HW);
+    const int f = (int)((i / HW) % Fp);
+    const int c = (int)((i / ((int64_t)HW * Fp)) % C);
+    const int bi = (int)(i / ((int64_t)HW * Fp * C));
+    const int64_t eoff = (((int64_t)bi * C + c) * Ft + (f + cond_f)) * HW + hw;
+    float e;
+    if (cfg) {
+        const float eu = eps[eoff];
+        const float ec = eps[eoff + (int64_t)b * C * Ft * HW];
+        e = eu + scale * (ec - eu);
+    } else {
+        e = eps[eoff];
+    }
+    const float a_t = coef[4 * index], a_prev = coef[4 * index + 1], sigma = coef[4 * index + 2], s1m = coef[4 * index + 3];
+    const float xv = x[i];
+    const float x0 = (xv - s1m * e) / sqrtf(a_t);
+    const float dir = sqrtf(1.f - a_prev - sigma * sigma) * e;
+    float nz = 0.f;
+    if (noise) nz = sigma * noise[i];
+    x_prev[i] = sqrtf(a_prev) * x0 + dir + nz;
+    if (pred_x0) pred_x0[i] = x0;
+}
+
 // pointwise channel mix on NCHW fp32 (VAE post_quant_conv, 4 -> 4): y[n,co,p] = sum_ci W[co,ci] x[n,ci,p] + b[co]
 __global__ void conv1x1_nchw_kernel(const float* __restrict__ x, int N, int Cin, int Cout, int HW,
                                     const float* __restrict__ Wt, const float* __restrict__ bias, float* __restrict__ y) {
@@ -495,6 +552,30 @@ extern "C" int seer_cfg_ddim_step(const float* eps, int32_t cfg, int32_t b, int3
     return SEER_OK;
 }
 
+extern "C" int seer_ddim_step_begin(const float* x0_emb, const float* x, int32_t b, int32_t reps, int32_t C, int32_t f1,
+                                    int32_t F_pred, int32_t HW, const int64_t* t_table, int32_t* step, float* sample,
+                                    int64_t* t_out, void* stream) {
+    if (!x || !t_table || !step || !sample || !t_out || b <= 0 || reps <= 0 || C <= 0 || f1 < 0 || F_pred <= 0 || HW <= 0 ||
+        (f1 > 0 && !x0_emb))
+        return SEER_EINVAL;
+    const int64_t n = (int64_t)b * C * (f1 + F_pred) * HW;
+    hipLaunchKernelGGL(ddim_assemble_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), x0_emb, x, b, reps, C, f1,
+                       F_pred, HW, t_table, step, sample, t_out);
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int seer_cfg_ddim_step_dev(const float* eps, int32_t cfg, int32_t b, int32_t C, int32_t F_total, int32_t cond_f,
+                                      int32_t HW, float scale, const float* coef, int32_t* step, const float* x,
+                                      const float* noise, float* x_prev, float* pred_x0, void* stream) {
+    if (!eps || !coef || !step || !x || !x_prev || b <= 0 || C <= 0 || F_total <= cond_f || cond_f < 0 || HW <= 0) return SEER_EINVAL;
+    const int64_t n = (int64_t)b * C * (F_total - cond_f) * HW;
+    hipLaunchKernelGGL(cfg_ddim_dev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), eps, cfg, b, C, F_total,
+                       cond_f, HW, scale, coef, step, x, noise, x_prev, pred_x0);
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
 extern "C" int seer_conv1x1_nchw_f32(const float* x, int32_t N, int32_t Cin, int32_t Cout, int32_t HW, const float* Wt,
                                      const float* bias, float* y, void* stream) {
     if (!x || !Wt || !y || N <= 0 || Cin <= 0 || Cout <= 0 || HW <= 0) return SEER_EINVAL;
@@ -522,7 +603,7 @@ extern "C" int seer_gaussian_sample(const float* moments, int32_t N, int32_t C, 
     return SEER_OK;
 }
 
-extern "C" int seer_abi_version(void) { return 14; }
+extern "C" int seer_abi_version(void) { return 15; }
 extern "C" const char* seer_build_arch(void) { return "gfx950"; }
 extern "C" const char* seer_strerror(int code) {
     switch (code) {

@@ -720,9 +720,12 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
             }
         }
         if constexpr (!GEGLU) {
-            if (do_rot) {
+            if (do_rot && n0 + wn * WTN < p.rot_cols) {      // (wave-uniform: a wave whose columns are all v columns has nothing to rotate)
                 // rotary on the q|k columns (attention.py:649-651), as in the general body, with the channel of each fragment
-                // column and the position of each fragment row computed once per lane instead of once per quad
+                // column and the position of each fragment row computed once per lane instead of once per quad.
+                // (Measured and dropped, profiles/r03_rotary_loads.log: unconditional (cos, sin) loads issued together per fragment
+                //  row, the unrotated quads kept by a select -- 33.5 vs 32.2 us on the 24 576-row projection: the cost of the
+                //  epilogue is the 63 MB of table reads per launch, not their latency.)
                 int tj[TN];                                 // float offset of the lane's (cos, sin) pairs in a table row, or -1
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {

@@ -56,6 +56,9 @@ class DDIMSampler(object):
         self.schedule = schedule
         self.device = torch.device(device) if not isinstance(device, torch.device) else device
         self.consume_rng_when_deterministic = True
+        # p_sample_ddim under graph replay hands out its static latent buffers instead of copies of them: the next step
+        # overwrites what the previous one returned.  ddim_sampling sets it for its own loop (and copies what it keeps).
+        self.static_step_outputs = False
 
     def register_buffer(self, name, attr):
         setattr(self, name, attr)
@@ -120,22 +123,28 @@ class DDIMSampler(object):
         timesteps = self.ddim_timesteps
         intermediates = {"x_inter": [img], "pred_x0": [img]}
         total_steps = timesteps.shape[0]
-        for i, step in enumerate(np.flip(timesteps)):
-            index = total_steps - i - 1
-            ts = self._t_table[index].expand(b)
-            img, pred_x0 = self.p_sample_ddim(unet, img, cond, ts, index=index, is_3d=is_3d, x0_emb=x0_emb,
-                                              cond_frames=cond_frames, temperature=temperature,
-                                              noise_dropout=noise_dropout,
-                                              unconditional_guidance_scale=unconditional_guidance_scale,
-                                              unconditional_conditioning=unconditional_conditioning)
-            if callback:
-                callback(i)
-            if img_callback:
-                img_callback(pred_x0, i)
-            if index % log_every_t == 0 or index == total_steps - 1:
-                intermediates["x_inter"].append(img)
-                intermediates["pred_x0"].append(pred_x0)
-        return img, intermediates
+        # inside this loop a captured step may hand out its static buffers (nothing here keeps a step's output past the next
+        # step without copying it)
+        static_before, self.static_step_outputs = self.static_step_outputs, True
+        try:
+            for i, step in enumerate(np.flip(timesteps)):
+                index = total_steps - i - 1
+                ts = self._t_table[index].expand(b)
+                img, pred_x0 = self.p_sample_ddim(unet, img, cond, ts, index=index, is_3d=is_3d, x0_emb=x0_emb,
+                                                  cond_frames=cond_frames, temperature=temperature,
+                                                  noise_dropout=noise_dropout,
+                                                  unconditional_guidance_scale=unconditional_guidance_scale,
+                                                  unconditional_conditioning=unconditional_conditioning)
+                if callback:
+                    callback(i)
+                if img_callback:
+                    img_callback(pred_x0.clone(), i)
+                if index % log_every_t == 0 or index == total_steps - 1:
+                    intermediates["x_inter"].append(img.clone())
+                    intermediates["pred_x0"].append(pred_x0.clone())
+        finally:
+            self.static_step_outputs = static_before
+        return img.clone(), intermediates
 
     @torch.no_grad()
     def p_sample_ddim(self, unet, x, c, t, index, is_3d=True, x0_emb=None, cond_frames=0, repeat_noise=False,
@@ -148,11 +157,21 @@ class DDIMSampler(object):
         b = x.shape[0]
         cond_f = 0
         x = x.to(torch.float32).contiguous()
+        uc, scale = unconditional_conditioning, unconditional_guidance_scale
+        sigma = float(self.ddim_sigmas[index])
+        # the whole step -- input assembly, CFG-batched UNet, CFG combine, DDIM update -- as ONE replayed hipGraph when the model
+        # replays graphs anyway (unet.use_graph) and the step is the one ddim_sample drives: batched CFG or none, eta = 0, and
+        # t = the schedule's own timestep of `index` (recognised by its address: a view of the device timestep table)
+        if (sigma == 0. and getattr(unet, "use_graph", False) and x.is_cuda and (uc is None or scale == 1. or uc.shape[2] == c.shape[2])
+                and torch.is_tensor(t) and t.dtype == torch.long and t.data_ptr() == self._t_table.data_ptr() + 8 * int(index)):
+            plain = uc is None or scale == 1.
+            done = self._graph_step(unet, x, c, None if plain else uc, index, x0_emb, 0 if plain else cond_frames, scale)
+            if done is not None:
+                return done
         x_cat = x
         if x0_emb is not None:
             cond_f = x0_emb.shape[2]
             x_cat = torch.cat([x0_emb.to(x.dtype), x], dim=2)
-        uc, scale = unconditional_conditioning, unconditional_guidance_scale
         t = t.to(torch.long)
         if uc is None or scale == 1.:
             eps = unet(x_cat, t, c)
@@ -170,7 +189,6 @@ class DDIMSampler(object):
             e_c = unet(x_cat, t, c, cond_frame=cond_frames)
             eps = torch.cat([e_uc, e_c])
             cfg = True
-        sigma = float(self.ddim_sigmas[index])
         noise = None
         if sigma != 0. or self.consume_rng_when_deterministic:
             noise = torch.randn(x.shape, device=x.device) * temperature
@@ -179,6 +197,113 @@ class DDIMSampler(object):
         x_prev, pred_x0 = ops.cfg_ddim_step(eps.float().contiguous(), x, self.ddim_coef, index, cfg=cfg, scale=scale,
                                             cond_f=cond_f, noise=noise if sigma != 0. else None)
         return x_prev, pred_x0
+
+
+    # ---- the captured step -----------------------------------------------------------------------------------------
+    def _graph_step(self, unet, x, c, uc, index, x0_emb, cond_frames, scale):
+        """One p_sample_ddim as a single hipGraph replay (seer_ddim_step_begin -> the UNet's kernels -> seer_cfg_ddim_step_dev):
+        no torch kernel between two UNet evaluations except the reference's per-step RNG draw, no host-written scalars -- the
+        schedule index lives in device memory and the captured step counts it down itself.  Returns None when this step cannot
+        take the path (sharded model, capture refused): the caller then runs the launches one by one."""
+        from .unet import SeerUNet
+        if not isinstance(unet, SeerUNet) or unet._shard is not None or unet._ops_backend is not ops \
+                or unet.config.center_input_sample or getattr(self, "_step_graph_broken", False):
+            return None
+        if unet._engine is None or unet._engine.device != x.device:
+            unet.prepare()
+        eng = unet._engine
+        if getattr(eng, "_graph_broken", False):
+            return None
+        cfg = uc is not None
+        if cfg:
+            cached = getattr(self, "_cfg_inputs", None)
+            if cached is None or cached[0] is not c or cached[1] is not uc or cached[3] != (c._version, uc._version):
+                cached = (c, uc, torch.cat([uc, c]).contiguous(), (c._version, uc._version))
+                self._cfg_inputs = cached
+            context = cached[2]
+        else:
+            context = c
+        b, Cc, Fp, h, w = x.shape
+        f1 = 0 if x0_emb is None else x0_emb.shape[2]
+        reps = 2 if cfg else 1
+        if context.dim() == 3:
+            context = context[:, None].expand(-1, f1 + Fp, -1, -1)
+        if context.shape[0] != reps * b or context.shape[1] != f1 + Fp or h % 8 or w % 8:
+            return None
+        ctx, L = eng._context(context)          # new prompt: the static context / K|V buffers are refreshed in place
+        key = ("step", (b, Cc, Fp, h, w), f1, cfg, int(cond_frames), float(scale), L, tuple(ctx.shape))
+        G = eng._graphs.get(key)
+        if G is None:
+            G = self._capture_step(eng, key, x, x0_emb, reps, cfg, int(cond_frames), float(scale), ctx, L)
+            if G is None:
+                return None
+        # inputs that are read by address: refreshed in place when the caller brings new ones (once per sample / per schedule)
+        # (the keyed tensors are kept alive with their keys: a freed tensor's address handed to the next sample's tensor must not
+        #  look like "unchanged")
+        if x0_emb is not None:
+            k0 = (x0_emb.data_ptr(), x0_emb._version)
+            if G["x0_key"] != k0 or G["x0_ref"] is not x0_emb:
+                G["x0"].copy_(x0_emb)
+                G["x0_key"], G["x0_ref"] = k0, x0_emb
+        ksch = (self.ddim_coef.data_ptr(), self._t_table.data_ptr(), self.ddim_coef.shape[0])
+        if G["sched_key"] != ksch or G["sched_ref"][0] is not self.ddim_coef:
+            n = self.ddim_coef.shape[0]
+            if n > G["coef"].shape[0]:
+                return None                         # a longer schedule than the one captured for: take the eager path
+            G["coef"][:n].copy_(self.ddim_coef)
+            G["ttab"][:n].copy_(self._t_table)
+            G["sched_key"], G["sched_ref"] = ksch, (self.ddim_coef, self._t_table)
+            G["expect"] = None
+        if x is not G["x"] and x.data_ptr() != G["x"].data_ptr():
+            G["x"].copy_(x)
+        if G["expect"] != index:
+            G["step"][:1].fill_(int(index))         # start of a chain (or a caller that jumps): the only host-written index
+        if self.consume_rng_when_deterministic:
+            torch.randn(x.shape, device=x.device)   # ddim_video.py:234 draws every step, also at sigma = 0: keep the RNG stream
+        G["graph"].replay()
+        G["expect"] = index - 1
+        if self.static_step_outputs:
+            return G["x"], G["pred"]
+        return G["x"].clone(), G["pred"].clone()
+
+    def _capture_step(self, eng, key, x, x0_emb, reps, cfg, cond_frames, scale, ctx, L):
+        dev = x.device
+        b, Cc, Fp, h, w = x.shape
+        f1 = 0 if x0_emb is None else x0_emb.shape[2]
+        nsched = max(int(self.ddim_coef.shape[0]), 64)
+        G = dict(x=torch.empty_like(x), pred=torch.empty_like(x),
+                 x0=(torch.empty_like(x0_emb, dtype=torch.float32).contiguous() if x0_emb is not None else None), x0_key=None,
+                 sample=torch.empty((reps * b, Cc, f1 + Fp, h, w), device=dev, dtype=torch.float32),
+                 t=torch.empty((reps * b,), device=dev, dtype=torch.long), step=torch.zeros((2,), device=dev, dtype=torch.int32),
+                 coef=torch.zeros((nsched, 4), device=dev, dtype=torch.float32),
+                 ttab=torch.zeros((nsched,), device=dev, dtype=torch.long), sched_key=None, sched_ref=(None, None), x0_ref=None,
+                 expect=None)
+        G["coef"][:, 0] = 1.0                        # a_t = 1 in the unused rows: the warm-up below must stay finite
+        G["x"].copy_(x)
+        if x0_emb is not None:
+            G["x0"].copy_(x0_emb)
+
+        def body():
+            ops.ddim_step_begin(G["x0"], G["x"], G["ttab"], G["step"], reps, G["sample"], G["t"])
+            eps = eng._forward(G["sample"], G["t"], ctx, L, cond_frames)
+            ops.cfg_ddim_step_dev(eps, G["x"], G["coef"], G["step"], cfg=cfg, scale=scale, cond_f=f1, x_prev=G["x"],
+                                  pred_x0=G["pred"])
+        try:
+            body()                                   # warm-up: K|V / rotary caches, allocations
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                body()
+        except Exception as e:      # noqa: BLE001  capture refused: keep the launch-by-launch path
+            self._step_graph_broken = True
+            import warnings
+            warnings.warn(f"hipGraph capture of the sampler step failed ({type(e).__name__}: {e}); stepping launch by launch")
+            return None
+        G["graph"] = g
+        if len(eng._graphs) > 6:
+            eng._graphs.clear()
+        eng._graphs[key] = G
+        return G
 
 
 def _from_rank0(unet, t: torch.Tensor) -> torch.Tensor:

@@ -234,13 +234,15 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
               window=None, Fq: Optional[int] = None, causal_offset: int = 0,
               seq_stride_rows: int = 1, batch_stride_rows: Optional[int] = None,
               lse: Optional[torch.Tensor] = None, q_prescaled: bool = False, variant: int = 0,
-              _desc_only: bool = False) -> torch.Tensor:
+              q_head_major: bool = False, kv_head_major: bool = False, _desc_only: bool = False) -> torch.Tensor:
     """q/k/v/out are 2-D token-major views [batch*S, >=heads*head_dim] (row stride = token stride, e.g. column slices
     of a fused qkv buffer).  window = (ws, F, H, W) selects the temporal window form (K/V: F*H*W tokens per batch
     element in memory, Sk = F*ws*ws per window; Q/O hold Fq frames, Fq = F unless frame-sharded).  causal_offset is the
     sequence position of query 0 in the key sequence (frame shards).  seq_stride_rows / batch_stride_rows: token s of
     sequence b sits in row b*batch_stride_rows + s*seq_stride_rows (default: sequences stored one after the other) --
     FSTextTransformer's attention over frames reads rows ordered (frame, token) with seq stride = tokens per frame.
+    q_head_major / kv_head_major: that operand is HEAD-MAJOR, [batch][head][tokens][head_dim] contiguous, passed as its 2-D view
+    [batch * heads * tokens, head_dim] (seer_attn_desc::q_hs / k_hs / v_hs); `out` is always token-major.
     q_prescaled: q already holds q * scale * log2(e) (gemm(..., col_scale=(qk_prescale(head_dim), cols))).
     variant: kernel selection for A/B runs (include/seer_hip.h, seer_attn_desc.variant); 0 = auto."""
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (out, "out")):
@@ -257,11 +259,19 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
         Fq = F if Fq is None else Fq
         tq, tk = Fq * H * W, F * H * W
         d.window_ws, d.F, d.H, d.W, d.Fq = ws, F, H, W, Fq
-    assert q.shape[0] == batch * tq and k.shape[0] == batch * tk and v.shape[0] == batch * tk
+    assert q.shape[0] == batch * tq * (heads if q_head_major else 1) and out.shape[0] == batch * tq
+    assert k.shape[0] == v.shape[0] == batch * tk * (heads if kv_head_major else 1)
     d.q_bs, d.o_bs = tq * q.stride(0), tq * out.stride(0)
     d.k_bs, d.v_bs = tk * k.stride(0), tk * v.stride(0)
+    if q_head_major:
+        assert q.is_contiguous() and q.shape[1] == head_dim
+        d.q_hs, d.q_bs = tq * head_dim, heads * tq * head_dim
+    if kv_head_major:
+        assert k.is_contiguous() and v.is_contiguous() and k.shape[1] == v.shape[1] == head_dim
+        d.k_hs = d.v_hs = tk * head_dim
+        d.k_bs = d.v_bs = heads * tk * head_dim
     if seq_stride_rows != 1 or batch_stride_rows is not None:
-        assert window is None and batch_stride_rows is not None
+        assert window is None and batch_stride_rows is not None and not (q_head_major or kv_head_major)
         d.q_ss, d.k_ss, d.v_ss, d.o_ss = (seq_stride_rows * t.stride(0) for t in (q, k, v, out))
         d.q_bs, d.k_bs, d.v_bs, d.o_bs = (batch_stride_rows * t.stride(0) for t in (q, k, v, out))
     d.batch, d.heads, d.head_dim, d.Sq, d.Sk = batch, heads, head_dim, Sq, Sk
@@ -489,6 +499,34 @@ def cfg_ddim_step(eps: torch.Tensor, x: torch.Tensor, coef: torch.Tensor, index:
     check(_lib.load().seer_cfg_ddim_step(_p(eps), int(cfg), b, Cc, Ft, cond_f, h * w, float(scale), _p(coef), index,
                                          _p(x), _p(noise), _p(x_prev), _p(pred), _stream()), "seer_cfg_ddim_step")
     return x_prev, pred
+
+
+def ddim_step_begin(x0_emb: Optional[torch.Tensor], x: torch.Tensor, t_table: torch.Tensor, step: torch.Tensor, reps: int,
+                    sample: torch.Tensor, t_out: torch.Tensor) -> None:
+    """first kernel of a captured sampler step: sample[reps*b, C, f1+Fp, h, w] = cat([x0_emb, x], 2) x reps,
+    t_out[:] = t_table[step[0]], step[1] = step[0] (include/seer_hip.h, seer_ddim_step_begin)"""
+    _req(x, torch.float32, "x"); _req(t_table, torch.int64, "t_table"); _req(step, torch.int32, "step")
+    b, Cc, Fp, h, w = x.shape
+    f1 = 0 if x0_emb is None else x0_emb.shape[2]
+    if x0_emb is not None:
+        _req(x0_emb, torch.float32, "x0_emb")
+        assert x0_emb.is_contiguous() and x0_emb.shape[:2] == x.shape[:2] and x0_emb.shape[3:] == x.shape[3:]
+    assert x.is_contiguous() and sample.is_contiguous() and sample.shape == (reps * b, Cc, f1 + Fp, h, w) and step.numel() >= 2
+    assert sample.dtype == torch.float32 and t_out.dtype == torch.int64 and t_out.numel() == reps * b
+    check(_lib.load().seer_ddim_step_begin(_p(x0_emb), _p(x), b, reps, Cc, f1, Fp, h * w, _p(t_table), _p(step), _p(sample),
+                                           _p(t_out), _stream()), "seer_ddim_step_begin")
+
+
+def cfg_ddim_step_dev(eps: torch.Tensor, x: torch.Tensor, coef: torch.Tensor, step: torch.Tensor, *, cfg: bool, scale: float,
+                      cond_f: int, x_prev: torch.Tensor, pred_x0: Optional[torch.Tensor], noise: Optional[torch.Tensor] = None):
+    """last kernel of a captured sampler step: cfg_ddim_step with index = step[1], then step[0] = index - 1; x_prev may be x"""
+    _req(eps, torch.float32, "eps"); _req(x, torch.float32, "x"); _req(coef, torch.float32, "coef"); _req(step, torch.int32, "step")
+    assert eps.is_contiguous() and x.is_contiguous() and x_prev.is_contiguous() and x_prev.shape == x.shape
+    b, Cc, Fp, h, w = x.shape
+    Ft = eps.shape[2]
+    assert Ft == Fp + cond_f and eps.shape[0] == (2 * b if cfg else b)
+    check(_lib.load().seer_cfg_ddim_step_dev(_p(eps), int(cfg), b, Cc, Ft, cond_f, h * w, float(scale), _p(coef), _p(step), _p(x),
+                                             _p(noise), _p(x_prev), _p(pred_x0), _stream()), "seer_cfg_ddim_step_dev")
 
 
 def clamp01_(x: torch.Tensor) -> torch.Tensor:

@@ -48,13 +48,13 @@ def test_other_modules_of_a_checkout_keep_resolving(tmp_path, installed, monkeyp
     (tmp_path / "utils" / "fvd_like.py").write_text("VALUE = 41\n")
     (tmp_path / "utils" / "ddim_sampling_utils.py").write_text("raise ImportError('the reference file must not be imported')\n")
     (tmp_path / "ldm" / "models" / "diffusion").mkdir(parents=True)
-    (tmp_path / "ldm" / "util.py").write_text("VALUE = 42\n")
+    (tmp_path / "ldm" / "util_like.py").write_text("VALUE = 42\n")
     monkeypatch.syspath_prepend(str(tmp_path))
     compat.install()          # again: drops cached parents so that the new sys.path entry is seen
     import utils.fvd_like
-    import ldm.util
+    import ldm.util_like
     from utils.ddim_sampling_utils import ddim_sample
-    assert utils.fvd_like.VALUE == 41 and ldm.util.VALUE == 42 and ddim_sample is seervideoldm_amd.ddim_sample
+    assert utils.fvd_like.VALUE == 41 and ldm.util_like.VALUE == 42 and ddim_sample is seervideoldm_amd.ddim_sample
 
 
 def test_runner_executes_an_unchanged_script(tmp_path):

@@ -378,6 +378,27 @@ def test_attention_fused_qkv_layout(device):
     _close(out, ref, rtol=2e-2, atol=1e-2, what="fused-qkv attention")
 
 
+@pytest.mark.parametrize("d,S,window", [(40, 1024, None), (40, 300, None), (80, 256, None), (40, 3 * 64, (8, 3, 16, 16))])
+def test_attention_head_major_operands(device, d, S, window):
+    """seer_attn_desc::q_hs / k_hs / v_hs: the same q, k, v handed over HEAD-MAJOR ([batch][head][tokens][d] contiguous) give the
+    bits of the token-major call -- same arithmetic, other addresses -- in both kernels, plain and windowed-causal"""
+    from seervideoldm_amd import ops
+    B, Hh = 2, 8
+    C = Hh * d
+    tok = S if window is None else window[1] * window[2] * window[3]
+    qkv = _rand((B * tok, 3 * C), device, 17).to(bf16)
+    kw = dict(batch=B, heads=Hh, head_dim=d, Sq=S, Sk=S, causal=window is not None, window=window)
+    want = torch.empty((B * tok, C), device=device, dtype=bf16)
+    ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], want, **kw)
+    hm = [t.reshape(B, tok, Hh, d).permute(0, 2, 1, 3).contiguous().reshape(B * Hh * tok, d) for t in qkv.split(C, dim=1)]
+    got = torch.empty_like(want)
+    ops.attention(qkv[:, :C], hm[1], hm[2], got, kv_head_major=True, **kw)
+    assert torch.equal(got, want)
+    got2 = torch.empty_like(want)
+    ops.attention(hm[0], hm[1], hm[2], got2, q_head_major=True, kv_head_major=True, **kw)
+    assert torch.equal(got2, want)
+
+
 def test_attention_random_shapes(device):
     """seeded ragged sequence lengths (tails in the last query block and the last key tile), causal with a query offset"""
     from seervideoldm_amd import ops

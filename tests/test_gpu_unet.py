@@ -167,6 +167,57 @@ def test_ddim_sampler_and_decode_match_oracle(device):
     assert clip1.shape == clip.shape
 
 
+def test_captured_sampler_step_equals_the_launch_by_launch_step(device):
+    """unet.use_graph: p_sample_ddim runs as ONE hipGraph -- input assembly, UNet, CFG combine, DDIM update, with the schedule
+    index counted down in device memory (seer_ddim_step_begin / seer_cfg_ddim_step_dev).  Same bits as the eager launches:
+    over whole samples, for a second sample (new start code, new conditioning frames, new prompt), for another schedule
+    length, for a caller that keeps the returned tensors or jumps in the schedule, and the RNG stream ends in the same state."""
+    cfg, sd, m = _model("mini", device)
+    b, f1, Fp, H = 1, 1, 2, 16
+    sampler = DDIMSampler(device)
+
+    def draw(seed):
+        x0 = (_randn((b, 4, f1, H, H), seed) * 0.9).to(device)
+        c = _randn((b, f1 + Fp, 77, cfg["cross_attention_dim"]), seed + 1).to(device)
+        uc = _randn((b, 1, 77, cfg["cross_attention_dim"]), seed + 2).expand(-1, f1 + Fp, -1, -1).contiguous().to(device)
+        return x0, c, uc, _randn((b, 4, Fp, H, H), seed + 3).to(device)
+
+    def sample(graph, S, args, scale=7.5):
+        x0, c, uc, noise = args
+        m.use_graph = graph
+        torch.manual_seed(5)
+        lat, inter = sampler.sample(unet=m, S=S, conditioning=c, batch_size=b, shape=(4, Fp, H, H), x0_emb=x0, verbose=False,
+                                    unconditional_guidance_scale=scale, unconditional_conditioning=uc, eta=0.0, x_T=noise, is_3d=True)
+        return lat, inter, torch.rand(3, device=device)
+
+    try:
+        for S, seed, scale in ((4, 1, 7.5), (4, 11, 7.5), (6, 21, 7.5), (4, 31, 1.0)):
+            args = draw(seed)
+            want, wi, wr = sample(False, S, args, scale)
+            got, gi, gr = sample(True, S, args, scale)
+            assert torch.equal(got, want) and torch.equal(gr, wr), (S, seed)
+            assert all(torch.equal(a, b_) for a, b_ in zip(gi["x_inter"] + gi["pred_x0"], wi["x_inter"] + wi["pred_x0"]))
+        assert any(isinstance(k, tuple) and k and k[0] == "step" for k in m._engine._graphs), "the captured step never ran"
+        # direct calls: the returned tensors are the caller's (not overwritten by the next step), and any index may come next
+        x0, c, uc, noise = draw(41)
+        sampler.make_schedule(4, verbose=False)
+        outs = {}
+        for graph in (False, True):
+            m.use_graph = graph
+            x = noise
+            seq = []
+            for index in (3, 2, 0, 1):
+                x, pred = sampler.p_sample_ddim(m, x, c, sampler._t_table[index].expand(b), index=index, x0_emb=x0,
+                                                unconditional_guidance_scale=7.5, unconditional_conditioning=uc)
+                seq.append((x, pred))
+            outs[graph] = seq
+        for (xa, pa), (xb, pb) in zip(outs[False], outs[True]):
+            assert torch.equal(xa, xb) and torch.equal(pa, pb)
+        assert len({t.data_ptr() for t, _ in outs[True]}) == 4
+    finally:
+        m.use_graph = False
+
+
 def test_vae_decode_matches_oracle(device):
     vae_kw = dict(ch=128, ch_mult=(1, 2, 2, 4), num_res_blocks=2)
     vsd = synth.synth_state_dict(synth.vae_param_shapes(**vae_kw))
