@@ -107,8 +107,9 @@ typedef struct seer_gemm_desc {
      * the tile's rows, rows = seer_gemm_colsum_rows(desc), z = the phase of an upsample == 2 conv (else 0).  The GroupNorm that
      * consumes C (ResnetBlock3D.norm1/norm2, SpatialTransformer3D.norm: resnet.py / attention.py of the reference run
      * F.group_norm on it) takes its statistics from these sums instead of a pass over C: seer_groupnorm_stats_from_colsums.
-     * A launch that cannot produce them (GEGLU, fp32 / transposed output, split-K, the weight-stationary kernel) fails with
-     * SEER_EINVAL when colsum is set: ask seer_gemm_colsum_rows first. */
+     * A split-K launch leaves them through its reduce pass (rows = 4 or 16).  A launch that cannot produce them (GEGLU, fp32 /
+     * transposed output, the weight-stationary kernel) fails with SEER_EINVAL when colsum is set: ask seer_gemm_colsum_rows
+     * first. */
     float* colsum;
 } seer_gemm_desc;
 

@@ -435,6 +435,11 @@ extern "C" int seer_attn_fwd(const seer_attn_desc* desc, void* stream) {
             // the d = 40 kernel pays ~3 us of set-up (constant region, LDS-DMA plan, reference pre-pass) that short key
             // sequences do not earn back (text cross-attention, Sk = 77: 18.7 vs 16.6 us, profiles/r02_attn40_variants.log)
             if (d.variant == 1 || d.variant == 6 || (d.variant == 0 && d.Sk < 256)) return launch_attn<40>(d, ws_log2, st);
+            // training forward (lse requested) on an UN-prescaled q: the d = 40 kernel would round q * scale * log2(e) to bf16
+            // before Q K^T, and its lse would belong to those rounded scores, while seer_attn_bwd rebuilds P = exp2(q.k * scale *
+            // log2(e) - lse) from the unrounded q in fp32 -- probabilities that no longer sum to 1 (~1 % off).  The generic kernel
+            // scales the fp32 scores, exactly as the backward does
+            if (d.variant == 0 && d.lse && !(d.flags & SEER_ATTN_Q_PRESCALED)) return launch_attn<40>(d, ws_log2, st);
             return seer_attn40_launch(d, ws_log2, st);
         case 80: return launch_attn<80>(d, ws_log2, st);
         case 96: return launch_attn<96>(d, ws_log2, st);      // FSTextTransformer (768 channels, 8 heads)

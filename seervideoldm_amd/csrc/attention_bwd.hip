@@ -355,6 +355,7 @@ extern "C" int seer_attn_bwd(const seer_attn_bwd_desc* desc, void* stream) {
     if (!f.Q || !f.K || !f.V || !f.O || !f.lse || !d.dO || !d.dQ || !d.dK || !d.dV || !d.delta) return SEER_EINVAL;
     if (f.batch <= 0 || f.heads <= 0 || f.Sq <= 0 || f.Sk <= 0) return SEER_EINVAL;
     if (f.q_hs || f.k_hs || f.v_hs) return SEER_ENOSYS;        // the backward reads token-major operands only
+    if (f.flags & SEER_ATTN_Q_PRESCALED) return SEER_ENOSYS;   // ... and an un-prescaled q (it applies scale * log2(e) itself)
     if ((f.q_ss | f.k_ss | f.v_ss | f.o_ss | d.do_ss) % 8 || (d.dq_ss | d.dk_ss | d.dv_ss) % 4) return SEER_EINVAL;
     if ((f.q_bs | f.k_bs | f.v_bs | f.o_bs | d.do_bs) % 8 || (d.dq_bs | d.dk_bs | d.dv_bs) % 4) return SEER_EINVAL;
     int ws_log2 = -1;

@@ -531,7 +531,9 @@ def test_attention_q_prescaled(device, d, S):
 
 
 def test_attention_d40_lse(device):
-    """the log-sum-exp the training step asks for comes from the tracked form of the d = 40 kernel (rounded P)"""
+    """the log-sum-exp the training step asks for: on an un-prescaled q it comes from the kernel that scales the fp32 scores (the
+    arithmetic seer_attn_bwd rebuilds P with); with variant 5 from the tracked form of the d = 40 kernel.  Both are checked, and
+    exp2(q.k * scale * log2(e) - lse) -- the backward's P -- must sum to 1 over the keys with the default routing."""
     from seervideoldm_amd import ops
     B, S, Hh, d = 2, 512, 8, 40
     C = Hh * d
@@ -545,6 +547,12 @@ def test_attention_d40_lse(device):
     s = torch.einsum("bhqd,bhkd->bhqk", q.permute(0, 2, 1, 3).float(), k.permute(0, 2, 1, 3).float()) * d ** -0.5
     ref = torch.logsumexp(s, -1) / math.log(2.0)            # log2 domain
     assert (lse.reshape(B, Hh, S) - ref).abs().max().item() < 2e-2
+    psum = torch.exp2(s / math.log(2.0) - lse.reshape(B, Hh, S, 1)).sum(-1)
+    assert (psum - 1).abs().max().item() < 2e-3, "the backward's probabilities must sum to 1"
+    lse5 = torch.zeros_like(lse)
+    ops.attention(q.reshape(B * S, C), k.reshape(B * S, C), v.reshape(B * S, C), out, batch=B, heads=Hh, head_dim=d,
+                  Sq=S, Sk=S, lse=lse5, variant=5)
+    assert (lse5.reshape(B, Hh, S) - ref).abs().max().item() < 2e-2
 
 
 def test_gemm_col_scale(device):
