@@ -1,16 +1,21 @@
 """Checks over the gfx950 assembly hipcc produced for libseer_hip.so (build.py keeps the device `.s` of every source under
 lib/obj/ and runs these on each build; a violation fails the build).
 
-Rule `pk_swap` -- no packed-fp32 instruction whose destination pair is also a source operand read with its halves SWAPPED:
+Rule `pk_src1_hi` -- no packed (VOP3P `v_pk_*`) arithmetic instruction whose SECOND source is read with `op_sel[1] = 1`,
+i.e. whose LOW result reads the HIGH half of src1 -- half-swapped or hi-broadcast alike:
 
-    v_pk_fma_f32 v[36:37], v[76:77], v[36:37], v[84:85] op_sel:[0,1,0] op_sel_hi:[1,0,0]
+    v_pk_fma_f32 v[36:37], v[76:77], v[36:37], v[84:85] op_sel:[0,1,0] op_sel_hi:[1,0,0]      (rotary epilogue, round 2)
+    v_pk_add_f32 v[66:67], v[66:67], v[92:93] op_sel:[0,1] op_sel_hi:[1,0]                    (LayerNorm backward's row sums)
 
-On MI355X that instruction (generated by the SLP vectoriser from the four scalar lines of a rotary pair) returned its addend
-alone -- the product term lost -- in lanes 48..63, about once per 1000 launches of the rotary q|k|v GEMM, but only while a second
-process ran the same network on the same GPU; never alone, never with the whole-pair form `rot_pair` (seer_common.h) that
-replaced it.  That was the "last-bit replay difference" of round 2 (profiles/r03_flake_root_cause.md).  The rule keeps the form
-out of every kernel; broadcast reads (`op_sel_hi` 0 without `op_sel` 1) of an aliased operand are common (GELU, bias adds) and
-have never failed, they are not flagged.
+On MI355X, while a second process runs the denoising network on the same GPU, such an instruction computes its low result in
+LANES 48..63 as if that operand were ZERO (fma: the addend alone; add: the other term alone; mul: 0) -- in three launches out of
+four of `scripts/lab_pkswap.cpp`, which isolates one instruction per kernel (profiles/r03_flake_12_lab_pkswap.log): every form
+with op_sel[1] = 1 fails (fma / mul / add, aliased destination or not, op_sel_hi 0 or 1, with or without neg), every other form
+never does in 2e13 lane-iterations each (src0 or src2 half-swapped or hi-broadcast, lo-broadcasts, plain accumulates, v_pk_mov_b32,
+scalar v_fma_f32), and nothing fails without the co-tenant or next to a co-tenant that runs the lab itself.  hipcc emits the form
+freely: the SLP vectoriser builds it from scalar code that pairs the two halves of different values.  That was the "last-bit
+replay difference" of round 2 and the 1 % gradient mismatches of the co-tenant training check (profiles/r03_flake_root_cause.md).
+`v_pk_mov_b32` is exempt: its low result reads only src0.
 
 Rule `attn40_vregs` -- attention40.hip issues its V'^T LDS reads in one asm statement (`lds_issue_kv`, ends with
 `s_waitcnt lgkmcnt(8)`) and waits for them in a later one (`lds_wait_v`, `s_waitcnt lgkmcnt(0)`): the hardware writes those
@@ -23,7 +28,7 @@ import re
 from pathlib import Path
 from typing import Iterable, List, Set, Tuple
 
-_PK = re.compile(r"^\s*(v_pk_(?:fma|mul|add)_f32)\s+v\[(\d+):(\d+)\],\s*(.*)$")
+_PK = re.compile(r"^\s*(v_pk_\w+)\s+v\[(\d+):(\d+)\],\s*(.*)$")
 _LABEL = re.compile(r"^([A-Za-z_][\w$.]*):")
 
 
@@ -35,25 +40,19 @@ def _sel(mods: str, name: str, default: int, n: int) -> List[int]:
     return v + [default] * (n - len(v))
 
 
-def check_pk_swap(lines: Iterable[str], fname: str = "") -> List[str]:
+def check_pk_src1_hi(lines: Iterable[str], fname: str = "") -> List[str]:
     out, kern = [], "?"
     for ln, line in enumerate(lines, 1):
         lab = _LABEL.match(line)
         if lab and not lab.group(1).startswith(".L"):
             kern = lab.group(1)
         m = _PK.match(line)
-        if not m:
+        if not m or m.group(1).startswith("v_pk_mov"):
             continue
-        _, d0, _, rest = m.groups()
-        body = rest.split(";")[0]
-        mm = re.match(r"((?:[^ ]+,\s*)*[^ ,]+)\s*(.*)", body)
-        srcs = [s.strip() for s in mm.group(1).split(",")]
-        mods = mm.group(2)
-        osl, osh = _sel(mods, "op_sel", 0, len(srcs)), _sel(mods, "op_sel_hi", 1, len(srcs))
-        for i, s in enumerate(srcs):
-            r = re.match(r"v\[(\d+):(\d+)\]", s)
-            if r and r.group(1) == d0 and osl[i] == 1 and osh[i] == 0:
-                out.append(f"{fname}:{ln}: [{kern}] destination aliases half-swapped source {i}: {line.strip()}")
+        body = m.group(4).split(";")[0]
+        osl = _sel(body, "op_sel", 0, 3)
+        if osl[1] == 1:
+            out.append(f"{fname}:{ln}: [{kern}] the low result reads the high half of src1 (op_sel[1] = 1): {line.strip()}")
     return out
 
 
@@ -150,7 +149,7 @@ def check_directory(objdir: Path) -> List[str]:
     pairs = 0
     for f in files:
         lines = f.read_text().splitlines(keepends=True)
-        problems += check_pk_swap(lines, f.name)
+        problems += check_pk_src1_hi(lines, f.name)
         if f.name.startswith("attention40"):
             v, p = check_attn40_vregs(lines, f.name)
             problems += v

@@ -205,9 +205,11 @@ __global__ void __launch_bounds__(256) conv_out_kernel(const bf16* __restrict__ 
         const int ox = (int)(pix % Wd);
         const int oy = (int)((pix / Wd) % H);
         const int64_t img = pix / ((int64_t)Wd * H);       // b*F + f
-        float acc[COUT];
+        // (even, odd) element pairs accumulated as whole packed operations: with scalar accumulators the SLP vectoriser builds
+        // packed multiplies that read the high half of their second source (op_sel[1] = 1), the form asm_check.py refuses
+        f32x2 acc[COUT];
 #pragma unroll
-        for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
+        for (int o = 0; o < COUT; ++o) acc[o] = f32x2{0.f, 0.f};
         for (int item = lane; item < 9 * nch; item += 64) {
             const int tap = item / nch, ch = item - tap * nch;
             const int ky = tap / 3, kx = tap - 3 * ky;
@@ -221,15 +223,17 @@ __global__ void __launch_bounds__(256) conv_out_kernel(const bf16* __restrict__ 
                 const float* w = wsm + (o * 9 + tap) * C0 + ch * 8;
                 const f32x4 w0 = *reinterpret_cast<const f32x4*>(w);
                 const f32x4 w1 = *reinterpret_cast<const f32x4*>(w + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[o] += f[e] * w0[e] + f[4 + e] * w1[e];
+                acc[o] = __builtin_elementwise_fma(f32x2{f[0], f[1]}, f32x2{w0[0], w0[1]}, acc[o]);
+                acc[o] = __builtin_elementwise_fma(f32x2{f[2], f[3]}, f32x2{w0[2], w0[3]}, acc[o]);
+                acc[o] = __builtin_elementwise_fma(f32x2{f[4], f[5]}, f32x2{w1[0], w1[1]}, acc[o]);
+                acc[o] = __builtin_elementwise_fma(f32x2{f[6], f[7]}, f32x2{w1[2], w1[3]}, acc[o]);
             }
         }
         const int f_ = (int)(img % F);
         const int b = (int)(img / F);
 #pragma unroll
         for (int o = 0; o < COUT; ++o) {
-            const float v = wave_sum(acc[o]);
+            const float v = wave_sum(acc[o][0] + acc[o][1]);
             if (lane == 0) y[((((int64_t)b * COUT + o) * F + f_) * H + oy) * Wd + ox] = v + (bias ? bias[o] : 0.f);
         }
     }

@@ -68,17 +68,21 @@ __device__ __forceinline__ void store16_out(void* base, unsigned voff, const u32
 #endif
 }
 
-// One interleaved rotary pair (x0, x1) -> (x0 c - x1 s, x1 c + x0 s) as two WHOLE packed operations, fma(x, (c, c), swap(x) * (-s, s)),
-// with the roundings of the scalar form fma(x0, c, -(x1 s)), fma(x1, c, x0 s).  The scalar form is not just slower: hipcc's SLP
-// vectoriser turns four such lines into v_pk_fma_f32 instructions that use one half of a register pair, among them
-//     v_pk_fma_f32 v[36:37], v[76:77], v[36:37], v[84:85] op_sel:[0,1,0] op_sel_hi:[1,0,0]      (destination = the half-swapped source)
-// and on MI355X that instruction returned the ADDEND ALONE (product term lost) in lanes 48..63 about once per 1000 launches of the
-// rotary q|k|v projection whenever a second process ran the same network on the GPU, and never otherwise: 2 700 wrong launches in
-// 3.5 M against 0 in 3.5 M with this form (profiles/r03_flake_root_cause.md; scripts/check_asm.py fails the build if the in-place
-// half-swapped form appears in any kernel again).
+// One interleaved rotary pair (x0, x1) -> (x0 c - x1 s, x1 c + x0 s) with the roundings of fma(x0, c, -(x1 s)), fma(x1, c, x0 s):
+// the crossed products t = (-x1 s, x0 s) as TWO SCALAR multiplies, then ONE packed fma x * (c, c) + t.  Do not write the rotation
+// as scalar fp32 lines, and do not leave the crossing to a packed instruction: hipcc (SLP vectoriser, shuffle folding) then emits
+// packed instructions that read the halves of a register pair crossed, and a crossed read is only safe on SOME operand positions.
+// Measured on MI355X (scripts/lab_pkswap.cpp, profiles/r03_flake_root_cause.md): a v_pk_{fma,mul,add}_f32 whose LOW result reads
+// the HIGH half of its SECOND source (op_sel[1] = 1) computes that result in lanes 48..63 as if the operand were zero whenever a
+// second process runs the denoising network on the GPU, and never otherwise.  Round 2's rotary epilogue contained
+//     v_pk_fma_f32 v[36:37], v[76:77], v[36:37], v[84:85] op_sel:[0,1,0] op_sel_hi:[1,0,0]
+// which returned the addend alone: 2 700 wrong launches of the q|k|v projection in 3.5 M, 0 in 3.5 M without the form.
+// seervideoldm_amd/asm_check.py fails the build if any kernel of the library contains it.
 __device__ __forceinline__ f32x2 rot_pair(f32x2 x, float c, float s) {
-    const f32x2 t = f32x2{x[1], x[0]} * f32x2{-s, s};
-    return __builtin_elementwise_fma(x, f32x2{c, c}, t);
+    float t0, t1;                                       // the crossed products as two scalar multiplies: no packed half-swap
+    asm("v_mul_f32_e64 %0, -%1, %2" : "=v"(t0) : "v"(s), "v"(x[1]));
+    asm("v_mul_f32_e32 %0, %1, %2" : "=v"(t1) : "v"(s), "v"(x[0]));
+    return __builtin_elementwise_fma(x, f32x2{c, c}, f32x2{t0, t1});
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }

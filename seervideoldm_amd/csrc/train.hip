@@ -382,24 +382,27 @@ __global__ void __launch_bounds__(256) ln_bwd_rows_kernel(const bf16* __restrict
             }
         }
         const float rstd = rsqrtf(wave_sum(q) * invC + eps);
-        float c1 = 0.f, c2 = 0.f;
+        // the two row sums as whole packed pairs over (even, odd) elements: written with scalar accumulators, the SLP vectoriser
+        // pairs c1 with c2 and reads the products half-swapped (v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]), a form that
+        // dropped a term next to a co-tenant process on MI355X (profiles/r03_flake_root_cause.md; asm_check.py refuses it)
+        f32x2 c1v = {0.f, 0.f}, c2v = {0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
             const int ch = lane + 64 * i;
             if (ch < nch) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float xh = (f[i][e] - mean) * rstd;
-                    const float gg = d[i][e] * gm[i][e];
-                    f[i][e] = xh;
-                    d[i][e] = gg;
-                    c1 += gg;
-                    c2 += gg * xh;
+                for (int e = 0; e < 8; e += 2) {
+                    const f32x2 xh = (f32x2{f[i][e], f[i][e + 1]} - f32x2{mean, mean}) * f32x2{rstd, rstd};
+                    const f32x2 gg = f32x2{d[i][e], d[i][e + 1]} * f32x2{gm[i][e], gm[i][e + 1]};
+                    f[i][e] = xh[0]; f[i][e + 1] = xh[1];
+                    d[i][e] = gg[0]; d[i][e + 1] = gg[1];
+                    c1v += gg;
+                    c2v = __builtin_elementwise_fma(gg, xh, c2v);
                 }
             }
         }
-        c1 = wave_sum(c1) * invC;
-        c2 = wave_sum(c2) * invC;
+        const float c1 = wave_sum(c1v[0] + c1v[1]) * invC;
+        const float c2 = wave_sum(c2v[0] + c2v[1]) * invC;
         if (rowstats && lane == 0) { rowstats[r * 2] = mean; rowstats[r * 2 + 1] = rstd; }
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {

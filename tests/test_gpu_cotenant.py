@@ -1,13 +1,15 @@
-"""Regression test of the round-2 "last-bit replay difference" (profiles/r03_flake_root_cause.md).
+"""Regression tests of the round-2 "last-bit replay difference" and of the 1 % gradient mismatches of the training step next to
+a co-tenant (profiles/r03_flake_root_cause.md).
 
-Root cause: the rotary epilogue of the q|k|v projection was four scalar lines per register quad; hipcc's SLP vectoriser
-compiled them to packed-fp32 instructions that use one half of a register pair, among them
-`v_pk_fma_f32 v[36:37], v[76:77], v[36:37], v[84:85] op_sel:[0,1,0] op_sel_hi:[1,0,0]` (destination = half-swapped source).
-On MI355X that instruction returned the addend alone in lanes 48..63 about once per 1000 launches -- but only while a SECOND
-PROCESS ran the same network on the GPU (which is what the two-rank test of round 2 did).  This test recreates the setting: a
-co-tenant process replays the mini network while this process launches the rotary projection a few hundred thousand times and
-runs the network eagerly and from its hipGraph; every result must be bit-identical.  On the round-2 library the projection loop
-fails ~400 times in 8 s."""
+Root cause: a packed-fp32 instruction whose low result reads the HIGH half of its second source (`op_sel[1] = 1`, e.g.
+`v_pk_fma_f32 v[36:37], v[76:77], v[36:37], v[84:85] op_sel:[0,1,0] op_sel_hi:[1,0,0]` in the rotary epilogue of round 2,
+`v_pk_add_f32 v[66:67], v[66:67], v[92:93] op_sel:[0,1] op_sel_hi:[1,0]` in LayerNorm backward's row sums) computes that result in
+lanes 48..63 as if the operand were zero -- on MI355X, sometimes, and only while a SECOND PROCESS runs the denoising network
+on the GPU (which is what the two-rank test of round 2 did).  hipcc's SLP vectoriser emits the form from scalar code; the build
+now refuses it (seervideoldm_amd/asm_check.py).  These tests recreate the setting: a co-tenant process replays the mini network
+while this process (1) launches the rotary projection a few hundred thousand times and runs the network eagerly and from its
+hipGraph, (2) repeats one fine-tuning step; every result must be bit-identical.  On the round-2 library the projection loop
+fails ~400 times in 8 s; on the library before the LayerNorm fix 1 training step in 100 differs."""
 import subprocess
 import sys
 import time
@@ -74,4 +76,38 @@ def test_results_do_not_depend_on_a_cotenant_process(device, cotenant):
             diff[mode] += int(not torch.equal(m(x, t, ctx), want))
     m.use_graph = False
     print(f"[cotenant] mini network next to a co-tenant, 300 eager + 300 replayed steps: {diff}")
+    assert diff == {"eager": 0, "replay": 0}
+
+
+def test_training_step_does_not_depend_on_a_cotenant_process(device, cotenant):
+    """forward + backward of a reduced (real channel widths) fine-tuning step, 400 repeats eager + 400 from the hipGraphs: loss
+    and both flat gradient buffers bit-identical every time (scripts/exp_flake_train.py is the long form with the op trace)"""
+    from seervideoldm_amd import FSTextTransformer, SeerUNet, synth
+    from seervideoldm_amd.trainer import SeerTrainer
+    cfg = dict(block_out_channels=(320, 640, 1280, 1280), layers_per_block=1, cross_attention_dim=192, attention_head_dim=8)
+    fs = dict(num_frames=16, num_layers=1, channels=192, n_heads=2, cross_attention_dim=192)
+    unet = SeerUNet(**cfg)
+    unet.load_state_dict(synth.synth_state_dict(synth.unet_param_shapes(cfg), device=device), strict=True)
+    fst = FSTextTransformer(num_frames=16, in_channels=192, out_channels=192, n_heads=2, num_layers=1, cross_attention_dim=192)
+    fst.load_state_dict(synth.synth_state_dict(synth.fstext_param_shapes(**fs), device=device), strict=True)
+    fst.set_numframe(4)
+    tr = SeerTrainer(unet.to(device), fst.to(device), lr=1e-5, max_grad_norm=0.3)
+    g = torch.Generator().manual_seed(1)
+    x, noise = torch.randn((1, 4, 4, 32, 32), generator=g).to(device), torch.randn((1, 4, 3, 32, 32), generator=g).to(device)
+    text, t = torch.randn((1, 77, 192), generator=g).to(device), torch.tensor([417], device=device)
+    diff = {}
+    for use_graph in (False, True):
+        ref, bad = None, 0
+        for _ in range(400):
+            tr.pu.g.zero_(); tr.pf.g.zero_()
+            loss = tr.forward_backward(x, noise, t, text, 1, use_graph=use_graph)
+            torch.cuda.synchronize()
+            if ref is None:
+                ref = (float(loss), tr.pu.g.clone(), tr.pf.g.clone())
+                assert torch.isfinite(ref[1]).all() and float(ref[1].abs().max()) > 0
+            else:
+                bad += int(float(loss) != ref[0] or not torch.equal(tr.pu.g, ref[1]) or not torch.equal(tr.pf.g, ref[2]))
+        diff["replay" if use_graph else "eager"] = bad
+    assert cotenant.poll() is None, "the co-tenant process must still be running"
+    print(f"[cotenant] fine-tuning step next to a co-tenant, 399 + 399 repeats: {diff}")
     assert diff == {"eager": 0, "replay": 0}
