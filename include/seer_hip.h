@@ -346,6 +346,24 @@ int seer_gemm_tn_f32(const void* A, int32_t lda, const void* B, int32_t ldb, int
 /* y[c*ldy + r] = x[r*ldx + c]; columns rows..ldy-1 of y are zero filled */
 int seer_transpose_bf16(const void* x, int64_t rows, int32_t cols, int32_t ldx, void* y, int64_t ldy, void* stream);
 
+/* The same for many matrices in one launch (the W^T refresh of all trainable matrices after an optimizer step).  `items` is a
+ * DEVICE array, read by the kernel: matrix i is x [rows, cols] with row pitch ldx -> y [cols, ldy], 64x64 tiles numbered
+ * tile0 + (tile row) + tiles_r * (tile column), tiles_r = ldy / 64, tile0 = the running sum of tiles_r * ceil(cols / 64)
+ * (ascending, items[0].tile0 = 0); total_tiles = that sum over all items.  Every item: cols % 8 == 0, ldx % 8 == 0,
+ * ldy % 64 == 0, ldy >= rows, x and y 16-byte aligned (the caller checks: the table is not readable from the host side). */
+typedef struct seer_transpose_item {
+    const void* x;
+    void* y;
+    int64_t rows;
+    int64_t ldy;
+    int64_t tile0;
+    int32_t cols;
+    int32_t ldx;
+    int32_t tiles_r;
+    int32_t reserved;
+} seer_transpose_item;
+int seer_transpose_batched_bf16(const seer_transpose_item* items, int32_t n_items, int64_t total_tiles, void* stream);
+
 /* out[c] = sum_r x[r][c] (bias gradients).  workspace: seer_colsum_workspace_floats(rows, cols) floats (the same size
  * serves seer_layernorm_bwd). */
 int64_t seer_colsum_workspace_floats(int64_t rows, int32_t cols);

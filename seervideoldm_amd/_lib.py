@@ -114,6 +114,7 @@ SIGNATURES = {
     "seer_gemm_tn_workspace_bytes": ([_i32, _i32, _i32], C.c_int64),
     "seer_gemm_tn_f32": ([_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp], C.c_int),
     "seer_transpose_bf16": ([_vp, _i64, _i32, _i32, _vp, _i64, _vp], C.c_int),
+    "seer_transpose_batched_bf16": ([_vp, _i32, _i64, _vp], C.c_int),
     "seer_colsum_workspace_floats": ([_i64, _i32], C.c_int64),
     "seer_colsum_bf16": ([_vp, _i64, _i32, _i32, _vp, _vp, _vp], C.c_int),
     "seer_layernorm_bwd": ([_vp, _vp, _i64, _i32, _i32, _i32, _vp, _f32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp], C.c_int),

@@ -72,6 +72,48 @@ __global__ void __launch_bounds__(256) transpose_vec_kernel(const bf16* __restri
     }
 }
 
+// many matrices in ONE launch (the W^T refresh of every trainable matrix after an optimizer step: ~190 launches of 5 us each
+// otherwise): block b finds its matrix by binary search over the items' first-tile indices, then works as transpose_vec_kernel
+__global__ void __launch_bounds__(256) transpose_batched_kernel(const seer_transpose_item* __restrict__ items, int n_items) {
+    __shared__ unsigned int tile[64][33];
+    int lo = 0, hi = n_items - 1;                    // last item whose tile0 <= blockIdx.x (tile0 ascending, items[0].tile0 == 0)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].tile0 <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const seer_transpose_item it = items[lo];
+    const int64_t local = (int64_t)blockIdx.x - it.tile0;
+    const int64_t r0 = (local % it.tiles_r) * 64;
+    const int c0 = (int)(local / it.tiles_r) * 64;
+    const bf16* __restrict__ x = reinterpret_cast<const bf16*>(it.x);
+    bf16* __restrict__ y = reinterpret_cast<bf16*>(it.y);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        const int r = idx >> 3, ch = idx & 7;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (r0 + r < it.rows && c0 + 8 * ch < it.cols) v = *reinterpret_cast<const u32x4*>(x + (r0 + r) * it.ldx + c0 + 8 * ch);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) tile[r][4 * ch + w] = v[w];
+    }
+    __syncthreads();
+    const unsigned short* t16 = reinterpret_cast<const unsigned short*>(&tile[0][0]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        const int rc = idx & 7, c = idx >> 3;
+        if (c0 + c < it.cols) {
+            unsigned short e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = t16[(8 * rc + j) * 66 + c];
+            u32x4 o;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) o[w] = (unsigned int)e[2 * w] | ((unsigned int)e[2 * w + 1] << 16);
+            *reinterpret_cast<u32x4*>(y + (int64_t)(c0 + c) * it.ldy + r0 + 8 * rc) = o;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // column partial sums: the block's 256 threads are cpp column owners (8 adjacent columns each) x rows_par row lanes over a
 // chunk of g.chunk_rows rows; row lanes are added through LDS in lane order; NV values per element.
@@ -242,50 +284,70 @@ __global__ void __launch_bounds__(1024) colfinal_kernel(const float* __restrict_
     }
 }
 
-// GroupNorm: per (b, c) sums A = sum gy, Bv = sum gy xhat (sums[b][{A,Bv}][C]) -> per (b, g) projections
-// s1 = sum_c gamma_c A_bc, s2 = sum_c gamma_c B_bc (scaled by 1/count), and dgamma_c = sum_b B_bc, dbeta_c = sum_b A_bc.
-// One block per group; a thread owns channels t and t + 64 of the group (cpg <= 128).
-__global__ void __launch_bounds__(64) gn_bwd_group_kernel(const float* __restrict__ sumsA, const float* __restrict__ sumsB, int batch,
-                                                          int C, int cpg, int groups, const float* __restrict__ gamma,
-                                                          float inv_count, float* __restrict__ proj /* [batch][groups][2] */,
-                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
+// GroupNorm backward, middle stage: the chunk partials of colpartial_kernel<2> (per (b, c): A = sum gy, Bv = sum gy xhat) -> per
+// (b, g) projections s1 = sum_c gamma_c A_bc, s2 = sum_c gamma_c B_bc (scaled by 1/count), and dgamma_c = sum_b B_bc,
+// dbeta_c = sum_b A_bc.  One block per group: 16 chunk lanes x 64 channel lanes add the partials (then in lane order: a fixed
+// order), wave 0 forms the projections; cpg <= 128.  (This was a colfinal_kernel launch + a per-group kernel.)
+__global__ void __launch_bounds__(1024) gn_bwd_group_fused_kernel(const float* __restrict__ ws, int nchunks, int batch, int C,
+                                                                  int cpg, int groups, const float* __restrict__ gamma,
+                                                                  float inv_count, float* __restrict__ proj,
+                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float red[4][16][64];                 // [v + 2 k2][chunk lane][channel lane]
     const int grp = blockIdx.x;
-    const int t = threadIdx.x;
+    const int cl = threadIdx.x & 63, kl = threadIdx.x >> 6;
     float dg[2] = {0.f, 0.f}, db[2] = {0.f, 0.f};
-    for (int b = 0; b < batch; ++b) {
-        float pa = 0.f, pb = 0.f;
+    // grid.y = batch when no d gamma / d beta is asked for (nothing crosses batch items then), 1 otherwise
+    for (int b = blockIdx.y; b < batch; b += gridDim.y) {
+        float s[4] = {0.f, 0.f, 0.f, 0.f};           // the four sums of this lane at once: independent loads in flight
+        const float* w = ws + ((int64_t)b * nchunks) * 2 * C + grp * cpg + cl;
+        const bool has0 = cl < cpg, has1 = cl + 64 < cpg;
+        for (int k = kl; k < nchunks; k += 16) {
+            const float* wk = w + (int64_t)k * 2 * C;
+            if (has0) { s[0] += wk[0]; s[1] += wk[C]; }
+            if (has1) { s[2] += wk[64]; s[3] += wk[C + 64]; }
+        }
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
-            const int cl = t + 64 * k2;
-            if (cl < cpg) {
-                const int c = grp * cpg + cl;
-                const float A = sumsA[(int64_t)b * C + c], Bv = sumsB[(int64_t)b * C + c];
-                pa += gamma[c] * A;
-                pb += gamma[c] * Bv;
-                dg[k2] += Bv;
-                db[k2] += A;
+        for (int j = 0; j < 4; ++j) red[j][kl][cl] = s[j];
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            float pa = 0.f, pb = 0.f;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const int c_local = cl + 64 * k2;
+                if (c_local < cpg) {
+                    float A = 0.f, Bv = 0.f;
+#pragma unroll
+                    for (int l = 0; l < 16; ++l) {
+                        A += red[2 * k2][l][cl];
+                        Bv += red[2 * k2 + 1][l][cl];
+                    }
+                    const float gm = gamma[grp * cpg + c_local];
+                    pa += gm * A;
+                    pb += gm * Bv;
+                    dg[k2] += Bv;
+                    db[k2] += A;
+                }
+            }
+            pa = wave_sum(pa);
+            pb = wave_sum(pb);
+            if (threadIdx.x == 0) {
+                proj[((int64_t)b * groups + grp) * 2] = pa * inv_count;
+                proj[((int64_t)b * groups + grp) * 2 + 1] = pb * inv_count;
             }
         }
-        pa = wave_sum(pa);
-        pb = wave_sum(pb);
-        if (t == 0) {
-            proj[((int64_t)b * groups + grp) * 2] = pa * inv_count;
-            proj[((int64_t)b * groups + grp) * 2 + 1] = pb * inv_count;
-        }
+        __syncthreads();
     }
-    if (dgamma) {
+    if (dgamma && threadIdx.x < 64) {
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
-            const int cl = t + 64 * k2;
-            if (cl < cpg) {
-                dgamma[grp * cpg + cl] = dg[k2];
-                dbeta[grp * cpg + cl] = db[k2];
+            const int c_local = cl + 64 * k2;
+            if (c_local < cpg) {
+                dgamma[grp * cpg + c_local] = dg[k2];
+                dbeta[grp * cpg + c_local] = db[k2];
             }
         }
     }
 }
-
-// dx = rstd * (gy*gamma - s1 - xhat*s2) (+ dres), bf16, split back into the two concat sources
 __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const ColArgs a, const ColGeom g, const float* __restrict__ proj,
                                                            const bf16* __restrict__ dres1, const bf16* __restrict__ dres2,
                                                            bf16* __restrict__ dx1, bf16* __restrict__ dx2) {
@@ -339,11 +401,15 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const ColArgs a, cons
 
 // ---------------------------------------------------------------------------------------------------------------------
 // LayerNorm backward rows: one wave per row (C <= 1536)
-template <int MAXC>
+// PART: the launch also leaves d beta / d gamma partial sums, one [2][C] slab per block in `partials` (each lane adds dy and
+// dy * xhat of its columns over the rows of its wave, the four waves of the block are added through LDS in wave order;
+// colfinal_kernel adds the slabs): no second pass over x and dy, no row statistics in memory
+template <int MAXC, bool PART>
 __global__ void __launch_bounds__(256) ln_bwd_rows_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, int64_t rows,
                                                           int C, int ldx, int lddy, const float* __restrict__ gamma, float eps,
                                                           const bf16* __restrict__ dres, int ldres, bf16* __restrict__ dx,
-                                                          int lddx, float* __restrict__ rowstats) {
+                                                          int lddx, float* __restrict__ partials) {
+    extern __shared__ float part_lds[];              // PART: [4 waves][2][C]
     const int lane = threadIdx.x & 63;
     const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * 4;
@@ -358,6 +424,13 @@ __global__ void __launch_bounds__(256) ln_bwd_rows_kernel(const bf16* __restrict
         }
     }
     const float invC = 1.0f / (float)C;
+    [[maybe_unused]] f32x2 pb[MAXC][4], pg[MAXC][4];     // PART: d beta, d gamma of this lane's columns (pairs)
+    if constexpr (PART) {
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pb[i][e] = pg[i][e] = f32x2{0.f, 0.f};
+    }
     for (int64_t r = wave_global; r < rows; r += nwaves) {
         float f[MAXC][8], d[MAXC][8];
         float s = 0.f;
@@ -393,7 +466,12 @@ __global__ void __launch_bounds__(256) ln_bwd_rows_kernel(const bf16* __restrict
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
                     const f32x2 xh = (f32x2{f[i][e], f[i][e + 1]} - f32x2{mean, mean}) * f32x2{rstd, rstd};
-                    const f32x2 gg = f32x2{d[i][e], d[i][e + 1]} * f32x2{gm[i][e], gm[i][e + 1]};
+                    const f32x2 dyv = f32x2{d[i][e], d[i][e + 1]};
+                    if constexpr (PART) {
+                        pb[i][e >> 1] += dyv;
+                        pg[i][e >> 1] = __builtin_elementwise_fma(dyv, xh, pg[i][e >> 1]);
+                    }
+                    const f32x2 gg = dyv * f32x2{gm[i][e], gm[i][e + 1]};
                     f[i][e] = xh[0]; f[i][e + 1] = xh[1];
                     d[i][e] = gg[0]; d[i][e + 1] = gg[1];
                     c1v += gg;
@@ -403,7 +481,6 @@ __global__ void __launch_bounds__(256) ln_bwd_rows_kernel(const bf16* __restrict
         }
         const float c1 = wave_sum(c1v[0] + c1v[1]) * invC;
         const float c2 = wave_sum(c2v[0] + c2v[1]) * invC;
-        if (rowstats && lane == 0) { rowstats[r * 2] = mean; rowstats[r * 2 + 1] = rstd; }
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
             const int ch = lane + 64 * i;
@@ -420,6 +497,25 @@ __global__ void __launch_bounds__(256) ln_bwd_rows_kernel(const bf16* __restrict
                 *reinterpret_cast<u32x4*>(dx + r * lddx + ch * 8) = pack8(o);
             }
         }
+    }
+    if constexpr (PART) {
+        const int wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+                float* o = part_lds + (size_t)wave * 2 * C + ch * 8;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[2 * e] = pb[i][e][0]; o[2 * e + 1] = pb[i][e][1];
+                    o[C + 2 * e] = pg[i][e][0]; o[C + 2 * e + 1] = pg[i][e][1];
+                }
+            }
+        }
+        __syncthreads();
+        float* out = partials + (int64_t)blockIdx.x * 2 * C;
+        for (int j = threadIdx.x; j < 2 * C; j += 256)
+            out[j] = ((part_lds[j] + part_lds[2 * C + j]) + part_lds[4 * C + j]) + part_lds[6 * C + j];
     }
 }
 
@@ -717,6 +813,14 @@ extern "C" int seer_transpose_bf16(const void* x, int64_t rows, int32_t cols, in
     return SEER_OK;
 }
 
+extern "C" int seer_transpose_batched_bf16(const seer_transpose_item* items, int32_t n_items, int64_t total_tiles, void* stream) {
+    if (!items || n_items <= 0 || total_tiles <= 0 || total_tiles > 0x7fffffffLL) return SEER_EINVAL;
+    hipLaunchKernelGGL(transpose_batched_kernel, dim3((unsigned)total_tiles), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       items, n_items);
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
 extern "C" int64_t seer_colsum_workspace_floats(int64_t rows, int32_t cols) {
     if (rows <= 0 || cols <= 0) return SEER_EINVAL;
     return ((rows + CS_ROWS_MIN - 1) / CS_ROWS_MIN) * 2 * (int64_t)cols + 2 * rows;
@@ -752,28 +856,28 @@ extern "C" int seer_layernorm_bwd(const void* x, const void* dy, int64_t rows, i
     const bf16* dyb = reinterpret_cast<const bf16*>(dy);
     const bf16* rb = reinterpret_cast<const bf16*>(dres);
     bf16* dxb = reinterpret_cast<bf16*>(dx);
-    int64_t blocks = (rows + 3) / 4;
-    if (blocks > 4096) blocks = 4096;
-    const ColGeom g = col_geom(C, rows);
-    float* rowstats = dgamma ? workspace + ((rows + CS_ROWS_MIN - 1) / CS_ROWS_MIN) * 2 * (int64_t)C : nullptr;
-#define SEER_LNB(MC) hipLaunchKernelGGL(ln_bwd_rows_kernel<MC>, dim3((unsigned)blocks), dim3(256), 0, st, xb, dyb, rows, C, ldx, \
-                                        lddy, gamma, eps, rb, ldres, dxb, lddx, rowstats)
+    // plain: one row per wave; with d gamma / d beta: two rows per wave, so that the per-block partial slabs stay few
+    // (<= ceil(rows / 8) slabs of [2][C] floats = the first region of seer_colsum_workspace_floats(rows, C))
+    int64_t blocks = dgamma ? (rows + 7) / 8 : (rows + 3) / 4;
+    const int64_t cap = dgamma ? 1024 : 4096;
+    if (blocks > cap) blocks = cap;
+    const size_t lds = dgamma ? (size_t)8 * C * sizeof(float) : 0;
+#define SEER_LNB(MC)                                                                                                              \
+    do {                                                                                                                          \
+        if (dgamma)                                                                                                               \
+            hipLaunchKernelGGL((ln_bwd_rows_kernel<MC, true>), dim3((unsigned)blocks), dim3(256), lds, st, xb, dyb, rows, C, ldx,  \
+                               lddy, gamma, eps, rb, ldres, dxb, lddx, workspace);                                               \
+        else                                                                                                                      \
+            hipLaunchKernelGGL((ln_bwd_rows_kernel<MC, false>), dim3((unsigned)blocks), dim3(256), 0, st, xb, dyb, rows, C, ldx,   \
+                               lddy, gamma, eps, rb, ldres, dxb, lddx, (float*)nullptr);                                         \
+    } while (0)
     if (C <= 512) SEER_LNB(1);
     else if (C <= 1024) SEER_LNB(2);
     else SEER_LNB(3);
 #undef SEER_LNB
     SEER_LAUNCH_CHECK();
     if (dgamma) {
-        ColArgs a{};
-        a.x1 = xb;
-        a.dy = dyb;
-        a.ldx = ldx;
-        a.lddy = lddy;
-        a.rowstats = rowstats;
-        const size_t lds = (size_t)g.rows_par * g.cpp * 16 * sizeof(float);
-        hipLaunchKernelGGL(colpartial_kernel<1>, dim3(g.nchunks, col_blocks(g), 1), dim3(256), lds, st, a, g, workspace);
-        SEER_LAUNCH_CHECK();
-        hipLaunchKernelGGL(colfinal_kernel, dim3((C + 63) / 64, 2, 1), dim3(1024), 0, st, workspace, g.nchunks, 2, C, dbeta, dgamma);
+        hipLaunchKernelGGL(colfinal_kernel, dim3((C + 63) / 64, 2, 1), dim3(1024), 0, st, workspace, (int)blocks, 2, C, dbeta, dgamma);
         SEER_LAUNCH_CHECK();
     }
     return SEER_OK;
@@ -820,10 +924,7 @@ extern "C" int seer_groupnorm_bwd(const void* x1, int32_t C1, const void* x2, in
     const size_t lds = (size_t)g.rows_par * g.cpp * 16 * sizeof(float);
     hipLaunchKernelGGL(colpartial_kernel<2>, grid, dim3(256), lds, st, a, g, workspace);
     SEER_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colfinal_kernel, dim3((C + 63) / 64, 2, batch), dim3(1024), 0, st, workspace, g.nchunks, 2, C, sums,
-                       sums + (int64_t)batch * C);
-    SEER_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(groups), dim3(64), 0, st, sums, sums + (int64_t)batch * C, batch, C, a.cpg, groups,
+    hipLaunchKernelGGL(gn_bwd_group_fused_kernel, dim3(groups, dgamma ? 1 : batch), dim3(1024), 0, st, workspace, g.nchunks, batch, C, a.cpg, groups,
                        gamma, a.inv_count, proj, dgamma, dbeta);
     SEER_LAUNCH_CHECK();
     hipLaunchKernelGGL(gn_bwd_apply_kernel, grid, dim3(256), 0, st, a, g, proj, reinterpret_cast<const bf16*>(dres1),

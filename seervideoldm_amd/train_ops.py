@@ -7,7 +7,7 @@ path.  The matrix products of the backward pass are plain ops.gemm / ops.conv3x3
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Tuple
+from typing import Sequence, Optional, Tuple
 
 import torch
 
@@ -78,6 +78,42 @@ def transpose(x: torch.Tensor, pad_to: int = 64) -> torch.Tensor:
     y = torch.empty((cols, ldy), device=x.device, dtype=bf16)
     check(_lib.load().seer_transpose_bf16(_p(x), rows, cols, x.stride(0), _p(y), ldy, _stream()), "seer_transpose_bf16")
     return y
+
+
+class TransposePlan:
+    """`run()` transposes every x_i [rows, cols] (bf16, row-strided views) into y_i [cols, round_up(rows, 64)] in ONE launch
+    (seer_transpose_batched_bf16).  The outputs are views of one arena and live as long as the plan; the item table is built
+    once, on the device, from the tensors' addresses -- the inputs must stay where they are (the trainer's flat bf16 weights do)."""
+
+    def __init__(self, xs: "Sequence[torch.Tensor]"):
+        assert len(xs) > 0
+        dev = xs[0].device
+        sizes, total = [], 0
+        for x in xs:
+            _req(x, bf16, "x")
+            assert x.dim() == 2 and x.stride(1) == 1 and x.device == dev
+            rows, cols = x.shape
+            ldy = (rows + 63) // 64 * 64
+            assert cols % 8 == 0 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0, "seer_transpose_batched_bf16: 16-byte rows"
+            sizes.append((rows, cols, ldy, total))
+            total += cols * ldy
+        self.arena = torch.zeros((total,), device=dev, dtype=bf16)
+        self.inputs = list(xs)                                     # keeps the sources alive: the table holds their addresses
+        self.outputs, table, tile0 = [], [], 0
+        for x, (rows, cols, ldy, off) in zip(xs, sizes):
+            y = self.arena[off:off + cols * ldy].view(cols, ldy)
+            assert y.data_ptr() % 16 == 0
+            self.outputs.append(y)
+            tiles_r = ldy // 64
+            # seer_transpose_item: x, y, rows, ldy, tile0 (int64 x 5), cols, ldx, tiles_r, reserved (int32 x 4) = 56 bytes
+            table.append((x.data_ptr(), y.data_ptr(), rows, ldy, tile0, cols | (x.stride(0) << 32), tiles_r))
+            tile0 += tiles_r * ((cols + 63) // 64)
+        self.total_tiles, self.n = tile0, len(table)
+        self.table = torch.tensor(table, dtype=torch.int64).to(dev)   # [n, 7] int64 = the C struct (little endian)
+
+    def run(self) -> None:
+        check(_lib.load().seer_transpose_batched_bf16(_p(self.table), self.n, self.total_tiles, _stream()),
+              "seer_transpose_batched_bf16")
 
 
 def _col_ws(rows: int, cols: int, device) -> torch.Tensor:

@@ -153,6 +153,14 @@ class SeerTrainer:
             fk = f"trf_blocks.{n}.transformer_blocks.1.attn1.rotary_emb.freqs"
             self.wf[f"trf_blocks.{n}.transformer_blocks.1.attn1.freqs"] = sd_f[fk].detach().to(self.device, f32).contiguous()
         self.conv_out_w = sd_u["conv_out.weight"].detach().to(self.device, f32).permute(0, 2, 3, 1).contiguous()
+        # W^T of every trainable matrix (the dX products read the weight [K][N]): one arena, refreshed by ONE launch at the top of
+        # each step (the weights move with every AdamW step) instead of one transpose launch per layer inside the backward pass
+        mats = [(P, W, k) for P, W in ((self.pu, self.w), (self.pf, self.wf)) for k in P.names if len(P.shapes[k]) == 2]
+        self._wt_plan = tops.TransposePlan([W[k] for _, W, k in mats])
+        for P in (self.pu, self.pf):
+            P.wT = {}
+        for (P, _, k), y in zip(mats, self._wt_plan.outputs):
+            P.wT[k] = y
         self._wT: Dict[str, torch.Tensor] = {}          # transposed copies of frozen matrices (dX GEMMs), built on first use
         self._rot_conj: Dict[int, torch.Tensor] = {}
         self._kv_cols = None
@@ -197,13 +205,20 @@ class SeerTrainer:
             tops.gemm_tn(dy, x, out=P.view(P.g, wkey), colsum=P.view(P.g, bkey) if bkey is not None else None)
         if not need_dx:
             return None
-        WT = tops.transpose(W[wkey]) if P is not None else self._frozenT(wkey)
+        WT = P.wT[wkey] if P is not None else self._frozenT(wkey)
         return ops.gemm(dy, WT, residual=dres, out=out)
 
     def _gn_fwd(self, x1, x2, B, rows_pb, name, eps, silu):
         ops, w = self.ops, self.w
         stats = torch.empty((B, self.eng.G, 2), device=x1.device, dtype=f32)
-        ops.groupnorm_stats(x1, x2, B, self.eng.G, stats)
+        # as in the inference engine (unet._Engine._gn): the column sums the producing GEMM / conv left next to its output, when
+        # every source has them -- no statistics pass over the activations
+        cs1 = getattr(x1, "colsums", None)
+        cs2 = getattr(x2, "colsums", None) if x2 is not None else None
+        if cs1 is not None and (x2 is None or cs2 is not None):
+            ops.groupnorm_stats_from_colsums(cs1, cs2, B, self.eng.G, stats)
+        else:
+            ops.groupnorm_stats(x1, x2, B, self.eng.G, stats)
         C = x1.shape[1] + (0 if x2 is None else x2.shape[1])
         count = rows_pb * (C // self.eng.G)
         y = ops.groupnorm_apply(x1, x2, B, self.eng.G, stats, count, eps, w[name + ".weight"], w[name + ".bias"], silu)
@@ -225,11 +240,12 @@ class SeerTrainer:
         off, n = self.eng.temb_slices[p]
         temb = self._temb[:, off:off + n]
         h1, s1 = self._gn_fwd(x, skip, B, rows_pb, p + ".norm1", self.eng.eps, True)
-        h2 = ops.conv3x3(h1, w[p + ".conv1.weight"], B * Fr, H, W, bias=w[p + ".conv1.bias"], rowvec=temb, rows_per_batch=rows_pb)
+        h2 = ops.conv3x3(h1, w[p + ".conv1.weight"], B * Fr, H, W, bias=w[p + ".conv1.bias"], rowvec=temb, rows_per_batch=rows_pb,
+                         colsum_batch=B)
         h3, s2 = self._gn_fwd(h2, None, B, rows_pb, p + ".norm2", self.eng.eps, True)
         has_sc = (p + ".conv_shortcut.weight") in w
         sc = ops.gemm(x, w[p + ".conv_shortcut.weight"], a2=skip, bias=w[p + ".conv_shortcut.bias"]) if has_sc else x
-        out = ops.conv3x3(h3, w[p + ".conv2.weight"], B * Fr, H, W, bias=w[p + ".conv2.bias"], residual=sc)
+        out = ops.conv3x3(h3, w[p + ".conv2.weight"], B * Fr, H, W, bias=w[p + ".conv2.bias"], residual=sc, colsum_batch=B)
         return out, (p, geo, s1, s2, has_sc, x.shape[1])
 
     def _resnet_bwd(self, saved, dout):
@@ -301,7 +317,7 @@ class SeerTrainer:
         ops.attention(q2, kv[:, :C], kv[:, C:], a2, lse=lse2, **kw2)
         h2 = ops.gemm(a2, w[tb + ".attn2.to_out.0.weight"], bias=w[tb + ".attn2.to_out.0.bias"], residual=h1)
         h3, sff = self._ff_fwd(None, w, self._unet_ff_names(tb), h2)
-        out = ops.gemm(h3, w[p + ".proj_out.weight"], bias=w[p + ".proj_out.bias"], residual=x)
+        out = ops.gemm(h3, w[p + ".proj_out.weight"], bias=w[p + ".proj_out.bias"], residual=x, colsum_batch=B)
         return out, (p, C, sg, h0, qkv, a1, lse1, kw1, h1, q2, kv, a2, lse2, kw2, sff)
 
     def _text_bwd(self, saved, dout, stop_after_kv=False):
@@ -381,7 +397,7 @@ class SeerTrainer:
                 self._scatter(h2, hf2, sl)
             else:
                 h2 = hf2
-        out = ops.gemm(h2, w[p + ".proj_out.weight"], bias=w[p + ".proj_out.bias"], residual=x)
+        out = ops.gemm(h2, w[p + ".proj_out.weight"], bias=w[p + ".proj_out.bias"], residual=x, colsum_batch=B)
         return out, (p, C, d, rot_dim, cs, Fr * HW, sg, hn, h0, n1, qkv, a1, lse, kw, sl, cond_frame, sff, h2)
 
     def _temporal_bwd(self, saved, dout):
@@ -455,7 +471,7 @@ class SeerTrainer:
                 skips.append(x); tape.append(("push", None))
             if i < n - 1:
                 x = ops.conv3x3(x, w[f"{p}.downsamplers.0.conv.weight"], B * Fr, geo[2], geo[3], stride=2,
-                                bias=w[f"{p}.downsamplers.0.conv.bias"])
+                                bias=w[f"{p}.downsamplers.0.conv.bias"], colsum_batch=B)
                 tape.append(("down", (f"{p}.downsamplers.0.conv.weight", geo)))
                 geo = (B, Fr, (geo[2] - 1) // 2 + 1, (geo[3] - 1) // 2 + 1)
                 skips.append(x); tape.append(("push", None))
@@ -472,7 +488,7 @@ class SeerTrainer:
                     x, s = self._temporal_fwd(f"{p}.temporal_attentions.{j}", x, geo, cond_frame); tape.append(("temporal", s))
             if i < n - 1:
                 x = ops.conv3x3(x, w[f"{p}.upsamplers.0.conv.weight"], B * Fr, geo[2], geo[3], upsample=True,
-                                bias=w[f"{p}.upsamplers.0.conv.bias"])
+                                bias=w[f"{p}.upsamplers.0.conv.bias"], colsum_batch=B)
                 tape.append(("up", (f"{p}.upsamplers.0.conv.weight", geo)))
                 geo = (B, Fr, geo[2] * 2, geo[3] * 2)
         x, s = self._gn_fwd(x, None, B, Fr * geo[2] * geo[3], "conv_norm_out", eng.eps, True); tape.append(("gn_out", s))
@@ -694,6 +710,7 @@ class SeerTrainer:
     def _phase_a(self, model_input, target, timesteps, text_cond_emb, cond_frames):
         b, _, Fr, _, _ = model_input.shape
         assert self.fstext.num_frames == Fr, "fstext.set_numframe(F) first (train.py:187)"
+        self._wt_plan.run()
         y, fs_saved = self._fstext_fwd(text_cond_emb)                     # [b*F*l, Dc] bf16, rows (b, f, l)
         t = timesteps if torch.is_tensor(timesteps) else torch.tensor([timesteps] * b)
         t = t.to(model_input.device, torch.int64).expand(b).contiguous()

@@ -157,6 +157,27 @@ def test_transpose(device, rows, cols):
     assert (y[:, rows:] == 0).all()
 
 
+def test_transpose_batched(device):
+    """many matrices, one launch: ragged row counts, column counts that are not tile multiples, row-strided sources; a second
+    run() picks up new values at the same addresses (the trainer's weights after an AdamW step)"""
+    from seervideoldm_amd import train_ops
+    shapes = [(64, 64), (100, 320), (924, 768), (1, 8), (2560, 320), (160, 1288), (77, 72), (3072, 768)]
+    flat = _rand((sum(r * (c + 8) for r, c in shapes),), device, 3).to(bf16)
+    xs, off = [], 0
+    for r, c in shapes:
+        xs.append(flat[off:off + r * (c + 8)].view(r, c + 8)[:, :c])
+        off += r * (c + 8)
+    plan = train_ops.TransposePlan(xs)
+    for rnd in range(2):
+        plan.run()
+        for x, y in zip(xs, plan.outputs):
+            rows, cols = x.shape
+            assert y.shape == (cols, (rows + 63) // 64 * 64)
+            assert torch.equal(y[:, :rows], x.t()), (rnd, rows, cols)
+            assert (y[:, rows:] == 0).all()
+        flat.mul_(-0.5)
+
+
 @pytest.mark.parametrize("rows,cols", [(64, 320), (924, 768), (12288, 960), (30, 2560), (1, 8)])
 def test_colsum(device, rows, cols):
     from seervideoldm_amd import train_ops

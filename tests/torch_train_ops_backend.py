@@ -87,6 +87,16 @@ def transpose(x, pad_to=64):
     return y
 
 
+class TransposePlan:
+    def __init__(self, xs):
+        self.inputs = list(xs)
+        self.outputs = [transpose(x) for x in xs]
+
+    def run(self):
+        for x, y in zip(self.inputs, self.outputs):
+            y.copy_(transpose(x))
+
+
 def colsum(x, out=None):
     s = x.float().sum(0)
     if out is None:
