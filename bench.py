@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     ap.add_argument("--no-train", action="store_true", help="skip the extra fine-tuning step measurement (config 5)")
+    ap.add_argument("--collective-timeout-s", type=float, default=300.0,
+                    help="N > 1: a phase with collectives (the partitioned step, the data-parallel fine-tuning step) that has not "
+                         "finished after this long is abandoned: rank 0 prints the line with what was measured so far, every rank exits")
     ap.add_argument("--no-capture-collectives", action="store_true",
                     help="N > 1: keep the RCCL exchanges of the partitioned step eager between hipGraph segments")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="sthv2",
@@ -173,6 +176,38 @@ def cpu_baseline(sd_cpu, cfg, budget_s):
                        f"({ts[0]:.1f} / {ts[1]:.1f} / {ts[2]:.1f} s, median used), scaled linearly in F to the full step")
 
 
+class Watchdog:
+    """N > 1 only.  A hung collective cannot be caught as an exception (the RCCL watchdog would abort the process, and the driver
+    would get no line at all): while a phase with collectives runs, a timer thread on every rank waits; if the phase is still
+    running at the deadline, rank 0 prints the JSON line built from what HAS been measured (`fallback()`), and every rank leaves
+    with exit code 0 (`os._exit`: no destructor waits on the hung stream)."""
+
+    def __init__(self, rank: int):
+        self.rank = rank
+        self._ev = None
+
+    def arm(self, seconds: float, fallback) -> None:
+        import threading
+        ev = threading.Event()
+        self._ev = ev
+
+        def run():
+            if not ev.wait(seconds):
+                if self.rank == 0:
+                    try:
+                        print(json.dumps(fallback()), flush=True)
+                    finally:
+                        os._exit(0)
+                time.sleep(5.0)          # rank 0 prints first
+                os._exit(0)
+        threading.Thread(target=run, daemon=True).start()
+
+    def disarm(self) -> None:
+        if self._ev is not None:
+            self._ev.set()
+            self._ev = None
+
+
 def main():
     args = parse()
     WORKLOAD.update({k: v for k, v in WORKLOADS[args.workload].items() if k != "name"})
@@ -273,20 +308,46 @@ def main():
 
     # ---- N > 1: the headline is ONE step partitioned over all GPUs (the north star's batch x frame sharding)
     weak, parallelism = None, "single"
+    dog = Watchdog(rank)
+
+    def make_line(ms, par, graph, roofline, cpu, clip, train, weak_obj):
+        line = {
+            "metric": "UNet denoising steps/sec (12-frame 256^2 latent, 50-step DDIM)" if args.workload == "sthv2"
+                      else f"UNet denoising steps/sec ({args.workload} workload, 50-step DDIM)",
+            "value": round((world if "independent samples" in par else 1) * 1e3 / ms, 3), "unit": "steps/s",
+            "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "scaling": "strong" if (world > 1 and "independent samples" not in par) else "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": WORKLOADS[args.workload]["name"] + ", "
+                                   "full-width SeerUNet 1.08G params, 50-step DDIM, scale 7.5",
+                       "global_batch": WORKLOADS[args.workload]["b"], "parallelism": par,
+                       "hip_graph": graph},
+            "roofline": roofline, "cpu_baseline": cpu, "end_to_end": clip, "train_step": train,
+        }
+        if weak_obj is not None:
+            line["weak_scaling"] = weak_obj
+        return line
+
     if world > 1:
         from seervideoldm_amd import parallel
         weak = {"value": round(world * 1e3 / ms_per_step, 3), "unit": "steps/s", "ms_per_step": round(ms_per_step, 3),
                 "scaling": "weak", "what": f"{world} independent samples, one CFG-batched sample per GPU, no data-path collective"}
-        shard = parallel.attach(model, world, rank, capture_collectives=False if args.no_capture_collectives else None)
         # the sharded step must never cost the line: a failure that reaches every rank (capture refused, a partition the frame
-        # count does not allow) is reported in the JSON and the independent-samples number stands as `value`.  (A rank that dies
-        # or hangs inside a collective cannot be caught from here; the RCCL watchdog ends the job.)
+        # count does not allow) is reported in the JSON and the independent-samples number stands as `value`.  A rank that
+        # HANGS inside a collective cannot be caught as an exception: the Watchdog prints the same fallback line at the deadline.
         sharded_error = None
+        dog.arm(args.collective_timeout_s, lambda: make_line(
+            ms_per_step, f"{world} independent samples (the partitioned step did not finish within "
+                         f"{args.collective_timeout_s:.0f} s: abandoned)", graph_live, None, None, None, None, weak))
+        shard = parallel.attach(model, world, rank, capture_collectives=False if args.no_capture_collectives else None)
         try:
             ms_sharded = timed_steps()
         except Exception as e:      # noqa: BLE001
             sharded_error = f"{type(e).__name__}: {e}"[:300]
-        if shard.agree(sharded_error is None, device):
+        ok = shard.agree(sharded_error is None, device)
+        dog.disarm()
+        if ok:
             ms_per_step = ms_sharded
             parallelism = f"{shard.describe()} over {world} RCCL ranks"
             graph_live = bool(model._engine._graphs and not getattr(model._engine, "_graph_broken", False))
@@ -417,6 +478,9 @@ def main():
             if world > 1:
                 import torch.distributed as dist
                 pg = dist.group.WORLD
+                dog.arm(args.collective_timeout_s, lambda: make_line(
+                    ms_per_step, parallelism, graph_live, roofline, None, clip,
+                    {"error": f"the data-parallel fine-tuning step did not finish within {args.collective_timeout_s:.0f} s"}, weak))
             train = time_train(device, steps=5, warmup=2, unet=model, process_group=pg)
             if world > 1:
                 tms = torch.tensor([train["ms_per_step"]], device=device)
@@ -432,28 +496,14 @@ def main():
                                           "samples_per_s": round(8e3 / big["ms_per_step"], 2)}
         except Exception as e:      # noqa: BLE001
             train = {"error": f"{type(e).__name__}: {e}"[:300]}
+        dog.disarm()
 
     cpu = None
     if sd_cpu is not None:
         cpu = cpu_baseline(sd_cpu, cfg, args.cpu_budget_s)
 
     if rank == 0:
-        line = {
-            "metric": "UNet denoising steps/sec (12-frame 256^2 latent, 50-step DDIM)" if args.workload == "sthv2"
-                      else f"UNet denoising steps/sec ({args.workload} workload, 50-step DDIM)",
-            "value": round((world if "independent samples" in parallelism else 1) * 1e3 / ms_per_step, 3), "unit": "steps/s",
-            "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "strong" if (world > 1 and "independent samples" not in parallelism) else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": WORKLOADS[args.workload]["name"] + ", "
-                                   "full-width SeerUNet 1.08G params, 50-step DDIM, scale 7.5",
-                       "global_batch": WORKLOADS[args.workload]["b"], "parallelism": parallelism,
-                       "hip_graph": graph_live},
-            "roofline": roofline, "cpu_baseline": cpu, "end_to_end": clip, "train_step": train,
-        }
-        if weak is not None:
-            line["weak_scaling"] = weak
-        print(json.dumps(line), flush=True)
+        print(json.dumps(make_line(ms_per_step, parallelism, graph_live, roofline, cpu, clip, train, weak)), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -40,3 +40,4 @@ def test_bench_multi_rank_contract(world, partition):
     ws = j["weak_scaling"]
     assert ws["scaling"] == "weak" and ws["value"] > 0 and abs(ws["value"] - world * 1e3 / ws["ms_per_step"]) < 1e-2 * ws["value"]
     assert j["vs_baseline"] is None and j["dtype"] == "bf16" and j["data"] == "synthetic"
+
