@@ -1246,7 +1246,12 @@ int resolve_tile(const seer_gemm_desc& d) {
             const long t96160 = (long)((d.M + 95) / 96) * ((d.N + 159) / 160) * d.batch;
             auto fill = [](long t) { return (double)t / (256.0 * (double)((t + 255) / 256)); };
             tile = fill(t96160) > fill(t128160) + 0.05 ? SEER_TILE_G96x160_2 : SEER_TILE_G128x160_2;
+            // the rotary epilogue (temporal q|k|v) reads a (cos, sin) row per output row: fewer, taller tiles re-read less of the
+            // table -- 24 576 x 960 x 320: 30.0 us on 128x160 against 34.8 on 96x160 (profiles/r03_tile_ab_rotary.log)
+            if ((d.epilogue & SEER_EPI_ROTARY) && t128160 >= 256) tile = SEER_TILE_G128x160_2;
         }
+        else if ((d.epilogue & SEER_EPI_ROTARY) && d.N == 1920 && nk >= 5 && (long)((d.M + 95) / 96) * 12 * d.batch >= 256)
+            tile = SEER_TILE_G96x160_2;      // 6 144 x 1 920 x 640 rotary: 24.0 us against 26.8 on 128x128 (same log)
         else if (t128 >= 256 && n_fits_128 && d.N >= 640) tile = SEER_TILE_G128x128_2;
         else if (t12864 >= 256 && nk >= 5) tile = SEER_TILE_G128x64_3;   // (K = 320 too: 8.9 vs 9.7 us on 12 288 x 320, r02_half_rows.log)
         else if (nk >= 64) tile = SEER_TILE_G64x64_5;        // long K on few tiles: deeper ring (see prepare(), unsplit_ring)
