@@ -181,7 +181,8 @@ typedef struct seer_attn_desc {
     uint32_t flags;
     /* kernel selection, a descriptor field so that A/B runs need no global state: 0 = auto; 1 = generic kernel, one K|V LDS
      * buffer; 6 = generic kernel, ping-pong buffers; head_dim 40 only: 3 = the d = 40 kernel (fast path with the in-launch
-     * fallback), 5 = the same kernel running its tracked-reference form directly (what lse != NULL selects) */
+     * fallback; 32 queries per wave), 2 = the same with 64 queries per wave (what 0 picks from four rounds of resident workgroups
+     * up), 5 = the kernel running its tracked-reference form directly (what lse != NULL selects) */
     int32_t variant;
     /* head strides (elements): head h of Q / K / V starts h * q_hs / k_hs / v_hs elements after the batch element's base.
      * 0 = head_dim: the heads are adjacent column groups of token-major rows (the layout of a fused [tokens, 3C] projection).

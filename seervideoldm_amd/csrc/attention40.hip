@@ -162,7 +162,7 @@ extern "C" long long* seer_lab_a40_stamps() {
 // arithmetic folds away -- and the two uses of the kernel carry different names in a profile (the spatial [192,1024,40] block is
 // the north star's kernel target; the causal window form serves the temporal blocks at 36 us, and one name for both reads 43)
 template <int QB, bool TRACK_ONLY, bool PLAIN>
-__global__ void __launch_bounds__(256, 3) seer_attn40_kernel(const seer_attn_desc p, const int ws_log2_arg, const int nqb) {
+__global__ void __launch_bounds__(256, QB == 1 ? 3 : 2) seer_attn40_kernel(const seer_attn_desc p, const int ws_log2_arg, const int nqb) {
     const int ws_log2 = PLAIN ? -1 : ws_log2_arg;
     const bool causal = PLAIN ? false : (p.causal != 0);
     constexpr int D = A40_D;
@@ -505,16 +505,31 @@ __global__ void __launch_bounds__(256, 3) seer_attn40_kernel(const seer_attn_des
 
 }  // namespace
 
-// called by seer_attn_fwd (attention.hip) for head_dim 40.  One shape is built: 32 queries per wave, 128 per workgroup,
-// three workgroups per CU (a 64-query wave shares its K / V fragments between two query blocks but spills at 168 registers and
-// measured 10-20 % slower, profiles/r02_attn40_variants.log).  variant 5, or lse != NULL, runs the tracked form directly.
+// called by seer_attn_fwd (attention.hip) for head_dim 40.  Two shapes: 32 queries per wave, 128 per workgroup, three workgroups
+// per CU; and 64 queries per wave, 256 per workgroup, two workgroups per CU (under the three-workgroup register bound that form
+// spilled at 168 registers and measured 10-20 % slower, profiles/r02_attn40_variants.log; at its own 240 it does not).
+// variant 5, or lse != NULL, runs the tracked form directly.
 int seer_attn40_launch(const seer_attn_desc& d, int ws_log2, hipStream_t st) {
     int nbatch = d.batch;
     if (ws_log2 >= 0) nbatch *= (d.H >> ws_log2) * (d.W >> ws_log2);
     const bool track = d.variant == 5 || d.lse != nullptr;
+    const bool plain = ws_log2 < 0 && !d.causal && d.causal_offset == 0;
+    // 64 queries per wave (K / V fragments, LDS-DMA issue and barriers shared by two query blocks; 240 registers: two waves per
+    // SIMD): as fast as the 32-query form where the grid is 1.5 rounds of the 512 resident workgroups (the 32^2 spatial block:
+    // 56.9 vs 58.6 us), 5 % faster once the rounds are many ([192, 4096, 40]: 604 vs 637 us; profiles/r03_lab_attn_qb2.log) --
+    // taken from four rounds up; variant 2 forces it (A/B runs, tests)
+    const int nqb2 = (d.Sq + 255) / 256;
+    // (plain launches only: under a causal mask the 64-query wave does the work of its later query block for the earlier
+    //  one too -- temporal window block 47 vs 36 us)
+    if (!track && (d.variant == 2 || (d.variant == 0 && plain && (long)nqb2 * nbatch * d.heads >= 2048))) {
+        dim3 grid2((unsigned)(nqb2 * nbatch * d.heads));
+        if (plain) hipLaunchKernelGGL((seer_attn40_kernel<2, false, true>), grid2, dim3(256), 0, st, d, ws_log2, nqb2);
+        else hipLaunchKernelGGL((seer_attn40_kernel<2, false, false>), grid2, dim3(256), 0, st, d, ws_log2, nqb2);
+        SEER_LAUNCH_CHECK();
+        return SEER_OK;
+    }
     const int nqb = (d.Sq + 127) / 128;
     dim3 grid((unsigned)(nqb * nbatch * d.heads));
-    const bool plain = ws_log2 < 0 && !d.causal && d.causal_offset == 0;
     if (track && plain) hipLaunchKernelGGL((seer_attn40_kernel<1, true, true>), grid, dim3(256), 0, st, d, ws_log2, nqb);
     else if (track) hipLaunchKernelGGL((seer_attn40_kernel<1, true, false>), grid, dim3(256), 0, st, d, ws_log2, nqb);
     else if (plain) hipLaunchKernelGGL((seer_attn40_kernel<1, false, true>), grid, dim3(256), 0, st, d, ws_log2, nqb);

@@ -465,11 +465,11 @@ def _rel_l2(got, ref):
     return ((got - ref).norm() / ref.norm().clamp_min(1e-30)).item()
 
 
-@pytest.mark.parametrize("variant", [1, 3, 5])
+@pytest.mark.parametrize("variant", [1, 2, 3, 5])
 @pytest.mark.parametrize("Sq,Sk,causal", [(1024, 1024, False), (768, 768, True), (1000, 930, False), (333, 333, True),
                                            (130, 2049, False), (64, 256, False)])
 def test_attention_d40_kernels(device, variant, Sq, Sk, causal):
-    """head_dim 40: the generic kernel (variant 1), the d = 40 kernel's fast path (3) and its tracked form (5) against the
+    """head_dim 40: the generic kernel (variant 1), the d = 40 kernel's fast path (3; 2 = its 64-queries-per-wave shape) and its tracked form (5) against the
     fp32 formula (xformers MEA as called at attention.py:622-630)"""
     from seervideoldm_amd import ops
     B, Hh, d = 2, 8, 40
@@ -489,7 +489,7 @@ def test_attention_d40_kernels(device, variant, Sq, Sk, causal):
     _close(out, ref, rtol=2e-2, atol=1e-2, what=f"d40 variant {variant} {Sq}x{Sk} causal={causal}")
 
 
-@pytest.mark.parametrize("d,variant", [(40, 1), (40, 3), (40, 5), (80, 0), (96, 0), (160, 0)])
+@pytest.mark.parametrize("d,variant", [(40, 1), (40, 2), (40, 3), (40, 5), (80, 0), (96, 0), (160, 0)])
 @pytest.mark.parametrize("amp", [3.0, 6.0])
 def test_attention_sharp_softmax(device, d, variant, amp):
     """scores hundreds of log2 units apart (cdna guide, rule 26: the rare branch needs its own test).  This is the case that
