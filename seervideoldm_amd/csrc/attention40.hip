@@ -386,6 +386,40 @@ __global__ void __launch_bounds__(256, QB == 1 ? 3 : 2) seer_attn40_kernel(const
                 }
                 bf16x8 vf[2][2];                                  // [key step][d tile], shared by the wave's query blocks
                 bool v_ready = false;
+                if constexpr (QB == 2 && PLAIN && !TRACK) {
+                    // two query blocks, software-pipelined: both score tiles are issued before the first exponentials, so the
+                    // matrix pipe works on block 1's Q K^T under block 0's exponentials and on block 0's P V under block 1's
+                    f32x16 s0 = qk(kf, 0);
+                    f32x16 s1 = qk(kf, 1);
+                    if (kb + 31 >= p.Sk) {
+                        mask_scores(s0, kb, 0);
+                        mask_scores(s1, kb, 1);
+                    }
+                    auto exp_pack = [&](const f32x16& sc, u32x4 (&pk)[2]) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const float e0 = __builtin_amdgcn_exp2f(sc[2 * i]), e1 = __builtin_amdgcn_exp2f(sc[2 * i + 1]);
+                            pk[i >> 2][i & 3] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, e1), __builtin_bit_cast(unsigned, e0),
+                                                                      0x07060302u);
+                        }
+                    };
+                    auto pv = [&](int qb, const u32x4 (&pk)[2]) {
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            const bf16x8 pb = __builtin_bit_cast(bf16x8, pk[s2]);
+                            oacc[qb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s2][0], pb, oacc[qb][0], 0, 0, 0);
+                            oacc[qb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s2][1], pb, oacc[qb][1], 0, 0, 0);
+                        }
+                    };
+                    u32x4 pk0[2], pk1[2];
+                    exp_pack(s0, pk0);
+                    lds_wait_v(vraw, vf[0][0], vf[0][1], vf[1][0], vf[1][1]);
+                    pv(0, pk0);
+                    exp_pack(s1, pk1);
+                    pv(1, pk1);
+                    A40_STAMP();
+                    continue;
+                }
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) {
                     if (causal && kb > q0w + 32 * qb + 31 + q_off) continue;      // this query block is above the diagonal
@@ -514,14 +548,15 @@ int seer_attn40_launch(const seer_attn_desc& d, int ws_log2, hipStream_t st) {
     if (ws_log2 >= 0) nbatch *= (d.H >> ws_log2) * (d.W >> ws_log2);
     const bool track = d.variant == 5 || d.lse != nullptr;
     const bool plain = ws_log2 < 0 && !d.causal && d.causal_offset == 0;
-    // 64 queries per wave (K / V fragments, LDS-DMA issue and barriers shared by two query blocks; 240 registers: two waves per
-    // SIMD): as fast as the 32-query form where the grid is 1.5 rounds of the 512 resident workgroups (the 32^2 spatial block:
-    // 56.9 vs 58.6 us), 5 % faster once the rounds are many ([192, 4096, 40]: 604 vs 637 us; profiles/r03_lab_attn_qb2.log) --
-    // taken from four rounds up; variant 2 forces it (A/B runs, tests)
+    // 64 queries per wave: K / V fragments, LDS-DMA issue and barriers are shared by two query blocks, and the two blocks are
+    // software-pipelined (both Q K^T chains first, then block 0's exponentials under block 1's chain, block 0's P V under block
+    // 1's exponentials); 240 registers, two waves per SIMD.  [192, 1024, 40]: 53.2 vs 56.3 us, [192, 4096, 40]: 582 vs 643 us
+    // (profiles/r03_lab_attn_qb2.log).  Taken by non-causal launches that fill at least one round of the 512 resident workgroups;
+    // variant 2 forces it, variant 3 the 32-query form (A/B runs, tests)
     const int nqb2 = (d.Sq + 255) / 256;
     // (plain launches only: under a causal mask the 64-query wave does the work of its later query block for the earlier
     //  one too -- temporal window block 47 vs 36 us)
-    if (!track && (d.variant == 2 || (d.variant == 0 && plain && (long)nqb2 * nbatch * d.heads >= 2048))) {
+    if (!track && (d.variant == 2 || (d.variant == 0 && plain && (long)nqb2 * nbatch * d.heads >= 512))) {
         dim3 grid2((unsigned)(nqb2 * nbatch * d.heads));
         if (plain) hipLaunchKernelGGL((seer_attn40_kernel<2, false, true>), grid2, dim3(256), 0, st, d, ws_log2, nqb2);
         else hipLaunchKernelGGL((seer_attn40_kernel<2, false, false>), grid2, dim3(256), 0, st, d, ws_log2, nqb2);
