@@ -228,30 +228,25 @@ __global__ void __launch_bounds__(256, QB == 1 ? 3 : 2) seer_attn40_kernel(const
     // ---- LDS-DMA plan: 20 wave instructions per tile (10 K + 10 V, 1 KiB each), wave w issues e = w + 4 i.
     // Source pointers are kept per slot and advanced by a constant per tile (128 keys = a whole number of frames of a
     // window, so the step is constant in the window form too); only a partial last tile recomputes them with the clamp.
-    int dma_row[5];                                  // key (inside the tile) whose row this lane fetches
-    int dma_c8[5];                                   // element offset of its 16-byte chunk
-    const bf16* dma_src[5];
+    // Kept per slot: ONE 32-bit byte offset from the wave-uniform K / V base of the (batch, head) -- the row / chunk of a lane are
+    // recomputed where they are needed (set-up and partial tiles), so the plan costs 5 registers, not 20.
+    unsigned dma_o[5];
     const int tok_step = ws_log2 < 0 ? A40_KT : (A40_KT >> (2 * ws_log2)) * tok.HW;   // tokens per tile
-    auto dma_addr = [&](int i, int kt0) {
-        const bool is_v = (wave + 4 * i) >= 10;
-        int kg = kt0 + dma_row[i];
-        kg = kg < p.Sk ? kg : p.Sk - 1;
-        const int64_t tk = tok(kg);
-        return is_v ? (Vg + tk * p.v_ss + dma_c8[i]) : (Kg + tk * p.k_ss + dma_c8[i]);
-    };
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
+    auto dma_off = [&](int i, int kt0) {
         const int e = wave + 4 * i;
         const bool is_v = e >= 10;
         const int j = is_v ? e - 10 : e;
         const int idx = 64 * j + lane;               // 16-byte chunk index inside the 128 x 5 image
         const int pos = idx / 5;
-        dma_c8[i] = (idx - pos * 5) * 8;
-        int key = pos;
+        const int c8 = (idx - pos * 5) * 8;          // element offset of the lane's 16-byte chunk
+        int key = pos;                               // key (inside the tile) whose row this lane fetches
         if (is_v)     // V rows are stored transposed inside every group of 16: key 4 y + x sits at row 4 x + y, so that the four
             key = (pos & ~15) + 4 * (pos & 3) + ((pos >> 2) & 3);     // keys of a transposed read are 4 rows (320 B) apart
-        dma_row[i] = key;
-    }
+        int kg = kt0 + key;
+        kg = kg < p.Sk ? kg : p.Sk - 1;
+        const int64_t tk = tok(kg);
+        return (unsigned)((tk * (is_v ? p.v_ss : p.k_ss) + c8) * 2);      // < 2^32: checked by the launcher
+    };
     auto issue_tile = [&](int t, unsigned char* stage) {
         const bool partial = (t + 1) * A40_KT > p.Sk;                 // wave-uniform
 #pragma unroll
@@ -259,10 +254,11 @@ __global__ void __launch_bounds__(256, QB == 1 ? 3 : 2) seer_attn40_kernel(const
             const int e = wave + 4 * i;
             const bool is_v = e >= 10;
             const int j = is_v ? e - 10 : e;
-            const bf16* src = partial ? dma_addr(i, t * A40_KT) : dma_src[i];
-            dma_src[i] += (int64_t)tok_step * (is_v ? p.v_ss : p.k_ss);
+            const unsigned off = partial ? dma_off(i, t * A40_KT) : dma_o[i];
+            dma_o[i] += (unsigned)(tok_step * (is_v ? p.v_ss : p.k_ss) * 2);
+            const unsigned char* base = reinterpret_cast<const unsigned char*>(is_v ? Vg : Kg);      // wave-uniform
             unsigned char* dst = stage + (is_v ? A40_HALF : 0) + j * 1024;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
     };
@@ -337,7 +333,7 @@ __global__ void __launch_bounds__(256, QB == 1 ? 3 : 2) seer_attn40_kernel(const
     auto run = [&](auto track) {
         constexpr bool TRACK = decltype(track)::value;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) dma_src[i] = dma_addr(i, 0);
+        for (int i = 0; i < 5; ++i) dma_o[i] = dma_off(i, 0);
         issue_tile(0, stage_a);
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
@@ -546,6 +542,11 @@ __global__ void __launch_bounds__(256, QB == 1 ? 3 : 2) seer_attn40_kernel(const
 int seer_attn40_launch(const seer_attn_desc& d, int ws_log2, hipStream_t st) {
     int nbatch = d.batch;
     if (ws_log2 >= 0) nbatch *= (d.H >> ws_log2) * (d.W >> ws_log2);
+    // the LDS-DMA plan addresses K / V rows by 32-bit byte offsets from the (batch, head) base
+    {
+        const int64_t ntok = ws_log2 >= 0 ? (int64_t)d.F * d.H * d.W : (int64_t)d.Sk;
+        if (ntok * (d.k_ss > d.v_ss ? d.k_ss : d.v_ss) * 2 >= (int64_t)1 << 32) return SEER_ENOSYS;
+    }
     const bool track = d.variant == 5 || d.lse != nullptr;
     const bool plain = ws_log2 < 0 && !d.causal && d.causal_offset == 0;
     // 64 queries per wave: K / V fragments, LDS-DMA issue and barriers are shared by two query blocks, and the two blocks are
