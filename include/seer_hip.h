@@ -111,6 +111,12 @@ typedef struct seer_gemm_desc {
      * transposed output, the weight-stationary kernel) fails with SEER_EINVAL when colsum is set: ask seer_gemm_colsum_rows
      * first. */
     float* colsum;
+    /* in-launch split-K (the 256 x 320 tile kernel, SEER_TILE_T256x320): two 32-bit counters per output tile,
+     * seer_gemm_sync_bytes(desc) bytes.  ZERO before the first launch that uses them; every launch leaves them zero again, so
+     * one buffer serves all launches that are ordered on one stream (launches that may overlap in time need their own).  NULL:
+     * the launch falls back to the two-launch split-K of the smaller tiles. */
+    void* sync;
+    int64_t sync_bytes;
 } seer_gemm_desc;
 
 #define SEER_TILE_AUTO 0
@@ -139,6 +145,7 @@ typedef struct seer_gemm_desc {
  * AUTO picks it for plain GEMMs with K <= 768 and M >= 1024, this value asks for it (falls back to AUTO when not eligible) */
 #define SEER_TILE_G256x256_2 21 /* 8 waves, 64x128 wave tiles, 2 x 64 KB stages: the only tile whose FLOPs per LDS-fill byte (128) reach the MFMA roof */
 #define SEER_TILE_WS 19
+#define SEER_TILE_T256x320 22  /* 8 waves (4 x 2), 64 x 160 wave tiles, 142 FLOP per LDS-fill byte; N % 320 == 0; K slices reduced inside the launch (desc.sync) */
 #define SEER_TILE_AUTO_TILED 20   /* AUTO restricted to the tile kernel (A/B runs against the weight-stationary kernel) */
 
 int seer_gemm_bf16(const seer_gemm_desc* desc /* host */, void* stream);
@@ -147,6 +154,8 @@ int64_t seer_gemm_workspace_bytes(const seer_gemm_desc* desc /* host */);
 /* rows per partial of the column sums this exact launch (same tile / splits / workspace fields) would write to desc->colsum,
  * or 0 when it cannot produce them; the buffer is [z][ceil(M / rows)][N][2] floats */
 int32_t seer_gemm_colsum_rows(const seer_gemm_desc* desc /* host */);
+/* bytes of zeroed counter memory (desc->sync) the call would use to reduce its K slices inside the launch (0: none) */
+int64_t seer_gemm_sync_bytes(const seer_gemm_desc* desc /* host */);
 
 /* ---- attention -------------------------------------------------------------------------- */
 /* Replaces xformers.ops.memory_efficient_attention as called from CrossAttention

@@ -81,6 +81,12 @@ int main(int argc, char** argv) {
     uint16_t *dA, *dW, *dC, *dR; float *dB; void* dWs;
     CK(hipMalloc(&dA, pool_elems * 2)); CK(hipMalloc(&dW, pool_elems * 2)); CK(hipMalloc(&dC, pool_elems * 2)); CK(hipMalloc(&dR, pool_elems * 2));
     CK(hipMalloc(&dB, 65536 * 4)); CK(hipMalloc(&dWs, (size_t)512 << 20));
+    void* dSync;                                   // counters of the in-launch split-K reduction (zero between launches)
+    CK(hipMalloc(&dSync, 1 << 20)); CK(hipMemset(dSync, 0, 1 << 20));
+    uint16_t* dC2 = nullptr;                       // LAB_CHECK=1: the same launch on the AUTO tile, compared on the host
+    float* dCs2 = nullptr;
+    const bool check = getenv("LAB_CHECK") != nullptr;
+    if (check) { CK(hipMalloc(&dC2, pool_elems * 2)); CK(hipMalloc(&dCs2, (size_t)64 << 20)); }
     float* dCs;                                    // column-sum partials (LAB_COLSUM=1)
     CK(hipMalloc(&dCs, (size_t)64 << 20));
     float* dTab;                                   // rotary (cos, sin) table: 12288 positions x 16 pairs
@@ -123,6 +129,8 @@ int main(int argc, char** argv) {
         int64_t ws = seer_gemm_workspace_bytes(&d);
         if (ws < 0) { printf("%-28s workspace query failed: %s\n", s.name, seer_strerror((int)ws)); continue; }
         if (ws > 0) { d.workspace = dWs; d.workspace_bytes = ws; }
+        const int64_t sb = seer_gemm_sync_bytes(&d);
+        if (sb > 0) { d.sync = dSync; d.sync_bytes = sb; }
         if (getenv("LAB_COLSUM") && !s.geglu) {      // the launch also leaves per-tile column sums (outputs that feed a GroupNorm)
             d.colsum = dCs;
             if (seer_gemm_colsum_rows(&d) <= 0) d.colsum = nullptr;
@@ -149,6 +157,49 @@ int main(int argc, char** argv) {
                 printf("  block %d wave %d hw_id %llx (10 ns ticks since start):", b, w, (unsigned long long)t[63]);
                 for (int i = 1; i < 63 && t[i]; ++i) printf(" %lld", t[i] - t[0]);
                 printf("\n");
+            }
+        }
+        if (check) {
+            // reference: the AUTO tile of the library on the same operands; bf16 outputs agree to a few ulps (different
+            // summation order), column sums to ~1e-3 relative
+            seer_gemm_desc r = d;
+            r.tile = 0; r.splits = 0; r.C = dC2; r.sync = nullptr; r.sync_bytes = 0; r.workspace = nullptr; r.workspace_bytes = 0;
+            r.colsum = nullptr;
+            const int64_t rws = seer_gemm_workspace_bytes(&r);
+            if (rws > 0) { r.workspace = (char*)dWs + ((size_t)256 << 20); r.workspace_bytes = rws; }
+            const size_t out_rows = s.conv && s.up == 2 ? (size_t)d.M * 4 : (size_t)d.M;
+            const size_t n_out = (size_t)out_rows * d.ldc;
+            CK(hipMemsetAsync(dC, 0xff, n_out * 2, st)); CK(hipMemsetAsync(dC2, 0xee, n_out * 2, st));
+            int rc1 = seer_gemm_bf16(&d, st), rc2 = seer_gemm_bf16(&r, st);
+            CK(hipStreamSynchronize(st));
+            std::vector<uint16_t> a(n_out), b(n_out);
+            CK(hipMemcpy(a.data(), dC, n_out * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), dC2, n_out * 2, hipMemcpyDeviceToHost));
+            double num = 0, den = 0, worst = 0; size_t bad = 0, first_bad = (size_t)-1;
+            for (size_t i = 0; i < n_out; ++i) {
+                uint32_t ua = (uint32_t)a[i] << 16, ub = (uint32_t)b[i] << 16; float fa, fb; memcpy(&fa, &ua, 4); memcpy(&fb, &ub, 4);
+                const double e = fabs((double)fa - fb);
+                num += e * e; den += (double)fb * fb;
+                if (e > worst) worst = e;
+                if (!(e <= 0.02 * fabs(fb) + 0.02)) { ++bad; if (first_bad == (size_t)-1) first_bad = i; }
+            }
+            printf("  check vs AUTO tile: rc %d %d, rel_l2 %.3g, max abs %.3g, %zu of %zu outside tolerance%s", rc1, rc2, sqrt(num / (den + 1e-30)), worst,
+                   bad, n_out, bad ? "  <-- MISMATCH" : "");
+            if (bad) printf(" (first at row %zu col %zu)", first_bad / d.ldc, first_bad % d.ldc);
+            printf("\n");
+            if (d.colsum) {
+                // column sums: total over all partials per column vs a host sum of the stored output
+                const int rows = seer_gemm_colsum_rows(&d);
+                const size_t parts = (size_t)(d.batch > 1 ? d.batch : 1) * ((d.M + rows - 1) / rows);
+                std::vector<float> cs(parts * d.N * 2);
+                CK(hipMemcpy(cs.data(), dCs, cs.size() * 4, hipMemcpyDeviceToHost));
+                double werr = 0;
+                for (int n = 0; n < d.N; ++n) {
+                    double s1 = 0, s2 = 0, h1 = 0, h2 = 0;
+                    for (size_t pp = 0; pp < parts; ++pp) { s1 += cs[(pp * d.N + n) * 2]; s2 += cs[(pp * d.N + n) * 2 + 1]; }
+                    for (size_t m = 0; m < out_rows; ++m) { uint32_t ua = (uint32_t)a[m * d.ldc + n] << 16; float fa; memcpy(&fa, &ua, 4); h1 += fa; h2 += (double)fa * fa; }
+                    werr = fmax(werr, fabs(s1 - h1) / (fabs(h1) + 1.0)); werr = fmax(werr, fabs(s2 - h2) / (fabs(h2) + 1.0));
+                }
+                printf("  colsum check (%d rows per partial, %zu partials): worst relative error %.3g%s\n", rows, parts, werr, werr > 1e-3 ? "  <-- MISMATCH" : "");
             }
         }
         total_ms += us * s.calls * 1e-3;

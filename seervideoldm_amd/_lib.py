@@ -13,7 +13,7 @@ _PKG = Path(__file__).resolve().parent
 _LIB_PATH = _PKG / "lib" / "libseer_hip.so"
 _lib = None
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 SEER_GEMM_PLAIN = 0
 SEER_GEMM_CONV3X3 = 1
@@ -48,7 +48,7 @@ class GemmDesc(C.Structure):
         ("rot_head_dim", C.c_int32), ("rot_dim", C.c_int32), ("rot_cols", C.c_int32),
         ("pad_after_only", C.c_int32),
         ("col_scale_cols", C.c_int32), ("col_scale", C.c_float),
-        ("colsum", C.c_void_p),
+        ("colsum", C.c_void_p), ("sync", C.c_void_p), ("sync_bytes", C.c_int64),
     ]
 
 
@@ -87,6 +87,7 @@ SIGNATURES = {
     "seer_gemm_bf16": ([C.POINTER(GemmDesc), _vp], C.c_int),
     "seer_gemm_workspace_bytes": ([C.POINTER(GemmDesc)], C.c_int64),
     "seer_gemm_colsum_rows": ([C.POINTER(GemmDesc)], C.c_int32),
+    "seer_gemm_sync_bytes": ([C.POINTER(GemmDesc)], C.c_int64),
     "seer_attn_fwd": ([C.POINTER(AttnDesc), _vp], C.c_int),
     "seer_rotary_table": ([_vp, _i32, _i32, _vp, _vp], C.c_int),
     "seer_rotary_inplace": ([_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp], C.c_int),

@@ -52,6 +52,10 @@ extern "C" long long* seer_lab_block_span() {
 bool seer_gemm_ws_eligible(const seer_gemm_desc& d);             // gemm_ws.hip: weight-stationary persistent kernel (short K)
 bool seer_gemm_ws_profitable(const seer_gemm_desc& d);
 int seer_gemm_ws_launch(const seer_gemm_desc& d, hipStream_t st);
+bool seer_gemm_t320_eligible(const seer_gemm_desc& d);           // gemm_t320.hip: 256 x 320 tile, in-launch split-K
+int64_t seer_gemm_t320_workspace_bytes(const seer_gemm_desc& d, int splits);
+int64_t seer_gemm_t320_sync_bytes(const seer_gemm_desc& d, int splits);
+int seer_gemm_t320_launch(const seer_gemm_desc& d, int splits, hipStream_t st);
 
 namespace {
 
@@ -1261,6 +1265,25 @@ int resolve_tile(const seer_gemm_desc& d) {
     return tile;
 }
 
+// The 256 x 320 tile kernel (gemm_t320.hip): 0 = this launch does not go there, else the number of K slices it runs with
+// (reduced inside the launch; needs desc.workspace and desc.sync, without them the launch runs unsplit).
+int t320_plan(const seer_gemm_desc& d) {
+    if (d.tile != SEER_TILE_T256x320) return 0;
+    if (d.mode != SEER_GEMM_PLAIN && d.mode != SEER_GEMM_CONV3X3) return 0;
+    if (!seer_gemm_t320_eligible(d)) return 0;
+    const bool geglu = (d.epilogue & SEER_EPI_GEGLU) != 0;
+    int s = 1;
+    if (!geglu && d.batch <= 1 && d.splits != 1) {
+        const int tiles = ((d.M + 255) / 256) * (d.N / 320), nk = d.K / BK;
+        if (d.splits > 1) s = d.splits;
+        else if (tiles < 200) s = 256 / tiles;
+        if (s > nk / 4) s = nk / 4;                  // a slice keeps at least four K tiles
+        if (s > 16) s = 16;
+        if (s < 1) s = 1;
+    }
+    return s;
+}
+
 template <int BM_, int BN_, int NS_, int WM_ = 2, int WN_ = 2>
 struct TileTag { static constexpr int BM = BM_, BN = BN_, NS = NS_, WM = WM_, WN = WN_; };
 
@@ -1294,6 +1317,8 @@ int dispatch_tile(int tile, F&& f) {
 extern "C" int64_t seer_gemm_workspace_bytes(const seer_gemm_desc* desc) {
     if (!desc) return SEER_EINVAL;
     seer_gemm_desc d = *desc;
+    if (const int s320 = t320_plan(d)) return seer_gemm_t320_workspace_bytes(d, s320);
+    if (d.tile == SEER_TILE_T256x320) d.tile = SEER_TILE_AUTO;
     if (d.tile == SEER_TILE_WS || d.tile == SEER_TILE_AUTO_TILED) d.tile = SEER_TILE_AUTO;
     int s = 1;
     const int rc = prepare(d, &s);
@@ -1301,9 +1326,17 @@ extern "C" int64_t seer_gemm_workspace_bytes(const seer_gemm_desc* desc) {
     return s > 1 ? (int64_t)s * d.M * d.N * (int64_t)sizeof(float) : 0;
 }
 
+extern "C" int64_t seer_gemm_sync_bytes(const seer_gemm_desc* desc) {
+    if (!desc) return SEER_EINVAL;
+    if (const int s320 = t320_plan(*desc)) return seer_gemm_t320_sync_bytes(*desc, s320);
+    return 0;
+}
+
 extern "C" int32_t seer_gemm_colsum_rows(const seer_gemm_desc* desc) {
     if (!desc) return 0;
     seer_gemm_desc d = *desc;
+    if (t320_plan(d)) return ((d.epilogue & SEER_EPI_GEGLU) || !colsum_store_ok(d)) ? 0 : 64;   // four 64-row partials per tile
+    if (d.tile == SEER_TILE_T256x320) d.tile = SEER_TILE_AUTO;
     const int requested = d.tile;
     if (requested == SEER_TILE_WS || requested == SEER_TILE_AUTO_TILED) d.tile = SEER_TILE_AUTO;
     int s = 1;
@@ -1312,7 +1345,7 @@ extern "C" int32_t seer_gemm_colsum_rows(const seer_gemm_desc* desc) {
     if (s > 1 && d.workspace && d.workspace_bytes >= (int64_t)s * d.M * d.N * (int64_t)sizeof(float))
         return d.batch <= 1 ? splitk_cs_rows(d.M) : 0;          // split-K: the reduce pass leaves them
     d.splits = 1;
-    d.tile = desc->tile;
+    d.tile = desc->tile == SEER_TILE_T256x320 ? SEER_TILE_AUTO : desc->tile;
     if (requested == SEER_TILE_WS || requested == SEER_TILE_AUTO_TILED) d.tile = SEER_TILE_AUTO;
     const int rows = dispatch_tile(resolve_tile(d), [&](auto t) {
         using T = decltype(t);
@@ -1325,6 +1358,20 @@ extern "C" int seer_gemm_bf16(const seer_gemm_desc* desc, void* stream) {
     if (!desc) return SEER_EINVAL;
     seer_gemm_desc d = *desc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (int s320 = t320_plan(d)) {
+        int sp = 1;
+        seer_gemm_desc chk = d;
+        chk.tile = SEER_TILE_AUTO;
+        const int rc320 = prepare(chk, &sp);         // the same argument checks as every other launch
+        if (rc320 != SEER_OK) return rc320;
+        d.K1 = chk.K1; d.lda2 = chk.lda2; d.batch = chk.batch; d.strideA = chk.strideA; d.strideW = chk.strideW; d.strideC = chk.strideC;
+        if (d.colsum && ((d.epilogue & SEER_EPI_GEGLU) || !colsum_store_ok(d))) return SEER_EINVAL;
+        if (s320 > 1 && (!d.workspace || d.workspace_bytes < seer_gemm_t320_workspace_bytes(d, s320) || !d.sync ||
+                         d.sync_bytes < seer_gemm_t320_sync_bytes(d, s320)))
+            s320 = 1;
+        return seer_gemm_t320_launch(d, s320, st);
+    }
+    if (d.tile == SEER_TILE_T256x320) d.tile = SEER_TILE_AUTO;      // not eligible: the tile kernels take it
     const int requested = d.tile;       // WS / AUTO_TILED are AUTO as far as tile and split-K selection go
     if (requested == SEER_TILE_WS || requested == SEER_TILE_AUTO_TILED) d.tile = SEER_TILE_AUTO;
     int s = 1;
@@ -1335,7 +1382,7 @@ extern "C" int seer_gemm_bf16(const seer_gemm_desc* desc, void* stream) {
         return launch_split(d, st);
     }
     d.splits = 1;
-    d.tile = desc->tile;            // prepare() may have picked a split tile; unsplit launches choose their own below
+    d.tile = desc->tile == SEER_TILE_T256x320 ? SEER_TILE_AUTO : desc->tile;            // prepare() may have picked a split tile; unsplit launches choose their own below
     if (!d.colsum && seer_gemm_ws_eligible(d) &&
         (requested == SEER_TILE_WS || (requested == SEER_TILE_AUTO && seer_gemm_ws_profitable(d)))) {
         const int rc_ws = seer_gemm_ws_launch(d, st);

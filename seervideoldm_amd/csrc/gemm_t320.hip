@@ -1,0 +1,662 @@
+// 256 x 320 x 64 tile GEMM / implicit-GEMM conv for gfx950: one 512-thread workgroup per CU, in-launch split-K reduction.
+//
+// Why this tile.  A CU fills LDS from L2 / MALL at ~70 GB/s whatever issues the loads (profiles/r02_lab_fill.log: one block
+// alone 74 GB/s, 256 blocks 68, 3x3 gathers ~51), so a tile's FLOPs per filled byte bound its rate: 128 x 128 -> 64 FLOP/B ->
+// ~1.1 PF, measured 1.07.  Every N of the denoising network is a multiple of 320 (320 * {1, 2, 3, 4, 6, 8, 12, 16, 32}) and
+// every M of its three upper levels a multiple of 256, so ONE tile shape, 256 x 320 (142 FLOP/B), covers them without a padded
+// column.  8 waves as 4 (M) x 2 (N), 64 x 160 wave tiles = 160 accumulator registers, v_mfma_f32_16x16x32_bf16 issued swapped
+// (a lane holds 4 consecutive output columns of one row, as in gemm.hip).
+//
+// Main loop = the 8-phase ping-pong schedule of gemm.hip's 256 x 256 tile (cdna_hip_programming.md, "256^2 8-phase template")
+// re-derived for this wave grid: a K tile is four LDS regions (A rows of quadrant-row 0 / 1 of every wave row: 16 KB each;
+// W columns of quadrant-column 0 / 1 of both wave columns: 20 KB each), four phases each multiply one 32 x 80 quadrant of the
+// wave tile (20 MFMAs) in the order (r0,c0) (r1,c0) (r1,c1) (r0,c1) so that the 40-register W fragments are read twice and the
+// 16-register A fragments three times per K tile; every region is restaged for K tile u + 2 one phase after its last read;
+// waves 4..7 run one barrier behind waves 0..3 (each SIMD hosts one wave of either half: one multiplies while the other reads
+// LDS and issues LDS-DMA); one counted s_waitcnt vmcnt(8) per K tile, never 0 inside the loop.
+//
+// Split-K without a second launch (seer_gemm_desc::sync).  Few-tile, long-K problems (every conv below the 32x32 level, the
+// feed-forward output projections) need K slices to occupy 256 CUs; the two-launch form pays a reduce kernel that re-reads
+// splits x M x N floats.  Here slice s of a tile writes its raw accumulators to workspace in REGISTER order (each store
+// instruction = 1 KB contiguous, write-through), arrives on the tile's counter, waits for its S - 1 peers (all resident: the
+// grid is at most one round of CUs, peers have adjacent block ids), then reduces ITS share of the accumulator quads over all
+// S slabs in slice order (deterministic, bit-identical from launch to launch), runs the epilogue on that share and stores it.
+// The hand-off follows MI355X_MICROARCH.md "Valid forms", table row 3: sc1 stores of whole 128-B lines, every storing wave's
+// s_waitcnt vmcnt(0), workgroup barrier, one lane's agent-scope atomic add; consumer: one lane polls with sc1 loads, workgroup
+// barrier, then sc1 loads only.  The last slice to finish reading resets both counters: `sync` stays zero between launches.
+#include "seer_common.h"
+#include <mutex>
+
+#ifndef SEER_T320_PROBE
+#define SEER_T320_PROBE 0      // measurement builds (results wrong): 1 = no LDS-DMA in the loop, 2 = no fragment reads, 4 = no MFMA
+#endif
+
+namespace {
+
+constexpr int BM = 256, BN = 320, BK = 64, NT = 512;
+constexpr int A_HALF = 128 * BK;                       // elements (16 KB)
+constexpr int B_HALF = 160 * BK;                       // elements (20 KB)
+constexpr int BUF = 2 * A_HALF + 2 * B_HALF;           // one K tile: [A r0 | A r1 | W c0 | W c1] = 72 KB
+constexpr int LDS_BYTES = 2 * BUF * 2 + 1024;          // two K tiles + 1 KB that absorbs the padding LDS-DMA pieces
+constexpr int NQ = 40;                                 // accumulator quads (f32x4) per lane: 4 row fragments x 10 column fragments
+constexpr int SMAX = 16;                               // K slices per tile, at most
+constexpr int QMAX = 20;                               // quads of one slice's share (S >= 2)
+
+__device__ __attribute__((aligned(16))) unsigned int seer_t320_zero_page[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ void lds_dma16(const void* src, void* dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+}
+
+template <bool CONV, bool GEGLU, bool SPLIT>
+__global__ void __launch_bounds__(NT) seer_gemm_t320_kernel(const seer_gemm_desc p) {
+    static_assert(!(GEGLU && (CONV || SPLIT)), "GEGLU: plain unsplit launches only");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16* const smem_b = reinterpret_cast<bf16*>(smem);
+    bf16* const dummy = smem_b + 2 * BUF;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int grp = wave >> 2;                         // 1: runs one barrier behind
+    const int frow = lane & 15, fq = lane >> 4;
+
+    // ---- block -> (tile, slice): slices of a tile have adjacent block ids (dispatched together); tiles in XCD-contiguous
+    // chunks grouped along M like gemm.hip (blocks b and b + 8 share an XCD)
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int tiles_n = p.N / BN;
+    const int S = SPLIT ? p.splits : 1;
+    int tile, slice;
+    if constexpr (SPLIT) {
+        tile = blockIdx.x / S;
+        slice = blockIdx.x - tile * S;
+    } else {
+        const int nwg = tiles_m * tiles_n;
+        const int L = blockIdx.x, xcd = L & 7, q = nwg >> 3, r = nwg & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+        slice = 0;
+    }
+    constexpr int GM = 8;
+    const int group = tile / (GM * tiles_n);
+    const int first_m = group * GM;
+    const int gsz = min(tiles_m - first_m, GM);
+    const int tm = first_m + (tile % (GM * tiles_n)) % gsz;
+    const int tn = (tile % (GM * tiles_n)) / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int z = SPLIT ? 0 : blockIdx.z;
+    const bf16* __restrict__ A = reinterpret_cast<const bf16*>(p.A) + (int64_t)z * p.strideA;
+    const bf16* __restrict__ A2 = reinterpret_cast<const bf16*>(p.A2);
+    const bf16* __restrict__ W = reinterpret_cast<const bf16*>(p.W) + (int64_t)z * p.strideW;
+
+    // ---- staging descriptors.  One LDS-DMA piece = 8 rows x 128 B; lane -> (row lane >> 3, 16-B slot lane & 7), the XOR swizzle
+    // goes on the SOURCE chunk.  A region rr: local row lr = 32 wm' + i <-> tile row 64 wm' + 32 rr + i; this wave stages local
+    // rows 16 wave + 8 c + (lane >> 3), c = 0, 1.  W region cc: local row lc = 80 wn' + j <-> tile column 160 wn' + 80 cc + j;
+    // this wave stages pieces wave, wave + 8, wave + 16 (the last only for wave < 4: 20 pieces per region).
+    const int schunk = ((lane & 7) ^ (lane >> 3)) * 8;
+    int a_row[4];                                      // [rr * 2 + c]: tile row of this lane's piece row (clamped to M)
+    int a_img[4], a_yx[4];                             // conv: image base offset (elements); packed (iy0 + 4) << 16 | (ix0 + 4)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int lr = 16 * wave + 8 * (c & 1) + (lane >> 3);
+        int gm = m0 + (lr >> 5) * 64 + (c >> 1) * 32 + (lr & 31);
+        gm = gm < p.M ? gm : p.M - 1;
+        a_row[c] = gm - m0;
+        if constexpr (CONV) {
+            const bool phase_mode = p.upsample == 2;
+            const int gw = phase_mode ? p.Win : p.Wout;
+            const int hw = phase_mode ? p.Hin * p.Win : p.Hout * p.Wout;
+            const int img = gm / hw;
+            const int rem = gm - img * hw;
+            const int oy = rem / gw, ox = rem - oy * gw;
+            const int pad0 = p.pad_after_only ? 0 : 1;
+            const int iy0 = phase_mode ? oy + ((int)blockIdx.z >> 1) - 1 : oy * p.stride - pad0;
+            const int ix0 = phase_mode ? ox + ((int)blockIdx.z & 1) - 1 : ox * p.stride - pad0;
+            a_img[c] = img * p.Hin * p.Win * p.Cin;
+            a_yx[c] = ((iy0 + 4) << 16) | (ix0 + 4);
+        }
+    }
+    int b_rel[6];                                      // [cc * 3 + t]: (tile column) * K, elements
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const int pc = wave + 8 * (c % 3);
+        const int lc = 8 * pc + (lane >> 3);
+        const int col = (lc / 80) * 160 + (c / 3) * 80 + (lc % 80);
+        b_rel[c] = pc < 20 ? col * p.K : 0;          // (the padding piece re-reads column 0 into the spare 1 KB)
+    }
+    const unsigned cin_magic = CONV ? 0xFFFFFFFFu / (unsigned)p.Cin + 1u : 0u;   // tap = umulhi(kbase, magic): exact for kbase * Cin < 2^32
+
+    const int nk_all = p.K / BK;
+    const int kt0 = SPLIT ? (int)((int64_t)nk_all * slice / S) : 0;
+    const int T = (SPLIT ? (int)((int64_t)nk_all * (slice + 1) / S) : nk_all) - kt0;
+
+    auto stage_a = [&](int u, int rr) {
+        if (u >= T) return;
+#if !(SEER_T320_PROBE & 1)
+        const int kbase = (kt0 + u) * BK;
+        bf16* dst = smem_b + (u & 1) * BUF + rr * A_HALF + (16 * wave) * BK;
+        if constexpr (CONV) {
+            const int tap = (int)__umulhi((unsigned)kbase, cin_magic);
+            const int ci0 = kbase - tap * p.Cin;
+            const int ksz = p.upsample == 2 ? 2 : 3;
+            const int ky = tap / ksz, kx = tap - ky * ksz;
+            const int Hs = p.upsample == 1 ? p.Hin * 2 : p.Hin;
+            const int Ws = p.upsample == 1 ? p.Win * 2 : p.Win;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int iy = (a_yx[rr * 2 + c] >> 16) - 4 + ky, ix = (a_yx[rr * 2 + c] & 0xffff) - 4 + kx;
+                const bool ok = (iy >= 0) & (iy < Hs) & (ix >= 0) & (ix < Ws);
+                const int sy = p.upsample == 1 ? (iy >> 1) : iy;
+                const int sx = p.upsample == 1 ? (ix >> 1) : ix;
+                const bf16* src = ok ? (A + a_img[rr * 2 + c] + (sy * p.Win + sx) * p.Cin + ci0 + schunk)
+                                     : reinterpret_cast<const bf16*>(seer_t320_zero_page);
+                lds_dma16(src, dst + 8 * c * BK);
+            }
+        } else {
+            const bool second = kbase >= p.K1;
+            const unsigned char* base = second ? reinterpret_cast<const unsigned char*>(A2 + (int64_t)m0 * p.lda2 + (kbase - p.K1))
+                                               : reinterpret_cast<const unsigned char*>(A + (int64_t)m0 * p.lda + kbase);
+            const int ld = second ? p.lda2 : p.lda;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const unsigned voff = (unsigned)(a_row[rr * 2 + c] * ld + schunk) * 2u;
+                lds_dma16(base + voff, dst + 8 * c * BK);
+            }
+        }
+#endif
+    };
+    auto stage_b = [&](int u, int cc) {
+        if (u >= T) return;
+#if !(SEER_T320_PROBE & 1)
+        const int kbase = (kt0 + u) * BK;
+        bf16* dst = smem_b + (u & 1) * BUF + 2 * A_HALF + cc * B_HALF + (8 * wave) * BK;
+        const unsigned char* wbase = reinterpret_cast<const unsigned char*>(W + (int64_t)n0 * p.K + kbase);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const unsigned voff = (unsigned)(b_rel[cc * 3 + t] + schunk) * 2u;
+            lds_dma16(wbase + voff, dst + 64 * t * BK);
+        }
+        {   // third piece: waves 4..7 have none -- theirs lands in the spare 1 KB, so that every wave counts 3 per W region
+            const unsigned voff = (unsigned)(b_rel[cc * 3 + 2] + schunk) * 2u;
+            lds_dma16(wbase + voff, wave < 4 ? dst + 128 * BK : dummy);
+        }
+#endif
+    };
+
+    bf16x8 fa[2][2], fb[2][5];
+    auto read_a = [&](int u, int rr) {
+#if !(SEER_T320_PROBE & 2)
+        const bf16* as = smem_b + (u & 1) * BUF + rr * A_HALF + (wm * 32) * BK;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int sw = (((ks * 4 + fq) ^ (frow & 7)) * 8);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8*>(as + (i * 16 + frow) * BK + sw);
+        }
+#endif
+    };
+    auto read_b = [&](int u, int cc) {
+#if !(SEER_T320_PROBE & 2)
+        const bf16* bs = smem_b + (u & 1) * BUF + 2 * A_HALF + cc * B_HALF + (wn * 80) * BK;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int sw = (((ks * 4 + fq) ^ (frow & 7)) * 8);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) fb[ks][j] = *reinterpret_cast<const bf16x8*>(bs + (j * 16 + frow) * BK + sw);
+        }
+#endif
+    };
+    auto barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    f32x4 acc[4][10];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 10; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#if SEER_T320_PROBE & 4
+#define SEER_T320_MFMA(R, C)                                                                                                 \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                                   \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(fa[ks][i]));                                 \
+            _Pragma("unroll") for (int j = 0; j < 5; ++j) asm volatile("" ::"v"(fb[ks][j]));                                 \
+        }
+#else
+#define SEER_T320_MFMA(R, C)                                                                                                 \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                     \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                    \
+                _Pragma("unroll") for (int j = 0; j < 5; ++j)                                                                \
+                    acc[2 * (R) + i][5 * (C) + j] =                                                                          \
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[2 * (R) + i][5 * (C) + j], 0, 0, 0);
+#endif
+#define SEER_T320_MMA(R, C)                                                                                                  \
+        do {                                                                                                                 \
+            barrier();                                                                                                       \
+            __builtin_amdgcn_s_setprio(1);                                                                                   \
+            SEER_T320_MFMA(R, C)                                                                                             \
+            __builtin_amdgcn_s_setprio(0);                                                                                   \
+            barrier();                                                                                                       \
+        } while (0)
+
+    // prologue: K tile 0 whole (10 pieces per wave), K tile 1 except its A r0 (8 pieces; A r0 goes out in phase 0 of tile 0)
+    stage_b(0, 0); stage_a(0, 0); stage_a(0, 1); stage_b(0, 1);
+    stage_b(1, 0); stage_a(1, 1); stage_b(1, 1);
+    if (T > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    barrier();
+    if (grp == 1) barrier();                           // waves 4..7 run one barrier behind from here on
+    for (int u = 0; u < T; ++u) {
+        // phase 0: quadrant (r0, c0)
+        read_b(u, 0);
+        read_a(u, 0);
+        stage_a(u + 1, 0);                             // its buffer's A r0 was last read in phase 3 of tile u - 1
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SEER_T320_MMA(0, 0);
+        // phase 1: (r1, c0); W c0 stays in registers
+        read_a(u, 1);
+        stage_b(u + 2, 0);                             // W c0 of this buffer: last read in phase 0
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SEER_T320_MMA(1, 0);
+        // phase 2: (r1, c1); A r1 stays
+        read_b(u, 1);
+        stage_a(u + 2, 1);                             // A r1: last read in phase 1
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SEER_T320_MMA(1, 1);
+        // phase 3: (r0, c1); W c1 stays.  The wait retires K tile u + 1 (everything but the 8 pieces of tile u + 2 issued in
+        // phases 1..3); its first read is in phase 0 of the next iteration, two barriers later.
+        read_a(u, 0);
+        stage_b(u + 2, 1);                             // W c1: last read in phase 2
+        if (u + 2 < T) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SEER_T320_MMA(0, 1);
+    }
+#undef SEER_T320_MMA
+#undef SEER_T320_MFMA
+    if (grp == 0) barrier();                           // re-align the two halves: every wave is done with the K-loop LDS
+
+    // =========================================================================================================================
+    // epilogue.  acc[i][j][r] = C[m0 + 64 wm + 16 i + frow][n0 + 160 wn + 16 j + 4 fq + r]
+    // =========================================================================================================================
+    bf16* Cb = reinterpret_cast<bf16*>(p.C) + (int64_t)z * p.strideC;
+    const bf16* R = reinterpret_cast<const bf16*>(p.residual);
+    const bool do_rot = (p.epilogue & SEER_EPI_ROTARY) != 0;
+    const bool do_cs = (p.epilogue & SEER_EPI_COLSCALE) != 0;
+    auto crow = [&](int m) -> int64_t {               // output row of GEMM row m (the phase convs scatter their rows)
+        if constexpr (CONV) {
+            if (p.upsample == 2) {
+                const int hw = p.Hin * p.Win;
+                const int img = m / hw, rem = m - img * hw;
+                const int y = rem / p.Win, x = rem - y * p.Win;
+                return ((int64_t)img * p.Hout + 2 * y + ((int)blockIdx.z >> 1)) * p.Wout + 2 * x + ((int)blockIdx.z & 1);
+            }
+        }
+        return m;
+    };
+    constexpr int BNO = GEGLU ? BN / 2 : BN;            // output columns of the tile
+    constexpr int CPITCH = BNO * 2 + 16;                // staged row pitch (bytes)
+    constexpr int PASS_ROWS = GEGLU ? 256 : 128;        // rows staged per pass (128 x 656 B = 82 KB; GEGLU: 256 x 336 B = 84 KB)
+    constexpr int NPASS = BM / PASS_ROWS;
+    constexpr int CPR = BNO / 8;                        // 16-byte chunks per staged row
+
+    // the quads this block finishes: all of them, or (split) its share [q0, q1) of q = 10 i + j, reduced over the S slabs
+    int q0 = 0, q1 = NQ;
+    f32x4 mine[SPLIT ? QMAX : 1];
+    if constexpr (SPLIT) {
+        q0 = NQ * slice / S;
+        q1 = NQ * (slice + 1) / S;
+        // ---- publish: raw accumulators in register order, [tile][slice][wave][q][lane] x 16 B, write-through
+        float* slabs = reinterpret_cast<float*>(p.workspace) + (int64_t)tile * S * (8 * NQ * 64 * 4);
+        {
+            float* my = slabs + (int64_t)slice * (8 * NQ * 64 * 4) + (wave * NQ * 64 + lane) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 10; ++j) store16_out(my + (i * 10 + j) * 256, __builtin_bit_cast(u32x4, acc[i][j]));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned int* cnt = reinterpret_cast<unsigned int*>(p.sync) + 2 * tile;
+        if (tid == 0) {
+            __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int spins = 0;
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)S && ++spins < (1 << 24))
+                __builtin_amdgcn_s_sleep(4);
+        }
+        __syncthreads();
+        // ---- reduce my share in slice order: sc1 loads only (the lines were written through by other CUs)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slabs, 0, S * (8 * NQ * 64 * 16), 0x00020000);
+        const int nq = q1 - q0;
+#pragma unroll
+        for (int k = 0; k < QMAX; ++k) {
+            if (k < nq) {
+                const int off = ((wave * NQ + q0 + k) * 64 + lane) * 16;
+                u32x4 v[SMAX];
+#pragma unroll
+                for (int sp = 0; sp < SMAX; ++sp)
+                    if (sp < S) v[sp] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, sp * (8 * NQ * 64 * 16), 16);
+                f32x4 sum = __builtin_bit_cast(f32x4, v[0]);
+#pragma unroll
+                for (int sp = 1; sp < SMAX; ++sp)
+                    if (sp < S) sum += __builtin_bit_cast(f32x4, v[sp]);
+                mine[k] = sum;
+            }
+        }
+        __syncthreads();                                // every wave holds its sums: this block no longer reads the slabs
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == (unsigned)S - 1u) {              // last reader of the tile: leave the counters as the next launch expects them
+                __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+
+    // ---- epilogue terms on one quad: v = the four values of row m (tile-relative row mt), GEMM columns n .. n + 3
+    auto finish_quad = [&](f32x4 v, int m, int n) -> f32x4 {
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (p.rowvec) {
+            const int mc = m < p.M ? m : p.M - 1;
+            v += *reinterpret_cast<const f32x4*>(p.rowvec + (int64_t)(mc / p.rows_per_batch) * p.rowvec_ld + n);
+        }
+        if (do_rot && n < p.rot_cols) {
+            const int ch = n % p.rot_head_dim;
+            if (ch < p.rot_dim) {
+                const int pos = m % p.rot_tokens_per_batch + p.rot_pos_offset;
+                const f32x4 cs = *reinterpret_cast<const f32x4*>(p.rot_table + ((int64_t)pos * (p.rot_dim / 2) + ch / 2) * 2);
+                const f32x2 r01 = rot_pair(f32x2{v[0], v[1]}, cs[0], cs[1]);
+                const f32x2 r23 = rot_pair(f32x2{v[2], v[3]}, cs[2], cs[3]);
+                v = f32x4{r01[0], r01[1], r23[0], r23[1]};
+            }
+        }
+        if (do_cs && n < p.col_scale_cols) v *= p.col_scale;
+        if (R) {
+            const int mc = m < p.M ? m : p.M - 1;
+            const u32x2 rv = *reinterpret_cast<const u32x2*>(R + (int64_t)mc * p.ldr + n);
+            v[0] += __builtin_bit_cast(float, rv[0] << 16);
+            v[1] += __builtin_bit_cast(float, rv[0] & 0xffff0000u);
+            v[2] += __builtin_bit_cast(float, rv[1] << 16);
+            v[3] += __builtin_bit_cast(float, rv[1] & 0xffff0000u);
+        }
+        return v;
+    };
+
+    if constexpr (!SPLIT) {
+        // unsplit: one pass per term over the register tile (the order of additions of gemm.hip: bias, GEGLU, row vector, rotary,
+        // column scale, residual)
+        if (p.bias) {
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * 160 + j * 16 + fq * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] += bv;
+            }
+        }
+        if constexpr (GEGLU) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < 10; j += 2) {
+                    const f32x4 g = acc[i][j + 1];
+                    const f32x2 ge0 = gelu_erf_f2(f32x2{g[0], g[1]}), ge1 = gelu_erf_f2(f32x2{g[2], g[3]});
+                    acc[i][j][0] *= ge0[0]; acc[i][j][1] *= ge0[1]; acc[i][j][2] *= ge1[0]; acc[i][j][3] *= ge1[1];
+                }
+                __builtin_amdgcn_sched_barrier(0);      // one fragment row of erf temporaries at a time
+            }
+        }
+        if (p.rowvec) {
+            // GEGLU: the row vector is indexed by OUTPUT column
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int m = m0 + wm * 64 + i * 16 + frow;
+                m = m < p.M ? m : p.M - 1;
+                const float* rv = p.rowvec + (int64_t)(m / p.rows_per_batch) * p.rowvec_ld;
+#pragma unroll
+                for (int j = 0; j < 10; j += (GEGLU ? 2 : 1)) {
+                    const int n = n0 + wn * 160 + j * 16 + fq * 4;
+                    const int nc = GEGLU ? ((n - fq * 4) >> 1) + fq * 4 : n;
+                    acc[i][j] += *reinterpret_cast<const f32x4*>(rv + nc);
+                }
+            }
+        }
+        if constexpr (!GEGLU) {
+            if (do_rot && n0 + wn * 160 < p.rot_cols) {
+                int tj[10];
+#pragma unroll
+                for (int j = 0; j < 10; ++j) {
+                    const int n = n0 + wn * 160 + j * 16 + fq * 4;
+                    const int ch = n % p.rot_head_dim;
+                    tj[j] = (n < p.rot_cols && ch < p.rot_dim) ? (ch / 2) * 2 : -1;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = m0 + wm * 64 + i * 16 + frow;
+                    const int pos = m % p.rot_tokens_per_batch + p.rot_pos_offset;
+                    const float* trow = p.rot_table + (int64_t)pos * (p.rot_dim / 2) * 2;
+#pragma unroll
+                    for (int j = 0; j < 10; ++j) {
+                        if (tj[j] >= 0) {
+                            const f32x4 cs = *reinterpret_cast<const f32x4*>(trow + tj[j]);
+                            const f32x2 r01 = rot_pair(f32x2{acc[i][j][0], acc[i][j][1]}, cs[0], cs[1]);
+                            const f32x2 r23 = rot_pair(f32x2{acc[i][j][2], acc[i][j][3]}, cs[2], cs[3]);
+                            acc[i][j] = f32x4{r01[0], r01[1], r23[0], r23[1]};
+                        }
+                    }
+                }
+            }
+            if (do_cs) {
+#pragma unroll
+                for (int j = 0; j < 10; ++j) {
+                    const float sc = (n0 + wn * 160 + j * 16 + fq * 4) < p.col_scale_cols ? p.col_scale : 1.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i][j] *= sc;
+                }
+            }
+        }
+        if (R) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int m = m0 + wm * 64 + i * 16 + frow;
+                m = m < p.M ? m : p.M - 1;
+                const bf16* rrow = R + (int64_t)m * p.ldr;
+                u32x2 rv[10];
+#pragma unroll
+                for (int j = 0; j < 10; j += (GEGLU ? 2 : 1)) {
+                    const int n = n0 + wn * 160 + j * 16 + fq * 4;
+                    const int nc = GEGLU ? ((n - fq * 4) >> 1) + fq * 4 : n;
+                    rv[j] = *reinterpret_cast<const u32x2*>(rrow + nc);
+                }
+#pragma unroll
+                for (int j = 0; j < 10; j += (GEGLU ? 2 : 1)) {
+                    acc[i][j][0] += __builtin_bit_cast(float, rv[j][0] << 16);
+                    acc[i][j][1] += __builtin_bit_cast(float, rv[j][0] & 0xffff0000u);
+                    acc[i][j][2] += __builtin_bit_cast(float, rv[j][1] << 16);
+                    acc[i][j][3] += __builtin_bit_cast(float, rv[j][1] & 0xffff0000u);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < QMAX; ++k) {
+            if (k < q1 - q0) {
+                const int q = q0 + k, i = q / 10, j = q - i * 10;
+                mine[k] = finish_quad(mine[k], m0 + wm * 64 + i * 16 + frow, n0 + wn * 160 + j * 16 + fq * 4);
+            }
+        }
+    }
+
+    // ---- bf16 rows leave through the (now idle) K-loop LDS: 16 B per lane along whole output rows.  Column sums of the tile
+    // as stored, per 64-row partial (row fragment i of the four wave rows): colsum[z][4 tile_m + i][N][2].
+    const bool wt_store = p.K <= 3072;
+    const int n0o = GEGLU ? (n0 >> 1) : n0;
+    float cs_s[2] = {0.f, 0.f}, cs_q[2] = {0.f, 0.f}, cs_s2[2] = {0.f, 0.f}, cs_q2[2] = {0.f, 0.f};
+    const int cs_cp = tid % 160, cs_i = tid / 160;      // column pair, row fragment (threads 480..511: none); fragment 3: threads < 160
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        if (ps > 0) __syncthreads();                    // the previous pass has been copied out
+        if constexpr (!SPLIT) {
+            if (GEGLU || (wm >> 1) == ps) {
+                const int rowb = ((GEGLU ? wm * 64 : (wm & 1) * 64) + frow) * CPITCH;
+#pragma unroll
+                for (int j = 0; j < 10; j += (GEGLU ? 2 : 1)) {
+                    const int cb = GEGLU ? (wn * 80 + (j >> 1) * 16 + fq * 4) * 2 : (wn * 160 + j * 16 + fq * 4) * 2;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        u32x2 o;
+                        o[0] = pack2(acc[i][j][0], acc[i][j][1]);
+                        o[1] = pack2(acc[i][j][2], acc[i][j][3]);
+                        *reinterpret_cast<u32x2*>(smem + rowb + i * 16 * CPITCH + cb) = o;
+                    }
+                }
+            }
+        } else {
+            if ((wm >> 1) == ps) {
+#pragma unroll
+                for (int k = 0; k < QMAX; ++k) {
+                    if (k < q1 - q0) {
+                        const int q = q0 + k, i = q / 10, j = q - i * 10;
+                        u32x2 o;
+                        o[0] = pack2(mine[k][0], mine[k][1]);
+                        o[1] = pack2(mine[k][2], mine[k][3]);
+                        *reinterpret_cast<u32x2*>(smem + ((wm & 1) * 64 + i * 16 + frow) * CPITCH + (wn * 160 + j * 16 + fq * 4) * 2) = o;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if constexpr (!GEGLU) {
+            if (p.colsum && cs_i < 3) {
+                // rows of fragment cs_i in this pass: 64 w + 16 cs_i + r for the two wave rows w of the pass
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int fi = e == 0 ? cs_i : 3;
+                    if (e == 1 && cs_i != 0) break;
+                    const int qq = fi * 10 + (cs_cp % 80) / 8;
+                    if (SPLIT && (qq < q0 || qq >= q1)) continue;
+                    float s0 = 0.f, s1 = 0.f, t0 = 0.f, t1 = 0.f;
+                    for (int w = 0; w < 2; ++w) {
+                        const int mrow = m0 + ps * 128 + w * 64 + fi * 16;
+#pragma unroll 4
+                        for (int r = 0; r < 16; ++r) {
+                            if (mrow + r < p.M) {
+                                const uint32_t v = *reinterpret_cast<const uint32_t*>(smem + (w * 64 + fi * 16 + r) * CPITCH + cs_cp * 4);
+                                const float f0 = __builtin_bit_cast(float, v << 16), f1 = __builtin_bit_cast(float, v & 0xffff0000u);
+                                s0 += f0; t0 += f0 * f0;
+                                s1 += f1; t1 += f1 * f1;
+                            }
+                        }
+                    }
+                    if (e == 0) { cs_s[0] += s0; cs_s[1] += s1; cs_q[0] += t0; cs_q[1] += t1; }
+                    else { cs_s2[0] += s0; cs_s2[1] += s1; cs_q2[0] += t0; cs_q2[1] += t1; }
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < (PASS_ROWS * CPR + NT - 1) / NT; ++it) {
+            const int c = tid + it * NT;
+            const int row = c / CPR, ch = c - row * CPR;
+            const int trow = ps * PASS_ROWS + row;
+            const int m = m0 + trow;
+            bool on = ((PASS_ROWS * CPR) % NT == 0 || c < PASS_ROWS * CPR) && m < p.M;
+            if constexpr (SPLIT) {
+                const int qq = ((trow >> 4) & 3) * 10 + (ch % 20) / 2;      // quad of this chunk: fragment row, fragment column
+                on = on && qq >= q0 && qq < q1;
+            }
+            if (on) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * CPITCH + ch * 16);
+                bf16* dst = Cb + crow(m) * p.ldc + n0o + ch * 8;
+                if (wt_store) store16_out(dst, v);
+                else *reinterpret_cast<u32x4*>(dst) = v;
+            }
+        }
+    }
+    if constexpr (!GEGLU) {
+        if (p.colsum && cs_i < 3) {
+            const int64_t part0 = ((int64_t)blockIdx.z * (SPLIT ? 0 : 1) * tiles_m + tm) * 4;
+            const int col = n0 + cs_cp * 2;
+            {
+                const int qq = cs_i * 10 + (cs_cp % 80) / 8;
+                if (!SPLIT || (qq >= q0 && qq < q1))
+                    *reinterpret_cast<f32x4*>(p.colsum + ((part0 + cs_i) * p.N + col) * 2) = f32x4{cs_s[0], cs_q[0], cs_s[1], cs_q[1]};
+            }
+            if (cs_i == 0) {
+                const int qq = 30 + (cs_cp % 80) / 8;
+                if (!SPLIT || (qq >= q0 && qq < q1))
+                    *reinterpret_cast<f32x4*>(p.colsum + ((part0 + 3) * p.N + col) * 2) = f32x4{cs_s2[0], cs_q2[0], cs_s2[1], cs_q2[1]};
+            }
+        }
+    }
+}
+
+std::once_flag g_t320_once;
+
+}  // namespace
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------
+// what the kernel handles (gemm.hip decides WHEN to use it)
+bool seer_gemm_t320_eligible(const seer_gemm_desc& d) {
+    if (d.N % 320 || d.K % 64 || d.M < 1) return false;
+    if (d.epilogue & (SEER_EPI_OUT_F32 | SEER_EPI_TRANS_OUT | SEER_EPI_SILU)) return false;
+    const bool geglu = (d.epilogue & SEER_EPI_GEGLU) != 0;
+    if (geglu && (d.mode == SEER_GEMM_CONV3X3 || (d.epilogue & (SEER_EPI_ROTARY | SEER_EPI_COLSCALE)))) return false;
+    if (d.ldc % 8 || (reinterpret_cast<uintptr_t>(d.C) & 15)) return false;
+    if (d.batch > 1 && (d.strideC % 8)) return false;
+    if (d.residual && (d.ldr % 4)) return false;
+    // 32-bit element offsets in the staging path
+    if (d.mode == SEER_GEMM_CONV3X3) {
+        if ((int64_t)d.M * d.Cin >= (1ll << 30) || (int64_t)d.K * d.Cin >= (1ll << 32)) return false;
+        if (d.Hin > 16000 || d.Win > 16000) return false;
+    } else {
+        if ((int64_t)256 * (d.lda > d.lda2 ? d.lda : d.lda2) >= (1ll << 30)) return false;
+    }
+    if ((int64_t)320 * d.K >= (1ll << 30)) return false;
+    return true;
+}
+
+int64_t seer_gemm_t320_workspace_bytes(const seer_gemm_desc& d, int splits) {
+    if (splits <= 1) return 0;
+    const int64_t tiles = (int64_t)((d.M + 255) / 256) * (d.N / 320);
+    return tiles * splits * (int64_t)(8 * NQ * 64 * 16);
+}
+int64_t seer_gemm_t320_sync_bytes(const seer_gemm_desc& d, int splits) {
+    if (splits <= 1) return 0;
+    const int64_t tiles = (int64_t)((d.M + 255) / 256) * (d.N / 320);
+    return tiles * 2 * (int64_t)sizeof(unsigned int);
+}
+
+int seer_gemm_t320_launch(const seer_gemm_desc& d0, int splits, hipStream_t st) {
+    seer_gemm_desc d = d0;
+    std::call_once(g_t320_once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_t320_kernel<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_t320_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_t320_kernel<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_t320_kernel<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_t320_kernel<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    });
+    const bool conv = d.mode == SEER_GEMM_CONV3X3;
+    const bool geglu = (d.epilogue & SEER_EPI_GEGLU) != 0;
+    const int tiles = ((d.M + 255) / 256) * (d.N / 320);
+    const int batch = d.batch > 1 ? d.batch : 1;
+    if (splits > 1) {
+        if (geglu || batch > 1 || splits > SMAX || splits > d.K / 64) return SEER_EINVAL;
+        if (!d.workspace || d.workspace_bytes < seer_gemm_t320_workspace_bytes(d, splits)) return SEER_EINVAL;
+        if (!d.sync || d.sync_bytes < seer_gemm_t320_sync_bytes(d, splits)) return SEER_EINVAL;
+        d.splits = splits;
+        dim3 grid(tiles * splits, 1, 1);
+        if (conv) hipLaunchKernelGGL((seer_gemm_t320_kernel<true, false, true>), grid, dim3(NT), LDS_BYTES, st, d);
+        else hipLaunchKernelGGL((seer_gemm_t320_kernel<false, false, true>), grid, dim3(NT), LDS_BYTES, st, d);
+    } else {
+        d.splits = 1;
+        dim3 grid(tiles, 1, batch);
+        if (conv) hipLaunchKernelGGL((seer_gemm_t320_kernel<true, false, false>), grid, dim3(NT), LDS_BYTES, st, d);
+        else if (geglu) hipLaunchKernelGGL((seer_gemm_t320_kernel<false, true, false>), grid, dim3(NT), LDS_BYTES, st, d);
+        else hipLaunchKernelGGL((seer_gemm_t320_kernel<false, false, false>), grid, dim3(NT), LDS_BYTES, st, d);
+    }
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}

@@ -467,7 +467,8 @@ def _rel_l2(got, ref):
 
 @pytest.mark.parametrize("variant", [1, 2, 3, 5])
 @pytest.mark.parametrize("Sq,Sk,causal", [(1024, 1024, False), (768, 768, True), (1000, 930, False), (333, 333, True),
-                                           (130, 2049, False), (64, 256, False)])
+                                           (130, 2049, False), (64, 256, False),
+                                           (4096, 4096, False)])      # BASELINE config 4: spatial attention of a 64x64 latent
 def test_attention_d40_kernels(device, variant, Sq, Sk, causal):
     """head_dim 40: the generic kernel (variant 1), the d = 40 kernel's fast path (3; 2 = its 64-queries-per-wave shape) and its tracked form (5) against the
     fp32 formula (xformers MEA as called at attention.py:622-630)"""
@@ -567,7 +568,8 @@ def test_gemm_col_scale(device):
         _close(out, ref, what=f"col_scale {M}x{N}x{K}")
 
 
-@pytest.mark.parametrize("d,Fr,H,W,ws", [(40, 4, 32, 32, 8), (80, 12, 16, 16, 4), (160, 3, 8, 8, 4)])
+@pytest.mark.parametrize("d,Fr,H,W,ws", [(40, 4, 32, 32, 8), (80, 12, 16, 16, 4), (160, 3, 8, 8, 4),
+                                         (80, 12, 32, 32, 8)])   # config 4's second level: 768 causal keys per window at d = 80
 def test_window_attention(device, d, Fr, H, W, ws):
     """temporal window attention == window_partition -> causal attention -> window_reverse (attention.py:42-69,661-703)."""
     from seervideoldm_amd import ops

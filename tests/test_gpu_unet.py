@@ -70,6 +70,8 @@ def _model(cfg_name, device):
     ("mini", 2, 3, 32, 0),      # window regimes ws=8 (32), ws=4 (16, 8), un-windowed mid (4)
     ("mini", 1, 4, 16, 2),      # cond_frame > 0: temporal FF skips the conditioning frames
     ("wide", 2, 2, 16, 0),      # head dims 40 / 80 / 160, un-windowed at 4 and 2
+    ("wide", 2, 2, 64, 0),      # BASELINE config 4's regimes: 4096-token spatial attention, ws = 8 at d = 40 and d = 80, the
+                                # windowed 8x8 mid block (ws = 4 at d = 160, attention.py:661-680)
 ])
 def test_unet_forward_matches_oracle(device, cfg_name, B, Fr, H, cond_frame):
     cfg, sd, m = _model(cfg_name, device)
