@@ -179,12 +179,19 @@ def cpu_baseline(sd_cpu, cfg, budget_s):
 class Watchdog:
     """N > 1 only.  A hung collective cannot be caught as an exception (the RCCL watchdog would abort the process, and the driver
     would get no line at all): while a phase with collectives runs, a timer thread on every rank waits; if the phase is still
-    running at the deadline, rank 0 prints the JSON line built from what HAS been measured (`fallback()`), and every rank leaves
-    with exit code 0 (`os._exit`: no destructor waits on the hung stream)."""
+    running at the deadline, rank 0 prints the JSON line built from what HAS been measured (`fallback()`) and every rank leaves
+    with exit code 3 (`os._exit`: no destructor waits on the hung stream) -- the line is there for the driver, the status tells
+    torchrun / CI that the job did not finish.  No in-process retry: a wedged stream is not recoverable; start a fresh process.
+    `disarm()` and the firing timer take the same lock, so a phase that ends at the deadline prints either its own line or the
+    fallback line, never both."""
+
+    EXIT_CODE = 3
 
     def __init__(self, rank: int):
+        import threading
         self.rank = rank
         self._ev = None
+        self._lock = threading.Lock()
 
     def arm(self, seconds: float, fallback) -> None:
         import threading
@@ -192,20 +199,25 @@ class Watchdog:
         self._ev = ev
 
         def run():
-            if not ev.wait(seconds):
+            if ev.wait(seconds):
+                return
+            with self._lock:
+                if ev.is_set():              # disarmed while we were waiting for the lock: the phase finished
+                    return
                 if self.rank == 0:
                     try:
                         print(json.dumps(fallback()), flush=True)
                     finally:
-                        os._exit(0)
-                time.sleep(5.0)          # rank 0 prints first
-                os._exit(0)
+                        os._exit(self.EXIT_CODE)
+                time.sleep(5.0)              # rank 0 prints first
+                os._exit(self.EXIT_CODE)
         threading.Thread(target=run, daemon=True).start()
 
     def disarm(self) -> None:
-        if self._ev is not None:
-            self._ev.set()
-            self._ev = None
+        with self._lock:
+            if self._ev is not None:
+                self._ev.set()
+                self._ev = None
 
 
 def main():

@@ -74,7 +74,7 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     // one pool of random bf16 / fp32 data, big enough for every operand
-    const size_t pool_elems = (size_t)96 << 20;
+    const size_t pool_elems = (size_t)(getenv("LAB_MMUL") ? 288 : 96) << 20;
     std::vector<uint16_t> h(pool_elems);
     uint32_t r = 7u;
     for (size_t i = 0; i < pool_elems; ++i) { r = r * 1664525u + 1013904223u; h[i] = f2bf(((float)(r >> 8) / 8388608.0f - 1.0f) * 0.5f); }
@@ -90,7 +90,7 @@ int main(int argc, char** argv) {
     float* dCs;                                    // column-sum partials (LAB_COLSUM=1)
     CK(hipMalloc(&dCs, (size_t)64 << 20));
     float* dTab;                                   // rotary (cos, sin) table: 12288 positions x 16 pairs
-    CK(hipMalloc(&dTab, (size_t)12288 * 32 * 4)); CK(hipMemset(dTab, 0, (size_t)12288 * 32 * 4));
+    CK(hipMalloc(&dTab, (size_t)4 * 12288 * 32 * 4)); CK(hipMemset(dTab, 0, (size_t)4 * 12288 * 32 * 4));
     CK(hipMemcpy(dA, h.data(), pool_elems * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dW, h.data() + 12345, (pool_elems - 12345) * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(dR, h.data() + 777, (pool_elems - 777) * 2, hipMemcpyHostToDevice)); CK(hipMemset(dB, 0, 65536 * 4));
     printf("seer ABI %d, iters %d, tile override %d\n%-28s %5s %9s %8s %9s\n", seer_abi_version(), iters, tile_override, "shape", "calls", "us/call", "TF/s", "ms/step");
@@ -99,6 +99,8 @@ int main(int argc, char** argv) {
         Shape s = s0;
         // LAB_MDIV=2|4: the same table for one CFG half / one CFG half of half the frames per rank (rows and images divided)
         if (const char* md = getenv("LAB_MDIV")) { const int dv = atoi(md); if (dv > 1) { s.M /= dv; } }
+        // LAB_MMUL=4: BASELINE config 4 (64x64 latent): four times the rows at every level
+        if (const char* mm = getenv("LAB_MMUL")) { if (atoi(mm) == 4) { if (s.conv) s.N *= 2; else s.M *= 4; } }
         if (s.conv && s.up == 1) s.calls = 0;     // the engine runs the phase form of the three upsampler convs
         if (only && !strstr(s.name, only)) continue;
         seer_gemm_desc d;

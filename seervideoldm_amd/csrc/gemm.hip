@@ -1266,21 +1266,69 @@ int resolve_tile(const seer_gemm_desc& d) {
 }
 
 // The 256 x 320 tile kernel (gemm_t320.hip): 0 = this launch does not go there, else the number of K slices it runs with
-// (reduced inside the launch; needs desc.workspace and desc.sync, without them the launch runs unsplit).
-int t320_plan(const seer_gemm_desc& d) {
-    if (d.tile != SEER_TILE_T256x320) return 0;
+// (reduced inside the launch; needs desc.workspace and desc.sync).
+//
+// AUTO takes it where a cost model calibrated on MI355X (profiles/r04_t320_*.log) puts it ahead of the smaller tiles:
+//   t = rounds * (K tiles per slice * 1.9 us [2.0 conv] + 7 us of prologue / epilogue) + slab bytes / 4.3 TB/s + 3 us
+// rounds = ceil(tiles * S / 256 CUs); slab bytes = 2 * tiles * S * 320 KB when S > 1 -- the partial tiles of a split launch go
+// through the fabric (write-through stores, sc1 loads) at HBM-like rates whatever the split, which is what keeps the big tile
+// away from the few-tile shapes of a 32x32-latent step: 256 workgroups x 320 KB x 2 = 164 MB = 38 us per split launch.
+// The smaller tiles are priced at the best rate they reach on these shape classes (0.80-0.95 PFLOP/s): the big tile is only
+// chosen where it beats that optimistic figure.
+double t320_model_us(const seer_gemm_desc& d, int S) {
+    const int nb = (d.mode == SEER_GEMM_CONV3X3 && d.upsample == 2) ? 4 : (d.batch > 1 ? d.batch : 1);
+    const int tiles = ((d.M + 255) / 256) * (d.N / 320) * nb, nk = d.K / BK;
+    const int rounds = (tiles * S + 255) / 256;
+    const double t_iter = d.mode == SEER_GEMM_CONV3X3 ? 2.0 : 1.9;
+    const double slab = S > 1 ? 2.0 * tiles * S * 327680.0 / 4.3e6 : 0.0;
+    return rounds * (((nk + S - 1) / S) * t_iter + 7.0) + slab + 3.0;
+}
+int t320_best_split(const seer_gemm_desc& d, bool can_split, double* t_best) {
+    static const int cand[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
+    const int nk = d.K / BK;
+    int best = 1;
+    double tb = t320_model_us(d, 1);
+    if (can_split)
+        for (int S : cand) {
+            if (S > nk / 4) break;                   // a slice keeps at least four K tiles
+            const double t = t320_model_us(d, S);
+            if (t < tb) { tb = t; best = S; }
+        }
+    if (t_best) *t_best = tb;
+    return best;
+}
+bool t320_buffers_ok(const seer_gemm_desc& d, int s) {
+    return d.workspace && d.workspace_bytes >= seer_gemm_t320_workspace_bytes(d, s) && d.sync &&
+           d.sync_bytes >= seer_gemm_t320_sync_bytes(d, s);
+}
+// assume_buffers: a size query -- plan as if workspace and sync will be provided; the launch plans with what it was given
+int t320_plan(const seer_gemm_desc& d, bool assume_buffers = false) {
+    if (d.tile != SEER_TILE_T256x320 && d.tile != SEER_TILE_AUTO) return 0;
     if (d.mode != SEER_GEMM_PLAIN && d.mode != SEER_GEMM_CONV3X3) return 0;
     if (!seer_gemm_t320_eligible(d)) return 0;
     const bool geglu = (d.epilogue & SEER_EPI_GEGLU) != 0;
-    int s = 1;
-    if (!geglu && d.batch <= 1 && d.splits != 1) {
-        const int tiles = ((d.M + 255) / 256) * (d.N / 320), nk = d.K / BK;
-        if (d.splits > 1) s = d.splits;
-        else if (tiles < 200) s = 256 / tiles;
-        if (s > nk / 4) s = nk / 4;                  // a slice keeps at least four K tiles
-        if (s > 16) s = 16;
-        if (s < 1) s = 1;
+    const bool phases = d.mode == SEER_GEMM_CONV3X3 && d.upsample == 2;
+    const bool can_split = !geglu && d.batch <= 1 && !phases && d.splits != 1;
+    if (d.tile == SEER_TILE_T256x320) {
+        int s = 1;
+        if (can_split) {
+            const int nk = d.K / BK;
+            s = d.splits > 1 ? d.splits : t320_best_split(d, true, nullptr);
+            if (s > nk / 4) s = nk / 4;
+            if (s > 16) s = 16;
+            if (s < 1) s = 1;
+            if (!assume_buffers && s > 1 && !t320_buffers_ok(d, s)) s = 1;      // asked for by name: run it unsplit
+        }
+        return s;
     }
+    // AUTO
+    if (d.M % 256 || d.splits > 1) return 0;          // (ragged row tiles and explicit split requests stay with the smaller tiles)
+    double t = 0.0;
+    const int s = t320_best_split(d, can_split && (assume_buffers || (d.sync != nullptr && d.workspace != nullptr)), &t);
+    const double flops = 2.0 * d.M * d.N * (double)d.K * (phases ? 4 : d.batch > 1 ? d.batch : 1);
+    const double rate = d.mode == SEER_GEMM_CONV3X3 ? 0.80e6 : geglu ? 0.78e6 : 0.85e6;      // FLOP per us
+    if (!(t < flops / rate)) return 0;
+    if (!assume_buffers && s > 1 && !t320_buffers_ok(d, s)) return 0;         // no room to split: the smaller tiles take it
     return s;
 }
 
@@ -1317,25 +1365,28 @@ int dispatch_tile(int tile, F&& f) {
 extern "C" int64_t seer_gemm_workspace_bytes(const seer_gemm_desc* desc) {
     if (!desc) return SEER_EINVAL;
     seer_gemm_desc d = *desc;
-    if (const int s320 = t320_plan(d)) return seer_gemm_t320_workspace_bytes(d, s320);
+    const int s320 = t320_plan(d, true);
+    const int64_t w320 = s320 ? seer_gemm_t320_workspace_bytes(d, s320) : 0;
     if (d.tile == SEER_TILE_T256x320) d.tile = SEER_TILE_AUTO;
     if (d.tile == SEER_TILE_WS || d.tile == SEER_TILE_AUTO_TILED) d.tile = SEER_TILE_AUTO;
     int s = 1;
     const int rc = prepare(d, &s);
     if (rc != SEER_OK) return rc;
-    return s > 1 ? (int64_t)s * d.M * d.N * (int64_t)sizeof(float) : 0;
+    // (a launch that is planned for the 256 x 320 tile but arrives without `sync` falls back to the smaller tiles: room for both)
+    const int64_t wold = s > 1 ? (int64_t)s * d.M * d.N * (int64_t)sizeof(float) : 0;
+    return w320 > wold ? w320 : wold;
 }
 
 extern "C" int64_t seer_gemm_sync_bytes(const seer_gemm_desc* desc) {
     if (!desc) return SEER_EINVAL;
-    if (const int s320 = t320_plan(*desc)) return seer_gemm_t320_sync_bytes(*desc, s320);
+    if (const int s320 = t320_plan(*desc, true)) return seer_gemm_t320_sync_bytes(*desc, s320);
     return 0;
 }
 
 extern "C" int32_t seer_gemm_colsum_rows(const seer_gemm_desc* desc) {
     if (!desc) return 0;
     seer_gemm_desc d = *desc;
-    if (t320_plan(d)) return ((d.epilogue & SEER_EPI_GEGLU) || !colsum_store_ok(d)) ? 0 : 64;   // four 64-row partials per tile
+    if (t320_plan(d)) return ((d.epilogue & SEER_EPI_GEGLU) || !colsum_store_ok(d) || d.M % 256) ? 0 : 64;   // four 64-row partials per tile
     if (d.tile == SEER_TILE_T256x320) d.tile = SEER_TILE_AUTO;
     const int requested = d.tile;
     if (requested == SEER_TILE_WS || requested == SEER_TILE_AUTO_TILED) d.tile = SEER_TILE_AUTO;
@@ -1358,17 +1409,14 @@ extern "C" int seer_gemm_bf16(const seer_gemm_desc* desc, void* stream) {
     if (!desc) return SEER_EINVAL;
     seer_gemm_desc d = *desc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (int s320 = t320_plan(d)) {
+    if (const int s320 = t320_plan(d)) {
         int sp = 1;
         seer_gemm_desc chk = d;
         chk.tile = SEER_TILE_AUTO;
         const int rc320 = prepare(chk, &sp);         // the same argument checks as every other launch
         if (rc320 != SEER_OK) return rc320;
         d.K1 = chk.K1; d.lda2 = chk.lda2; d.batch = chk.batch; d.strideA = chk.strideA; d.strideW = chk.strideW; d.strideC = chk.strideC;
-        if (d.colsum && ((d.epilogue & SEER_EPI_GEGLU) || !colsum_store_ok(d))) return SEER_EINVAL;
-        if (s320 > 1 && (!d.workspace || d.workspace_bytes < seer_gemm_t320_workspace_bytes(d, s320) || !d.sync ||
-                         d.sync_bytes < seer_gemm_t320_sync_bytes(d, s320)))
-            s320 = 1;
+        if (d.colsum && ((d.epilogue & SEER_EPI_GEGLU) || !colsum_store_ok(d) || d.M % 256)) return SEER_EINVAL;
         return seer_gemm_t320_launch(d, s320, st);
     }
     if (d.tile == SEER_TILE_T256x320) d.tile = SEER_TILE_AUTO;      // not eligible: the tile kernels take it

@@ -97,7 +97,10 @@ __global__ void __launch_bounds__(NT) seer_gemm_t320_kernel(const seer_gemm_desc
     // this wave stages pieces wave, wave + 8, wave + 16 (the last only for wave < 4: 20 pieces per region).
     const int schunk = ((lane & 7) ^ (lane >> 3)) * 8;
     int a_row[4];                                      // [rr * 2 + c]: tile row of this lane's piece row (clamped to M)
-    int a_img[4], a_yx[4];                             // conv: image base offset (elements); packed (iy0 + 4) << 16 | (ix0 + 4)
+    // conv: byte offset of tap (0, 0) of the piece row's pixel, this lane's chunk included (negative above / left of the image),
+    // and one validity bit per tap: bit 9 c + tap of a_ok[rr]
+    int a_pix[4];
+    unsigned a_ok[2] = {0u, 0u};
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int lr = 16 * wave + 8 * (c & 1) + (lane >> 3);
@@ -114,18 +117,26 @@ __global__ void __launch_bounds__(NT) seer_gemm_t320_kernel(const seer_gemm_desc
             const int pad0 = p.pad_after_only ? 0 : 1;
             const int iy0 = phase_mode ? oy + ((int)blockIdx.z >> 1) - 1 : oy * p.stride - pad0;
             const int ix0 = phase_mode ? ox + ((int)blockIdx.z & 1) - 1 : ox * p.stride - pad0;
-            a_img[c] = img * p.Hin * p.Win * p.Cin;
-            a_yx[c] = ((iy0 + 4) << 16) | (ix0 + 4);
+            a_pix[c] = ((img * p.Hin * p.Win + iy0 * p.Win + ix0) * p.Cin + schunk) * 2;
+            const int ksz = phase_mode ? 2 : 3;
+            unsigned bits = 0u;
+            for (int ky = 0; ky < ksz; ++ky)
+                for (int kx = 0; kx < ksz; ++kx)
+                    if (iy0 + ky >= 0 && iy0 + ky < p.Hin && ix0 + kx >= 0 && ix0 + kx < p.Win) bits |= 1u << (ky * ksz + kx);
+            a_ok[c >> 1] |= bits << (9 * (c & 1));
         }
     }
-    int b_rel[6];                                      // [cc * 3 + t]: (tile column) * K, elements
+    unsigned b_rel[3];                                 // [t]: byte offset of this lane's chunk in W region 0 (region 1: + 80 rows of W)
 #pragma unroll
-    for (int c = 0; c < 6; ++c) {
-        const int pc = wave + 8 * (c % 3);
+    for (int t = 0; t < 3; ++t) {
+        const int pc = wave + 8 * t;
         const int lc = 8 * pc + (lane >> 3);
-        const int col = (lc / 80) * 160 + (c / 3) * 80 + (lc % 80);
-        b_rel[c] = pc < 20 ? col * p.K : 0;          // (the padding piece re-reads column 0 into the spare 1 KB)
+        const int col = (lc / 80) * 160 + (lc % 80);
+        b_rel[t] = pc < 20 ? (unsigned)(col * p.K + schunk) * 2u : (unsigned)schunk * 2u;   // (a padding piece re-reads row 0)
     }
+    // conv: the input tensor as a raw buffer (bytes; eligibility keeps it under 2 GB)
+    const unsigned a_bytes = CONV ? (unsigned)((int64_t)(p.M / ((p.upsample == 2 ? p.Hin * p.Win : p.Hout * p.Wout))) * p.Hin * p.Win * p.Cin * 2) : 0u;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(A), 0, (int)a_bytes, 0x00020000);
     const unsigned cin_magic = CONV ? 0xFFFFFFFFu / (unsigned)p.Cin + 1u : 0u;   // tap = umulhi(kbase, magic): exact for kbase * Cin < 2^32
 
     const int nk_all = p.K / BK;
@@ -138,21 +149,19 @@ __global__ void __launch_bounds__(NT) seer_gemm_t320_kernel(const seer_gemm_desc
         const int kbase = (kt0 + u) * BK;
         bf16* dst = smem_b + (u & 1) * BUF + rr * A_HALF + (16 * wave) * BK;
         if constexpr (CONV) {
+            // LDS-DMA through a buffer resource over the input tensor: a lane whose tap falls outside the image asks for the byte
+            // just past the tensor and the bounds check returns zeros -- no zero page, no 64-bit address select, no branch
             const int tap = (int)__umulhi((unsigned)kbase, cin_magic);
             const int ci0 = kbase - tap * p.Cin;
             const int ksz = p.upsample == 2 ? 2 : 3;
             const int ky = tap / ksz, kx = tap - ky * ksz;
-            const int Hs = p.upsample == 1 ? p.Hin * 2 : p.Hin;
-            const int Ws = p.upsample == 1 ? p.Win * 2 : p.Win;
+            const int tap_b = (ky * p.Win + kx) * p.Cin * 2;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const int iy = (a_yx[rr * 2 + c] >> 16) - 4 + ky, ix = (a_yx[rr * 2 + c] & 0xffff) - 4 + kx;
-                const bool ok = (iy >= 0) & (iy < Hs) & (ix >= 0) & (ix < Ws);
-                const int sy = p.upsample == 1 ? (iy >> 1) : iy;
-                const int sx = p.upsample == 1 ? (ix >> 1) : ix;
-                const bf16* src = ok ? (A + a_img[rr * 2 + c] + (sy * p.Win + sx) * p.Cin + ci0 + schunk)
-                                     : reinterpret_cast<const bf16*>(seer_t320_zero_page);
-                lds_dma16(src, dst + 8 * c * BK);
+                const bool ok = ((a_ok[rr] >> (9 * c + tap)) & 1u) != 0u;
+                const unsigned voff = ok ? (unsigned)(a_pix[rr * 2 + c] + tap_b) : a_bytes;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(dst + 8 * c * BK), 16, voff,
+                                                         ci0 * 2, 0, 0);
             }
         } else {
             const bool second = kbase >= p.K1;
@@ -172,16 +181,11 @@ __global__ void __launch_bounds__(NT) seer_gemm_t320_kernel(const seer_gemm_desc
 #if !(SEER_T320_PROBE & 1)
         const int kbase = (kt0 + u) * BK;
         bf16* dst = smem_b + (u & 1) * BUF + 2 * A_HALF + cc * B_HALF + (8 * wave) * BK;
-        const unsigned char* wbase = reinterpret_cast<const unsigned char*>(W + (int64_t)n0 * p.K + kbase);
+        const unsigned char* wbase = reinterpret_cast<const unsigned char*>(W + (int64_t)(n0 + 80 * cc) * p.K + kbase);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const unsigned voff = (unsigned)(b_rel[cc * 3 + t] + schunk) * 2u;
-            lds_dma16(wbase + voff, dst + 64 * t * BK);
-        }
-        {   // third piece: waves 4..7 have none -- theirs lands in the spare 1 KB, so that every wave counts 3 per W region
-            const unsigned voff = (unsigned)(b_rel[cc * 3 + 2] + schunk) * 2u;
-            lds_dma16(wbase + voff, wave < 4 ? dst + 128 * BK : dummy);
-        }
+        for (int t = 0; t < 2; ++t) lds_dma16(wbase + b_rel[t], dst + 64 * t * BK);
+        // third piece: waves 4..7 have none -- theirs lands in the spare 1 KB, so that every wave counts 3 per W region
+        lds_dma16(wbase + b_rel[2], wave < 4 ? dst + 128 * BK : dummy);
 #endif
     };
 
@@ -304,6 +308,7 @@ __global__ void __launch_bounds__(NT) seer_gemm_t320_kernel(const seer_gemm_desc
     constexpr int NPASS = BM / PASS_ROWS;
     constexpr int CPR = BNO / 8;                        // 16-byte chunks per staged row
 
+    const int n0o = GEGLU ? (n0 >> 1) : n0;             // first output column of the tile
     // the quads this block finishes: all of them, or (split) its share [q0, q1) of q = 10 i + j, reduced over the S slabs
     int q0 = 0, q1 = NQ;
     f32x4 mine[SPLIT ? QMAX : 1];
@@ -386,6 +391,25 @@ __global__ void __launch_bounds__(NT) seer_gemm_t320_kernel(const seer_gemm_desc
         return v;
     };
 
+    // unsplit launches add the residual from LDS: the rows of a pass are fetched 16 B per lane along whole rows (the accumulator
+    // layout would fetch 8 B per lane in 16 different rows per instruction) into the slots the output will be staged in; a lane
+    // reads its quad's 8 B back, adds in fp32, rounds once and overwrites the slot.  The fetch of pass 0 is issued behind the other
+    // epilogue terms (ahead of them its 40 registers spill next to the 160 accumulators), the fetch of pass 1 behind the barrier
+    // that publishes pass 0.
+    u32x4 rres[SPLIT ? 1 : (PASS_ROWS * CPR) / NT];
+    auto fetch_residual = [&](int ps) {
+        if constexpr (!SPLIT) {
+#pragma unroll
+            for (int it = 0; it < (PASS_ROWS * CPR) / NT; ++it) {
+                const int c = tid + it * NT;
+                const int row = c / CPR, ch = c - row * CPR;
+                const int m = m0 + ps * PASS_ROWS + row;
+                rres[it] = m < p.M ? *reinterpret_cast<const u32x4*>(R + (int64_t)m * p.ldr + n0o + ch * 8) : u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+    };
+    const bool res_lds = !SPLIT && R != nullptr && (p.ldr % 8 == 0) && ((reinterpret_cast<uintptr_t>(R) & 15) == 0);
+
     if constexpr (!SPLIT) {
         // unsplit: one pass per term over the register tile (the order of additions of gemm.hip: bias, GEGLU, row vector, rotary,
         // column scale, residual)
@@ -458,28 +482,6 @@ __global__ void __launch_bounds__(NT) seer_gemm_t320_kernel(const seer_gemm_desc
                 }
             }
         }
-        if (R) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int m = m0 + wm * 64 + i * 16 + frow;
-                m = m < p.M ? m : p.M - 1;
-                const bf16* rrow = R + (int64_t)m * p.ldr;
-                u32x2 rv[10];
-#pragma unroll
-                for (int j = 0; j < 10; j += (GEGLU ? 2 : 1)) {
-                    const int n = n0 + wn * 160 + j * 16 + fq * 4;
-                    const int nc = GEGLU ? ((n - fq * 4) >> 1) + fq * 4 : n;
-                    rv[j] = *reinterpret_cast<const u32x2*>(rrow + nc);
-                }
-#pragma unroll
-                for (int j = 0; j < 10; j += (GEGLU ? 2 : 1)) {
-                    acc[i][j][0] += __builtin_bit_cast(float, rv[j][0] << 16);
-                    acc[i][j][1] += __builtin_bit_cast(float, rv[j][0] & 0xffff0000u);
-                    acc[i][j][2] += __builtin_bit_cast(float, rv[j][1] << 16);
-                    acc[i][j][3] += __builtin_bit_cast(float, rv[j][1] & 0xffff0000u);
-                }
-            }
-        }
     } else {
 #pragma unroll
         for (int k = 0; k < QMAX; ++k) {
@@ -493,13 +495,23 @@ __global__ void __launch_bounds__(NT) seer_gemm_t320_kernel(const seer_gemm_desc
     // ---- bf16 rows leave through the (now idle) K-loop LDS: 16 B per lane along whole output rows.  Column sums of the tile
     // as stored, per 64-row partial (row fragment i of the four wave rows): colsum[z][4 tile_m + i][N][2].
     const bool wt_store = p.K <= 3072;
-    const int n0o = GEGLU ? (n0 >> 1) : n0;
+    if (res_lds) fetch_residual(0);
     float cs_s[2] = {0.f, 0.f}, cs_q[2] = {0.f, 0.f}, cs_s2[2] = {0.f, 0.f}, cs_q2[2] = {0.f, 0.f};
     const int cs_cp = tid % 160, cs_i = tid / 160;      // column pair, row fragment (threads 480..511: none); fragment 3: threads < 160
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
         if (ps > 0) __syncthreads();                    // the previous pass has been copied out
         if constexpr (!SPLIT) {
+            if (res_lds) {
+#pragma unroll
+                for (int it = 0; it < (PASS_ROWS * CPR) / NT; ++it) {
+                    const int c = tid + it * NT;
+                    const int row = c / CPR, ch = c - row * CPR;
+                    *reinterpret_cast<u32x4*>(smem + row * CPITCH + ch * 16) = rres[it];
+                }
+                __syncthreads();
+                if (ps + 1 < NPASS) fetch_residual(ps + 1);
+            }
             if (GEGLU || (wm >> 1) == ps) {
                 const int rowb = ((GEGLU ? wm * 64 : (wm & 1) * 64) + frow) * CPITCH;
 #pragma unroll
@@ -507,10 +519,28 @@ __global__ void __launch_bounds__(NT) seer_gemm_t320_kernel(const seer_gemm_desc
                     const int cb = GEGLU ? (wn * 80 + (j >> 1) * 16 + fq * 4) * 2 : (wn * 160 + j * 16 + fq * 4) * 2;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
+                        u32x2* slot = reinterpret_cast<u32x2*>(smem + rowb + i * 16 * CPITCH + cb);
+                        f32x4 v = acc[i][j];
+                        if (res_lds) {
+                            const u32x2 rv = *slot;
+                            v[0] += __builtin_bit_cast(float, rv[0] << 16);
+                            v[1] += __builtin_bit_cast(float, rv[0] & 0xffff0000u);
+                            v[2] += __builtin_bit_cast(float, rv[1] << 16);
+                            v[3] += __builtin_bit_cast(float, rv[1] & 0xffff0000u);
+                        } else if (R) {
+                            int m = m0 + wm * 64 + i * 16 + frow;
+                            m = m < p.M ? m : p.M - 1;
+                            const int n = n0 + wn * 160 + j * 16 + fq * 4;
+                            const u32x2 rv = *reinterpret_cast<const u32x2*>(R + (int64_t)m * p.ldr + (GEGLU ? ((n - fq * 4) >> 1) + fq * 4 : n));
+                            v[0] += __builtin_bit_cast(float, rv[0] << 16);
+                            v[1] += __builtin_bit_cast(float, rv[0] & 0xffff0000u);
+                            v[2] += __builtin_bit_cast(float, rv[1] << 16);
+                            v[3] += __builtin_bit_cast(float, rv[1] & 0xffff0000u);
+                        }
                         u32x2 o;
-                        o[0] = pack2(acc[i][j][0], acc[i][j][1]);
-                        o[1] = pack2(acc[i][j][2], acc[i][j][3]);
-                        *reinterpret_cast<u32x2*>(smem + rowb + i * 16 * CPITCH + cb) = o;
+                        o[0] = pack2(v[0], v[1]);
+                        o[1] = pack2(v[2], v[3]);
+                        *slot = o;
                     }
                 }
             }
@@ -609,7 +639,11 @@ bool seer_gemm_t320_eligible(const seer_gemm_desc& d) {
     if (d.residual && (d.ldr % 4)) return false;
     // 32-bit element offsets in the staging path
     if (d.mode == SEER_GEMM_CONV3X3) {
+        if (d.upsample == 1) return false;             // the nearest-2x read-through form stays with the smaller tiles
         if ((int64_t)d.M * d.Cin >= (1ll << 30) || (int64_t)d.K * d.Cin >= (1ll << 32)) return false;
+        const int64_t hw_out = d.upsample == 2 ? (int64_t)d.Hin * d.Win : (int64_t)d.Hout * d.Wout;
+        if (hw_out <= 0 || d.M % hw_out) return false;
+        if ((d.M / hw_out) * d.Hin * d.Win * d.Cin * 2 >= (1ll << 31)) return false;     // the input tensor as one raw buffer
         if (d.Hin > 16000 || d.Win > 16000) return false;
     } else {
         if ((int64_t)256 * (d.lda > d.lda2 ? d.lda : d.lda2) >= (1ll << 30)) return false;

@@ -105,6 +105,23 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias=None, residual=None, rowvec=N
     return out
 
 
+_SYNC_BYTES = 1 << 16          # counters of the in-launch split-K reduction: two 32-bit words per output tile
+_sync_buffers: dict = {}
+
+
+def _sync_buffer(device) -> torch.Tensor:
+    """seer_gemm_desc::sync: zeroed ONCE per device; every launch leaves it zero again, and the engines launch on one stream
+    (launches that could overlap in time would need buffers of their own).  Created outside any graph capture: the first
+    call of a shape is always an eager warm-up, and a memset inside a captured step would replay with every step."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    buf = _sync_buffers.get(key)
+    if buf is None:
+        assert not torch.cuda.is_current_stream_capturing(), "the split-K counter buffer must exist before a graph capture"
+        buf = torch.zeros((_SYNC_BYTES,), device=device, dtype=torch.uint8)
+        _sync_buffers[key] = buf
+    return buf
+
+
 def _launch_gemm(d: GemmDesc, device, what: str, colsum_batch: int = 0) -> Optional[ColSums]:
     """split-K needs a caller-provided fp32 workspace (the library never allocates): ask, allocate, launch.
     colsum_batch > 0: also ask for per-tile column sums when the launch can produce them and no tile straddles two of the
@@ -116,6 +133,11 @@ def _launch_gemm(d: GemmDesc, device, what: str, colsum_batch: int = 0) -> Optio
     if nbytes > 0:
         ws = torch.empty((nbytes // 4,), device=device, dtype=torch.float32)
         d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
+    nsync = lib.seer_gemm_sync_bytes(C.byref(d))
+    if nsync < 0:
+        check(int(nsync), what)
+    if 0 < nsync <= _SYNC_BYTES:
+        d.sync, d.sync_bytes = _sync_buffer(device).data_ptr(), _SYNC_BYTES
     cs = None
     if colsum_batch > 0 and d.M % colsum_batch == 0:
         rows = lib.seer_gemm_colsum_rows(C.byref(d))
