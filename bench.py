@@ -33,6 +33,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 
+HBM_PEAK_GBS = 8000.0                     # same guide: HBM3E 8 TB/s (spec)
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16
 PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"
 WORKLOAD = dict(b=1, cond_frames=2, frames=12, latent=32, ddim_steps=50, scale=7.5)
@@ -423,7 +424,8 @@ def main():
                         step_breakdown_ms={k: round(v["ms"] / reps, 3) for k, v in summ.items()},
                         attention_tflops=round(summ.get("attention", {}).get("tflops", 0.0), 2),
                         groupnorms_from_colsums=f"{eng.gn_from_colsums} of {eng.n_groupnorms()}",
-                        spatial_attention_block=attn_block)
+                        spatial_attention_block=attn_block,
+                        rows=timed.family_rows(reps, MFMA_BF16_DENSE_PEAK_TFLOPS, HBM_PEAK_GBS))
         if traffic_note:
             roofline["traffic_note"] = traffic_note
 

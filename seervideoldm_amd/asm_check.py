@@ -140,10 +140,17 @@ def check_attn40_vregs(lines: Iterable[str], fname: str = "") -> Tuple[List[str]
     return out, pairs
 
 
-def check_directory(objdir: Path) -> List[str]:
-    """run every rule over the device assembly under `objdir`; returns the violations"""
+def check_directory(objdir: Path, sources: Iterable[str] = ()) -> List[str]:
+    """run every rule over the device assembly under `objdir`; returns the violations.  `sources`: the .hip files of the build --
+    only their assembly is read (a stale .s of a removed source must neither fail nor mask a build); empty = every *gfx950.s.
+    Scope of the packed-instruction rule: packed fp32 arithmetic (v_pk_{fma,mul,add}_f32: destinations are register PAIRS, which
+    is what _PK matches) -- the forms measured in profiles/r03_flake_root_cause.md.  16-bit packed forms (one destination
+    VGPR) were not measured and are not judged."""
     problems: List[str] = []
     files = sorted(objdir.glob("*gfx950.s"))
+    stems = {Path(x).stem for x in sources}
+    if stems:
+        files = [f for f in files if f.name.split("-hip-")[0] in stems]
     if not files:
         return [f"no device assembly (*gfx950.s) under {objdir}: build with seervideoldm_amd.build"]
     pairs = 0

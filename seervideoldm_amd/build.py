@@ -41,7 +41,7 @@ def _hipcc() -> str:
 
 def _digest() -> str:
     h = hashlib.sha256()
-    for p in sorted(list(CSRC.glob("*")) + [ROOT / "include" / "seer_hip.h", Path(__file__).resolve()]):
+    for p in sorted(list(CSRC.glob("*")) + [ROOT / "include" / "seer_hip.h", Path(__file__).resolve(), PKG / "asm_check.py"]):
         if p.is_file():
             h.update(p.name.encode())
             h.update(p.read_bytes())
@@ -82,7 +82,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     # the assembly rules of asm_check.py: instruction forms that misbehaved on MI355X, and the register discipline of the
     # inline-asm LDS reads in attention40.hip
     from .asm_check import check_directory
-    problems = check_directory(objdir)
+    problems = check_directory(objdir, SOURCES)
     if problems:
         raise RuntimeError("assembly check failed (seervideoldm_amd/asm_check.py):\n" + "\n".join(problems[:40]))
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]

@@ -1324,9 +1324,12 @@ int t320_plan(const seer_gemm_desc& d, bool assume_buffers = false) {
     // AUTO
     if (d.M % 256 || d.splits > 1) return 0;          // (ragged row tiles and explicit split requests stay with the smaller tiles)
     double t = 0.0;
-    const int s = t320_best_split(d, can_split && (assume_buffers || (d.sync != nullptr && d.workspace != nullptr)), &t);
+    // AUTO never splits K on this kernel: the in-launch reduction waits for peer workgroups, which is only safe when this process
+    // has the GPU to itself (gemm_t320.hip); ask for SEER_TILE_T256x320 + splits by name where that holds
+    (void)can_split;
+    const int s = t320_best_split(d, false, &t);
     const double flops = 2.0 * d.M * d.N * (double)d.K * (phases ? 4 : d.batch > 1 ? d.batch : 1);
-    const double rate = d.mode == SEER_GEMM_CONV3X3 ? 0.80e6 : geglu ? 0.78e6 : 0.85e6;      // FLOP per us
+    const double rate = d.mode == SEER_GEMM_CONV3X3 ? 0.80e9 : geglu ? 0.78e9 : 0.85e9;      // FLOP per us (0.78-0.85 PFLOP/s)
     if (!(t < flops / rate)) return 0;
     if (!assume_buffers && s > 1 && !t320_buffers_ok(d, s)) return 0;         // no room to split: the smaller tiles take it
     return s;
@@ -1386,7 +1389,8 @@ extern "C" int64_t seer_gemm_sync_bytes(const seer_gemm_desc* desc) {
 extern "C" int32_t seer_gemm_colsum_rows(const seer_gemm_desc* desc) {
     if (!desc) return 0;
     seer_gemm_desc d = *desc;
-    if (t320_plan(d)) return ((d.epilogue & SEER_EPI_GEGLU) || !colsum_store_ok(d) || d.M % 256) ? 0 : 64;   // four 64-row partials per tile
+    if (const int s320 = t320_plan(d))            // one partial per wave row (64 rows) unsplit, per 16-row fragment when K is split
+        return ((d.epilogue & SEER_EPI_GEGLU) || !colsum_store_ok(d) || d.M % 256) ? 0 : (s320 > 1 ? 16 : 64);
     if (d.tile == SEER_TILE_T256x320) d.tile = SEER_TILE_AUTO;
     const int requested = d.tile;
     if (requested == SEER_TILE_WS || requested == SEER_TILE_AUTO_TILED) d.tile = SEER_TILE_AUTO;

@@ -312,6 +312,7 @@ __global__ void __launch_bounds__(NT) seer_gemm_t320_kernel(const seer_gemm_desc
     // the quads this block finishes: all of them, or (split) its share [q0, q1) of q = 10 i + j, reduced over the S slabs
     int q0 = 0, q1 = NQ;
     f32x4 mine[SPLIT ? QMAX : 1];
+    int& timed_out_s = *reinterpret_cast<int*>(dummy);     // (inside the ONE LDS array: a second __shared__ object can cost the K loop its counted waits)
     if constexpr (SPLIT) {
         q0 = NQ * slice / S;
         q1 = NQ * (slice + 1) / S;
@@ -332,8 +333,13 @@ __global__ void __launch_bounds__(NT) seer_gemm_t320_kernel(const seer_gemm_desc
             int spins = 0;
             while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)S && ++spins < (1 << 24))
                 __builtin_amdgcn_s_sleep(4);
+            // The wait assumes the S slices of a tile become resident together: true for one process per GPU (block ids of a tile are
+            // adjacent, dispatch is in order).  Two processes that BOTH run spin-waiting kernels on one GPU can hold each other's
+            // CUs; the bound turns that into a loud failure (a NaN share) instead of a hang -- AUTO therefore never splits K here.
+            timed_out_s = spins >= (1 << 24);
         }
         __syncthreads();
+        const bool timed_out = timed_out_s != 0;
         // ---- reduce my share in slice order: sc1 loads only (the lines were written through by other CUs)
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slabs, 0, S * (8 * NQ * 64 * 16), 0x00020000);
         const int nq = q1 - q0;
@@ -349,7 +355,7 @@ __global__ void __launch_bounds__(NT) seer_gemm_t320_kernel(const seer_gemm_desc
 #pragma unroll
                 for (int sp = 1; sp < SMAX; ++sp)
                     if (sp < S) sum += __builtin_bit_cast(f32x4, v[sp]);
-                mine[k] = sum;
+                mine[k] = timed_out ? f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")} : sum;
             }
         }
         __syncthreads();                                // every wave holds its sums: this block no longer reads the slabs
@@ -496,8 +502,6 @@ __global__ void __launch_bounds__(NT) seer_gemm_t320_kernel(const seer_gemm_desc
     // as stored, per 64-row partial (row fragment i of the four wave rows): colsum[z][4 tile_m + i][N][2].
     const bool wt_store = p.K <= 3072;
     if (res_lds) fetch_residual(0);
-    float cs_s[2] = {0.f, 0.f}, cs_q[2] = {0.f, 0.f}, cs_s2[2] = {0.f, 0.f}, cs_q2[2] = {0.f, 0.f};
-    const int cs_cp = tid % 160, cs_i = tid / 160;      // column pair, row fragment (threads 480..511: none); fragment 3: threads < 160
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
         if (ps > 0) __syncthreads();                    // the previous pass has been copied out
@@ -560,29 +564,32 @@ __global__ void __launch_bounds__(NT) seer_gemm_t320_kernel(const seer_gemm_desc
         }
         __syncthreads();
         if constexpr (!GEGLU) {
-            if (p.colsum && cs_i < 3) {
-                // rows of fragment cs_i in this pass: 64 w + 16 cs_i + r for the two wave rows w of the pass
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int fi = e == 0 ? cs_i : 3;
-                    if (e == 1 && cs_i != 0) break;
-                    const int qq = fi * 10 + (cs_cp % 80) / 8;
-                    if (SPLIT && (qq < q0 || qq >= q1)) continue;
+            // column sums of the pass as stored (bf16-rounded), per CONTIGUOUS row block: unsplit, one partial per wave row (64
+            // rows: colsum[z][4 tile_m + wave row][N][2]); split, one per 16-row fragment of a wave row (a slice finishes whole
+            // quads: colsum[16 tile_m + 4 wave row + fragment][N][2], every entry written by exactly one slice).  A thread owns a
+            // column pair of one block and adds its rows in order: deterministic, no atomics.
+            if (p.colsum) {
+                constexpr int NB = SPLIT ? 8 : 2;             // row blocks in a pass
+                constexpr int RB = SPLIT ? 16 : 64;           // rows per block
+                for (int e = tid; e < 160 * NB; e += NT) {
+                    const int cp = e % 160, blk = e / 160;
+                    if constexpr (SPLIT) {
+                        const int qq = (blk & 3) * 10 + (cp % 80) / 8;
+                        if (qq < q0 || qq >= q1) continue;
+                    }
+                    const int mrow = m0 + ps * 128 + blk * RB;
                     float s0 = 0.f, s1 = 0.f, t0 = 0.f, t1 = 0.f;
-                    for (int w = 0; w < 2; ++w) {
-                        const int mrow = m0 + ps * 128 + w * 64 + fi * 16;
 #pragma unroll 4
-                        for (int r = 0; r < 16; ++r) {
-                            if (mrow + r < p.M) {
-                                const uint32_t v = *reinterpret_cast<const uint32_t*>(smem + (w * 64 + fi * 16 + r) * CPITCH + cs_cp * 4);
-                                const float f0 = __builtin_bit_cast(float, v << 16), f1 = __builtin_bit_cast(float, v & 0xffff0000u);
-                                s0 += f0; t0 += f0 * f0;
-                                s1 += f1; t1 += f1 * f1;
-                            }
+                    for (int r = 0; r < RB; ++r) {
+                        if (mrow + r < p.M) {
+                            const uint32_t v = *reinterpret_cast<const uint32_t*>(smem + (blk * RB + r) * CPITCH + cp * 4);
+                            const float f0 = __builtin_bit_cast(float, v << 16), f1 = __builtin_bit_cast(float, v & 0xffff0000u);
+                            s0 += f0; t0 += f0 * f0;
+                            s1 += f1; t1 += f1 * f1;
                         }
                     }
-                    if (e == 0) { cs_s[0] += s0; cs_s[1] += s1; cs_q[0] += t0; cs_q[1] += t1; }
-                    else { cs_s2[0] += s0; cs_s2[1] += s1; cs_q2[0] += t0; cs_q2[1] += t1; }
+                    const int64_t part = ((int64_t)(SPLIT ? 0 : blockIdx.z) * tiles_m + tm) * (2 * NB) + ps * NB + blk;
+                    *reinterpret_cast<f32x4*>(p.colsum + (part * p.N + n0 + cp * 2) * 2) = f32x4{s0, t0, s1, t1};
                 }
             }
         }
@@ -602,22 +609,6 @@ __global__ void __launch_bounds__(NT) seer_gemm_t320_kernel(const seer_gemm_desc
                 bf16* dst = Cb + crow(m) * p.ldc + n0o + ch * 8;
                 if (wt_store) store16_out(dst, v);
                 else *reinterpret_cast<u32x4*>(dst) = v;
-            }
-        }
-    }
-    if constexpr (!GEGLU) {
-        if (p.colsum && cs_i < 3) {
-            const int64_t part0 = ((int64_t)blockIdx.z * (SPLIT ? 0 : 1) * tiles_m + tm) * 4;
-            const int col = n0 + cs_cp * 2;
-            {
-                const int qq = cs_i * 10 + (cs_cp % 80) / 8;
-                if (!SPLIT || (qq >= q0 && qq < q1))
-                    *reinterpret_cast<f32x4*>(p.colsum + ((part0 + cs_i) * p.N + col) * 2) = f32x4{cs_s[0], cs_q[0], cs_s[1], cs_q[1]};
-            }
-            if (cs_i == 0) {
-                const int qq = 30 + (cs_cp % 80) / 8;
-                if (!SPLIT || (qq >= q0 && qq < q1))
-                    *reinterpret_cast<f32x4*>(p.colsum + ((part0 + 3) * p.N + col) * 2) = f32x4{cs_s2[0], cs_q2[0], cs_s2[1], cs_q2[1]};
             }
         }
     }

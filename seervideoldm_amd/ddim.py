@@ -231,8 +231,9 @@ class DDIMSampler(object):
         if context.shape[0] != reps * b or context.shape[1] != f1 + Fp or h % 8 or w % 8:
             return None
         ctx, L = eng._context(context)          # new prompt: the static context / K|V buffers are refreshed in place
-        key = ("step", (b, Cc, Fp, h, w), f1, cfg, int(cond_frames), float(scale), L, tuple(ctx.shape))
-        G = eng._graphs.get(key)
+        # (the guidance scale is only part of a CFG step: a plain step at another scale is the same graph)
+        key = ("step", (b, Cc, Fp, h, w), f1, cfg, int(cond_frames), float(scale) if cfg else None, L, tuple(ctx.shape))
+        G = eng.graph_get(key)
         if G is None:
             G = self._capture_step(eng, key, x, x0_emb, reps, cfg, int(cond_frames), float(scale), ctx, L)
             if G is None:
@@ -300,9 +301,7 @@ class DDIMSampler(object):
             warnings.warn(f"hipGraph capture of the sampler step failed ({type(e).__name__}: {e}); stepping launch by launch")
             return None
         G["graph"] = g
-        if len(eng._graphs) > 6:
-            eng._graphs.clear()
-        eng._graphs[key] = G
+        eng.graph_put(key, G)
         return G
 
 

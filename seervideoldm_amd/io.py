@@ -52,14 +52,7 @@ def image_grid(x_samples_ddim: torch.Tensor, x0_image: torch.Tensor) -> torch.Te
     red[:, [1, 2]] = 0
     green[:, [0, 2]] = 0
     data = torch.cat([cnd, green, pred, red], dim=-1)
-    # torchvision.utils.make_grid(data, nrow=1, padding=6, pad_value=0.5): one image per row, a 6-pixel border of pad_value
-    # around the whole grid and between the rows
-    pad, W = 6, data.shape[-1]
-    grid = torch.full((c, n * (h + pad) + pad, W + 2 * pad), 0.5)
-    for k in range(n):
-        y0 = pad + k * (h + pad)
-        grid[:, y0:y0 + h, pad:pad + W] = data[k]
-    return grid
+    return _make_grid_rows(data)      # torchvision.utils.make_grid(data, nrow=1, padding=6, pad_value=0.5)
 
 
 def save_visualization_onegif(x_samples_ddim: torch.Tensor, x0_image: torch.Tensor, sample_id: int, image_path: str,
@@ -80,8 +73,10 @@ def save_visualization_onegif(x_samples_ddim: torch.Tensor, x0_image: torch.Tens
 
 def _make_grid_rows(data: torch.Tensor, pad: int = 6, pad_value: float = 0.5) -> torch.Tensor:
     """torchvision.utils.make_grid(data, nrow=1, padding=pad, pad_value=pad_value): one image per row, a border of `pad_value`
-    around the grid and between the rows"""
+    around the grid and between the rows -- except for n == 1, which make_grid returns unpadded"""
     n, c, h, W = data.shape
+    if n == 1:              # torchvision: a single image comes back as it is (tensor.squeeze(0)), no border
+        return data[0].clone()
     grid = torch.full((c, n * (h + pad) + pad, W + 2 * pad), pad_value)
     for k in range(n):
         y0 = pad + k * (h + pad)

@@ -99,12 +99,21 @@ class FrameShard:
         if not probe_capture(device, group=self.frame_group()):
             self.capture_collectives = False
 
+    def control_group(self):
+        """a communicator of all ranks that NO step collective uses: a rank that failed alone and votes while its peers are still
+        inside the step's own all-reduce / all-gather (same ranks when P == world) must not meet them on their communicator --
+        a size-1 MIN against a GroupNorm all-reduce is a mismatched collective, i.e. a hang or a garbage flag.  Created by
+        every rank at the same point (attach())."""
+        if "control" not in self._pgs:
+            self._pgs["control"] = dist.new_group(list(range(self.world)))
+        return self._pgs["control"]
+
     def agree(self, ok: bool, device) -> bool:
-        """True iff `ok` on every rank (eager MIN all-reduce over WORLD): how the ranks take a fallback together"""
+        """True iff `ok` on every rank (eager MIN all-reduce over the control group): how the ranks take a fallback together"""
         if self.world == 1 or not (dist.is_available() and dist.is_initialized()):
             return ok
         flag = torch.tensor([1.0 if ok else 0.0], device=device if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.control_group())
         return bool(flag.item() > 0.5)
 
     def describe(self) -> str:
@@ -235,6 +244,8 @@ def attach(model, world: int, rank: int, batch_groups: Optional[int] = None, cap
     """make `model.forward` run sharded: every rank passes the FULL (sample, timestep, context) and gets the FULL output.
     capture_collectives=False keeps the eager exchanges between hipGraph segments (the conservative replay)."""
     shard = FrameShard(world, rank, batch_groups, capture_collectives)
+    if world > 1 and dist.is_available() and dist.is_initialized():
+        shard.control_group()                # every rank, here: new_group is itself collective
     if shard.capture_collectives:
         dev = next(model.parameters()).device
         if dev.type != "cuda" or not probe_capture(dev):

@@ -115,5 +115,53 @@ class TimedOps:
         rows = [(t, n, ms, (fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)) for t, (n, ms, fl) in agg.items()]
         return sorted(rows, key=lambda x: -x[2])
 
+    @staticmethod
+    def _family(cls: str, tag) -> str:
+        """the ~15 kernel families of a denoising step (bench.py roofline.rows)"""
+        if tag is None:
+            return cls
+        t = tag.split()
+        if t[0] == "gemm":
+            M, N, K = int(t[1][1:]), int(t[2][1:]), int(t[3][1:])
+            lvl = {24576: "L0", 6144: "L1", 1536: "L2", 384: "L3/mid"}.get(M, f"M{M}")
+            if "geglu" in t:
+                return f"ff.net.0 GEGLU {lvl}"
+            if "+res" in t and K == 4 * N:
+                return f"ff.net.2 +res {lvl}"
+            if N == 3 * K:
+                return f"q|k|v projection {lvl}"
+            return f"projections / 1x1 {lvl}"
+        if t[0] == "conv":
+            return f"conv3x3 {t[2]}"
+        if t[0] == "conv_up2x":
+            return "conv3x3 behind nearest-2x (4 phase convs)"
+        if t[0] == "attn":
+            sq, sk = int(t[2][2:]), int(t[3][2:])
+            kind = "temporal window" if t[5] == "causal1" else ("text cross" if sk == 77 else "spatial self")
+            return f"attention {kind} {t[4]} Sq{sq}"
+        return cls
+
+    def family_rows(self, reps: int, mfma_peak_tflops: float, hbm_peak_gbs: float):
+        """[{name, launches (per step), us (average per launch), ms (per step), bound, frac}] sorted by time: the spread the
+        class average of the roofline line hides.  frac = algorithmic FLOP/s over the dense bf16 MFMA peak for the MFMA
+        kernels, algorithmic bytes/s over the HBM peak for the normalisation kernels."""
+        agg = {}
+        for cls, recs in self.records.items():
+            for r in recs:
+                a = agg.setdefault(self._family(cls, r[4]), [0, 0.0, 0.0, 0.0])
+                a[0] += 1
+                a[1] += r[0].elapsed_time(r[1])
+                a[2] += r[2]
+                a[3] += r[3]
+        rows = []
+        for name, (n, ms, fl, by) in agg.items():
+            if ms <= 0:
+                continue
+            mfma = fl > 0
+            frac = (fl / (ms * 1e-3) / 1e12 / mfma_peak_tflops) if mfma else (by / (ms * 1e-3) / 1e9 / hbm_peak_gbs)
+            rows.append(dict(name=name, launches=n // reps, us=round(ms / n * 1e3, 2), ms=round(ms / reps, 3),
+                             bound="mfma" if mfma else "hbm", frac=round(frac, 4)))
+        return sorted(rows, key=lambda r: -r["ms"])
+
     def reset(self):
         self.records.clear()

@@ -214,10 +214,27 @@ class _Engine:
         self._rot_cache: Dict[Tuple, torch.Tensor] = {}
         self._kv_cache: Dict[str, torch.Tensor] = {}
         self._kv_key = None
-        self._graphs: Dict[Tuple, object] = {}
+        self._graphs: Dict[Tuple, object] = {}     # captured steps (whole-step graphs and sampler-step graphs), LRU: see graph_get / graph_put
         self._rec = None                # _SegmentRecorder while a segmented capture is running
         self._attn_list = None          # list that collects the text cross-attention scores of a return_attn forward
         self._attn_wanted = ()
+
+    # ---- captured graphs: ONE cache, ONE eviction policy ------------------------------------------------------------
+    # Every entry owns a private graph memory pool with a full set of step activations, so the cache is small and evicts the
+    # single least-recently-used entry (dict order = recency), never everything at once.
+    MAX_GRAPHS = 6
+
+    def graph_get(self, key):
+        g = self._graphs.get(key)
+        if g is not None:
+            self._graphs[key] = self._graphs.pop(key)          # most recently used last
+        return g
+
+    def graph_put(self, key, g) -> None:
+        self._graphs.pop(key, None)
+        while len(self._graphs) >= self.MAX_GRAPHS:
+            self._graphs.pop(next(iter(self._graphs)))         # the least recently used one
+        self._graphs[key] = g
 
     # ---- weight packing ---------------------------------------------------------------------------------------
     def _pack(self, sd):
@@ -547,7 +564,7 @@ class _Engine:
         launch per stretch between two collectives (GroupNorm statistics / K|V exchanges stay eager torch.distributed
         calls on the same stream)."""
         key = (tuple(sample.shape), L, cond_frame, tuple(ctx.shape))
-        g = self._graphs.get(key)
+        g = self.graph_get(key)
         if g is None:
             # warm up eagerly (fills the K/V and rotary caches, creates process groups, lets allocations settle), then capture
             s_in, t_in = sample.clone(), t.clone()
@@ -588,9 +605,7 @@ class _Engine:
                 warnings.warn(f"hipGraph capture of the denoising step failed ({type(err).__name__}: {err}); running eagerly")
                 return self._forward(sample, t, ctx, L, cond_frame)
             g = (rec, s_in, t_in, out)
-            if len(self._graphs) > 4:
-                self._graphs.clear()
-            self._graphs[key] = g
+            self.graph_put(key, g)
         rec, s_in, t_in, out = g
         s_in.copy_(sample)
         t_in.copy_(t)

@@ -57,6 +57,10 @@ def test_gif_frames_and_grid_pixels(tmp_path):
     assert torch.all(green[1] == 1) and torch.all(green[0] == 0) and torch.all(green[2] == 0)
     assert torch.equal(row0[:, 2:2 + H, f0 * wp + 4 + 2:f0 * wp + 4 + 2 + W], vids[0, :, 0])
 
+    # a one-sample batch: torchvision.utils.make_grid returns the single image unpadded (tensor.squeeze(0)) -- no grey border
+    g1 = sio.image_grid(vids[:1], cond[:1])
+    assert g1.shape == (3, hp, f0 * wp + 4 + f * wp + 4) and torch.equal(g1, grid[:, 6:6 + hp, 6:6 + g1.shape[2]])
+
     gif, png = sio.save_visualization_onegif(vids, cond, 7, str(tmp_path / "img.jpg"))
     from PIL import Image
     im = Image.open(gif)
