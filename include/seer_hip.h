@@ -28,6 +28,11 @@ extern "C" {
 #define SEER_ENOSYS (-38)   /* shape class not built (e.g. head dim) */
 #define SEER_ELAUNCH (-5)   /* hipLaunchKernel reported an error */
 
+/* storage type of 16-bit activations for the *_dt entry points: bf16 everywhere on the UNet path, IEEE half on the VAE path (the
+ * reference decodes in fp32: inference_img.py:118) */
+#define SEER_DT_BF16 0
+#define SEER_DT_F16 1
+
 /* library / device info ------------------------------------------------------------------- */
 int seer_abi_version(void);                 /* bumps when a struct below changes */
 const char* seer_strerror(int code);        /* host string */
@@ -64,6 +69,11 @@ const char* seer_build_arch(void);          /* "gfx950" */
 #define SEER_EPI_COLSCALE 32u  /* multiply the output columns n < col_scale_cols by col_scale (after bias / rotary): the q columns
                                 * of a projection leave the GEMM as q * scale * log2(e), rounded to bf16 ONCE, for
                                 * SEER_ATTN_Q_PRESCALED (attention.py:622-630 applies the scale inside the attention op) */
+
+#define SEER_EPI_F16 64u       /* A, A2, W, residual and C hold IEEE half (fp16) instead of bf16; fp32 accumulation as always.  For the
+                                * VAE, which the reference never autocasts (inference_img.py:118, ddim_sampling_utils.py:37-41):
+                                * 11 significand bits at the bf16 MFMA rate.  Plain and conv launches, unsplit; not with GEGLU,
+                                * rotary or colsum */
 
 typedef struct seer_gemm_desc {
     const void* A;          /* bf16 */
@@ -256,6 +266,13 @@ int seer_groupnorm_stats_from_colsums(const float* cs1, int32_t C1, int32_t phas
 int seer_groupnorm_apply(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t batch,
                          int64_t rows_per_batch, int32_t groups, const float* stats, double count, float eps,
                          const float* gamma, const float* beta, int32_t silu, void* y, void* stream);
+/* the same two with the storage type of x1 / x2 / y chosen by `dtype` (SEER_DT_*): the VAE's nn.GroupNorm(32, eps 1e-6)
+ * (ldm/modules/diffusionmodules/model.py:38-40) on fp16 activations */
+int seer_groupnorm_stats_dt(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t batch,
+                            int64_t rows_per_batch, int32_t groups, float* stats, float* workspace, int32_t dtype, void* stream);
+int seer_groupnorm_apply_dt(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t batch,
+                            int64_t rows_per_batch, int32_t groups, const float* stats, double count, float eps,
+                            const float* gamma, const float* beta, int32_t silu, void* y, int32_t dtype, void* stream);
 
 /* nn.LayerNorm(C) per token row (attention.py:198-200,275-277), eps 1e-5; bf16 in/out, fp32 statistics. */
 int seer_layernorm(const void* x, int64_t rows, int32_t C, int32_t ldx, const float* gamma, const float* beta,
@@ -265,6 +282,9 @@ int seer_layernorm(const void* x, int64_t rows, int32_t C, int32_t ldx, const fl
  * ldm/modules/diffusionmodules/model.py:186-197) */
 int seer_softmax_rows(const void* x, int32_t x_is_f32, int64_t rows, int32_t n, int32_t ld, float scale, void* y,
                       int32_t ldy, void* stream);
+/* ... with 16-bit x and y in the storage type `dtype` (SEER_DT_*) */
+int seer_softmax_rows_dt(const void* x, int32_t x_is_f32, int64_t rows, int32_t n, int32_t ld, float scale, void* y,
+                         int32_t ldy, int32_t dtype, void* stream);
 
 /* ---- small / boundary kernels ----------------------------------------------------------- */
 /* diffusers Timesteps(320, flip_sin_to_cos, freq_shift) (unet_3d_condition.py:97,307): out[b] = [cos | sin](t*f_i)
@@ -285,6 +305,12 @@ int seer_conv_in(const float* x, int32_t B, int32_t Cin, int32_t F, int32_t H, i
  * (unet_3d_condition.py:205,370).  W fp32 [Cout][3][3][C0]. */
 int seer_conv_out(const void* x, int32_t B, int32_t C0, int32_t F, int32_t H, int32_t W_, const float* Wt,
                   const float* bias, int32_t Cout, float* y, void* stream);
+/* the VAE's conv_in / conv_out (ldm/modules/diffusionmodules/model.py:487-491,556-568) with the channels-last side stored
+ * as `dtype` (SEER_DT_*); conv_out: Cout = 3 for SEER_DT_F16 */
+int seer_conv_in_dt(const float* x, int32_t B, int32_t Cin, int32_t F, int32_t H, int32_t W_, const float* Wt,
+                    const float* bias, int32_t Cout, void* y, int32_t dtype, void* stream);
+int seer_conv_out_dt(const void* x, int32_t B, int32_t C0, int32_t F, int32_t H, int32_t W_, const float* Wt,
+                     const float* bias, int32_t Cout, float* y, int32_t dtype, void* stream);
 
 /* pointwise channel mix on NCHW fp32: the VAE's post_quant_conv (1x1, 4->4; ldm/models/autoencoder.py:330-333).
  * W fp32 [Cout][Cin]. */

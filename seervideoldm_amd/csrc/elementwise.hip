@@ -133,6 +133,7 @@ __global__ void __launch_bounds__(256) linear_smallm_kernel(const float* __restr
 // ---- conv_in: [B, Cin, F, H, W] fp32 -> channels-last bf16 [B*F*H*W, Cout]; weights fp32 [3][3][Cin][Cout] ----
 // per block: the 9*Cin*Cout weights and the 3x3xCin input patches of its `ppb` pixels are staged in LDS once (every
 // output-channel group needs the same 9*Cin inputs); a thread owns 8 output channels of one pixel lane
+template <bool F16>
 __global__ void __launch_bounds__(256) conv_in_kernel(const float* __restrict__ x, int B, int Cin, int F, int H, int Wd,
                                                       const float* __restrict__ Wt, const float* __restrict__ bias,
                                                       int Cout, bf16* __restrict__ y, int ppb) {
@@ -182,13 +183,13 @@ __global__ void __launch_bounds__(256) conv_in_kernel(const float* __restrict__ 
 #pragma unroll
             for (int e = 0; e < 4; ++e) { acc[e] += xv * w0[e]; acc[4 + e] += xv * w1[e]; }
         }
-        *reinterpret_cast<u32x4*>(y + (p0 + pp) * Cout + cg * 8) = pack8(acc);
+        *reinterpret_cast<u32x4*>(y + (p0 + pp) * Cout + cg * 8) = pack8t<F16>(acc);
     }
 }
 
 // ---- conv_out: channels-last bf16 [B*F*H*W, C0] -> [B, Cout, F, H, W] fp32; weights fp32 [Cout][3][3][C0] -------
 // weights in LDS once per block; one wave per pixel (lanes over the 9 * C0/8 input chunks), `ppb` pixels per block
-template <int COUT>
+template <int COUT, bool F16 = false>
 __global__ void __launch_bounds__(256) conv_out_kernel(const bf16* __restrict__ x, int B, int C0, int F, int H, int Wd,
                                                        const float* __restrict__ Wt, const float* __restrict__ bias,
                                                        float* __restrict__ y, int ppb) {
@@ -217,7 +218,7 @@ __global__ void __launch_bounds__(256) conv_out_kernel(const bf16* __restrict__ 
             if (iy < 0 || iy >= H || ix < 0 || ix >= Wd) continue;
             const u32x4 v = *reinterpret_cast<const u32x4*>(x + ((img * H + iy) * Wd + ix) * C0 + ch * 8);
             float f[8];
-            unpack8(v, f);
+            unpack8t<F16>(v, f);
 #pragma unroll
             for (int o = 0; o < COUT; ++o) {
                 const float* w = wsm + (o * 9 + tap) * C0 + ch * 8;
@@ -479,31 +480,55 @@ extern "C" int seer_linear_smallm(const float* x, int32_t B, int32_t K, const vo
     return SEER_OK;
 }
 
+extern "C" int seer_conv_in_dt(const float* x, int32_t B, int32_t Cin, int32_t F, int32_t H, int32_t W_, const float* Wt,
+                               const float* bias, int32_t Cout, void* y, int32_t dtype, void* stream);
 extern "C" int seer_conv_in(const float* x, int32_t B, int32_t Cin, int32_t F, int32_t H, int32_t W_, const float* Wt,
                             const float* bias, int32_t Cout, void* y, void* stream) {
+    return seer_conv_in_dt(x, B, Cin, F, H, W_, Wt, bias, Cout, y, SEER_DT_BF16, stream);
+}
+extern "C" int seer_conv_in_dt(const float* x, int32_t B, int32_t Cin, int32_t F, int32_t H, int32_t W_, const float* Wt,
+                               const float* bias, int32_t Cout, void* y, int32_t dtype, void* stream) {
+    if (dtype != SEER_DT_BF16 && dtype != SEER_DT_F16) return SEER_EINVAL;
     if (!x || !Wt || !y || B <= 0 || Cin <= 0 || F <= 0 || H <= 0 || W_ <= 0 || Cout <= 0 || Cout % 8 || Cout > 2048)
         return SEER_EINVAL;
     const int ppb = 32;
     const size_t lds = ((size_t)9 * Cin * Cout + (size_t)ppb * 9 * Cin) * sizeof(float);
-    static std::atomic<bool> done{false};
-    const int rc = ensure_lds(conv_in_kernel, lds, &done);
+    static std::atomic<bool> done{false}, done16{false};
+    const int rc = dtype == SEER_DT_F16 ? ensure_lds(conv_in_kernel<true>, lds, &done16) : ensure_lds(conv_in_kernel<false>, lds, &done);
     if (rc != SEER_OK) return rc;
     const int64_t npix = (int64_t)B * F * H * W_;
-    hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(256), lds, S(stream), x, B, Cin, F, H, W_,
-                       Wt, bias, Cout, reinterpret_cast<bf16*>(y), ppb);
+    if (dtype == SEER_DT_F16)
+        hipLaunchKernelGGL(conv_in_kernel<true>, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(256), lds, S(stream), x, B, Cin, F, H, W_,
+                           Wt, bias, Cout, reinterpret_cast<bf16*>(y), ppb);
+    else
+        hipLaunchKernelGGL(conv_in_kernel<false>, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(256), lds, S(stream), x, B, Cin, F, H, W_,
+                           Wt, bias, Cout, reinterpret_cast<bf16*>(y), ppb);
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }
 
+extern "C" int seer_conv_out_dt(const void* x, int32_t B, int32_t C0, int32_t F, int32_t H, int32_t W_, const float* Wt,
+                                const float* bias, int32_t Cout, float* y, int32_t dtype, void* stream);
 extern "C" int seer_conv_out(const void* x, int32_t B, int32_t C0, int32_t F, int32_t H, int32_t W_, const float* Wt,
                              const float* bias, int32_t Cout, float* y, void* stream) {
+    return seer_conv_out_dt(x, B, C0, F, H, W_, Wt, bias, Cout, y, SEER_DT_BF16, stream);
+}
+extern "C" int seer_conv_out_dt(const void* x, int32_t B, int32_t C0, int32_t F, int32_t H, int32_t W_, const float* Wt,
+                                const float* bias, int32_t Cout, float* y, int32_t dtype, void* stream) {
+    if (dtype != SEER_DT_BF16 && dtype != SEER_DT_F16) return SEER_EINVAL;
     if (!x || !Wt || !y || B <= 0 || C0 <= 0 || C0 % 8 || F <= 0 || H <= 0 || W_ <= 0) return SEER_EINVAL;
     const int64_t npix = (int64_t)B * F * H * W_;
     const int ppb = 32;
     dim3 grid((unsigned)((npix + ppb - 1) / ppb));
     const size_t lds = (size_t)Cout * 9 * C0 * sizeof(float);
     const bf16* xb = reinterpret_cast<const bf16*>(x);
-    if (Cout == 4) {
+    if (dtype == SEER_DT_F16) {
+        if (Cout != 3) return SEER_ENOSYS;            // the VAE decoder's RGB head is the one fp16 consumer
+        static std::atomic<bool> done16{false};
+        const int rc = ensure_lds(conv_out_kernel<3, true>, lds, &done16);
+        if (rc != SEER_OK) return rc;
+        hipLaunchKernelGGL((conv_out_kernel<3, true>), grid, dim3(256), lds, S(stream), xb, B, C0, F, H, W_, Wt, bias, y, ppb);
+    } else if (Cout == 4) {
         static std::atomic<bool> done{false};
         const int rc = ensure_lds(conv_out_kernel<4>, lds, &done);
         if (rc != SEER_OK) return rc;

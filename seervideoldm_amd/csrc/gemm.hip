@@ -90,7 +90,30 @@ constexpr bool tile_colsum_ok() {
     return !PP8 && BN <= NT && BM * CPITCH + (NT / (BN / 2)) * BN * 8 <= (NS == 0 ? 2 : NS) * STAGE * (int)sizeof(bf16);
 }
 
-template <int BM, int BN, bool CONV, bool GEGLU, bool SPLIT, int NS, int WM = 2, int WN = 2>
+// F16: A, A2, W, residual and C hold IEEE half instead of bf16 (SEER_EPI_F16: the VAE, which the reference runs in fp32 --
+// 11 significand bits instead of 8 at the same MFMA rate).  Same 16-bit loads and LDS image; only the MFMA opcode and the
+// pack / unpack of the epilogue differ.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+template <bool F16>
+__device__ __forceinline__ f32x4 mma16(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ unsigned int pack2t(float lo, float hi) {
+    if constexpr (F16) return pack2h(lo, hi);
+    else return pack2(lo, hi);
+}
+template <bool F16>
+__device__ __forceinline__ f32x2 unpack2t(unsigned int v) {
+    if constexpr (F16) {
+        return f32x2{half_bits_to_f32(v), half_bits_to_f32(v >> 16)};
+    } else {
+        return f32x2{__builtin_bit_cast(float, v << 16), __builtin_bit_cast(float, v & 0xffff0000u)};
+    }
+}
+
+template <int BM, int BN, bool CONV, bool GEGLU, bool SPLIT, int NS, int WM = 2, int WN = 2, bool F16 = false>
 __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm_desc p) {
     constexpr int NT = 64 * WM * WN;               // threads per block
     constexpr int RPP = NT / 8;                    // tile rows staged per pass (8 lanes x 16 B cover one 128-B row)
@@ -325,7 +348,7 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mma16<F16>(wf[ks][j], af[ks][i], acc[i][j]);
     };
 
     if constexpr (PP8) {
@@ -429,7 +452,7 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
                 _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                \
                     _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
                         acc[4 * (R) + i][2 * (C) + j] =                                                                      \
-                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[4 * (R) + i][2 * (C) + j], 0, 0, 0); \
+                            mma16<F16>(fb[ks][j], fa[ks][i], acc[4 * (R) + i][2 * (C) + j]);                                                \
             __builtin_amdgcn_s_setprio(0);                                                                                   \
             barrier();                                                                                                       \
         } while (0)
@@ -553,7 +576,7 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mma16<F16>(wf[ks][j], af[ks][i], acc[i][j]);
         };
         {
         PSTAMP();
@@ -770,10 +793,11 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
                         const u32x2 rv = rpre[i][j];
-                        acc[i][j][0] += __builtin_bit_cast(float, rv[0] << 16);
-                        acc[i][j][1] += __builtin_bit_cast(float, rv[0] & 0xffff0000u);
-                        acc[i][j][2] += __builtin_bit_cast(float, rv[1] << 16);
-                        acc[i][j][3] += __builtin_bit_cast(float, rv[1] & 0xffff0000u);
+                        const f32x2 r01 = unpack2t<F16>(rv[0]), r23 = unpack2t<F16>(rv[1]);
+                        acc[i][j][0] += r01[0];
+                        acc[i][j][1] += r01[1];
+                        acc[i][j][2] += r23[0];
+                        acc[i][j][3] += r23[1];
                     }
                 }
             }
@@ -788,8 +812,8 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 u32x2 o;
-                o[0] = pack2(acc[i][j][0], acc[i][j][1]);
-                o[1] = pack2(acc[i][j][2], acc[i][j][3]);
+                o[0] = pack2t<F16>(acc[i][j][0], acc[i][j][1]);
+                o[1] = pack2t<F16>(acc[i][j][2], acc[i][j][3]);
                 *reinterpret_cast<u32x2*>(smem + at + i * 16 * CPITCH) = o;
             }
         }
@@ -860,23 +884,25 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
                     u32x2 rv;
                     if constexpr (RES_PRE) rv = rpre[i][j];
                     else rv = *reinterpret_cast<const u32x2*>(R + (int64_t)m * p.ldr + nc);
-                    v[0] += __builtin_bit_cast(float, rv[0] << 16);
-                    v[1] += __builtin_bit_cast(float, rv[0] & 0xffff0000u);
-                    v[2] += __builtin_bit_cast(float, rv[1] << 16);
-                    v[3] += __builtin_bit_cast(float, rv[1] & 0xffff0000u);
+                    const f32x2 r01 = unpack2t<F16>(rv[0]), r23 = unpack2t<F16>(rv[1]);
+                    v[0] += r01[0];
+                    v[1] += r01[1];
+                    v[2] += r23[0];
+                    v[3] += r23[1];
                 }
                 if (trans) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         if (out_f32) Cf[(int64_t)(nc + r) * p.ldc + m] = v[r];
+                        else if constexpr (F16) reinterpret_cast<_Float16*>(Cb)[(int64_t)(nc + r) * p.ldc + m] = (_Float16)v[r];
                         else Cb[(int64_t)(nc + r) * p.ldc + m] = (bf16)v[r];
                     }
                 } else if (out_f32) {
                     *reinterpret_cast<f32x4*>(Cf + (int64_t)m * p.ldc + nc) = f32x4{v[0], v[1], v[2], v[3]};
                 } else {
                     u32x2 o;
-                    o[0] = pack2(v[0], v[1]);
-                    o[1] = pack2(v[2], v[3]);
+                    o[0] = pack2t<F16>(v[0], v[1]);
+                    o[1] = pack2t<F16>(v[2], v[3]);
                     if (staged) {
                         const int row_l = wm * WTM + i * 16 + frow;
                         const int col_l = nc - (GEGLU ? (n0 >> 1) : n0);
@@ -916,7 +942,8 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
                     for (int r = rs; r < rows; r += CS_RS) {
                         const uint32_t v = *reinterpret_cast<const uint32_t*>(
                             smem + r * CPITCH + (CSWZ ? (chunk ^ (r & 15)) : chunk) * 16 + within);
-                        const float f0 = __builtin_bit_cast(float, v << 16), f1 = __builtin_bit_cast(float, v & 0xffff0000u);
+                        const f32x2 f01 = unpack2t<F16>(v);
+                        const float f0 = f01[0], f1 = f01[1];
                         s0 += f0; q0 += f0 * f0;
                         s1 += f1; q1 += f1 * f1;
                     }
@@ -1103,6 +1130,31 @@ int launch_tile(const seer_gemm_desc& d, hipStream_t st) {
 }
 
 template <int BM, int BN, int NS>
+std::once_flag g_tile_f16_lds_once;
+
+// SEER_EPI_F16 launches (the VAE): plain and conv, unsplit, the tiles AUTO reaches on the VAE's shapes
+template <int BM, int BN, int NS>
+int launch_tile_f16(const seer_gemm_desc& d, hipStream_t st) {
+    const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
+    dim3 grid(tiles_m * tiles_n, 1, d.batch > 1 ? d.batch : 1);
+    const size_t lds = (size_t)(NS == 0 ? 2 : NS) * (BM + BN) * BK * sizeof(bf16);
+    if (lds > 64 * 1024) {
+        std::call_once(g_tile_f16_lds_once<BM, BN, NS>, [lds] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, true, false, false, NS, 2, 2, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, false, false, false, NS, 2, 2, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        });
+    }
+    if (d.mode == SEER_GEMM_CONV3X3)
+        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, true, false, false, NS, 2, 2, true>), grid, dim3(256), lds, st, d);
+    else
+        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, false, false, NS, 2, 2, true>), grid, dim3(256), lds, st, d);
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+template <int BM, int BN, int NS>
 int launch_split_tile(const seer_gemm_desc& d, hipStream_t st) {
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, 1, d.splits);
@@ -1180,7 +1232,7 @@ int prepare(seer_gemm_desc& d, int* splits) {
 
     // split-K decision: few output tiles and a long K loop (deep-level convs / linears, M = 384 .. 1536)
     int s = 1;
-    const bool can_split = d.batch == 1 && !geglu && !(d.epilogue & (SEER_EPI_TRANS_OUT | SEER_EPI_ROTARY)) &&
+    const bool can_split = d.batch == 1 && !geglu && !(d.epilogue & (SEER_EPI_TRANS_OUT | SEER_EPI_ROTARY | SEER_EPI_F16)) &&
                            (d.tile == SEER_TILE_AUTO || d.tile == SEER_TILE_64x64 || d.tile == SEER_TILE_G64x64_3 ||
                             d.tile == SEER_TILE_G128x128_2 || d.tile == SEER_TILE_G96x160_2) &&
                            d.splits != 1;
@@ -1269,7 +1321,7 @@ int resolve_tile(const seer_gemm_desc& d) {
 // (reduced inside the launch; needs desc.workspace and desc.sync).
 //
 // AUTO takes it where a cost model calibrated on MI355X (profiles/r04_t320_*.log) puts it ahead of the smaller tiles:
-//   t = rounds * (K tiles per slice * 1.9 us [2.0 conv] + 7 us of prologue / epilogue) + slab bytes / 4.3 TB/s + 3 us
+//   t = rounds * (K tiles per slice * 1.9 us [2.0 conv] + 7 us of prologue / epilogue [12 GEGLU]) + slab bytes / 4.3 TB/s + 3 us
 // rounds = ceil(tiles * S / 256 CUs); slab bytes = 2 * tiles * S * 320 KB when S > 1 -- the partial tiles of a split launch go
 // through the fabric (write-through stores, sc1 loads) at HBM-like rates whatever the split, which is what keeps the big tile
 // away from the few-tile shapes of a 32x32-latent step: 256 workgroups x 320 KB x 2 = 164 MB = 38 us per split launch.
@@ -1281,7 +1333,8 @@ double t320_model_us(const seer_gemm_desc& d, int S) {
     const int rounds = (tiles * S + 255) / 256;
     const double t_iter = d.mode == SEER_GEMM_CONV3X3 ? 2.0 : 1.9;
     const double slab = S > 1 ? 2.0 * tiles * S * 327680.0 / 4.3e6 : 0.0;
-    return rounds * (((nk + S - 1) / S) * t_iter + 7.0) + slab + 3.0;
+    const double fixed = (d.epilogue & SEER_EPI_GEGLU) ? 12.0 : 7.0;      // prologue + epilogue of a tile (the erf epilogue: +5 us)
+    return rounds * (((nk + S - 1) / S) * t_iter + fixed) + slab + 3.0;
 }
 int t320_best_split(const seer_gemm_desc& d, bool can_split, double* t_best) {
     static const int cand[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
@@ -1435,7 +1488,7 @@ extern "C" int seer_gemm_bf16(const seer_gemm_desc* desc, void* stream) {
     }
     d.splits = 1;
     d.tile = desc->tile == SEER_TILE_T256x320 ? SEER_TILE_AUTO : desc->tile;            // prepare() may have picked a split tile; unsplit launches choose their own below
-    if (!d.colsum && seer_gemm_ws_eligible(d) &&
+    if (!d.colsum && !(d.epilogue & SEER_EPI_F16) && seer_gemm_ws_eligible(d) &&
         (requested == SEER_TILE_WS || (requested == SEER_TILE_AUTO && seer_gemm_ws_profitable(d)))) {
         const int rc_ws = seer_gemm_ws_launch(d, st);
         if (rc_ws != SEER_ENOSYS) return rc_ws;
@@ -1443,6 +1496,16 @@ extern "C" int seer_gemm_bf16(const seer_gemm_desc* desc, void* stream) {
     if (requested == SEER_TILE_WS || requested == SEER_TILE_AUTO_TILED) d.tile = SEER_TILE_AUTO;   // the tile kernel picks its own
 
     const int tile = resolve_tile(d);
+    if (d.epilogue & SEER_EPI_F16) {
+        if (d.colsum || (d.epilogue & (SEER_EPI_GEGLU | SEER_EPI_ROTARY))) return SEER_EINVAL;
+        switch (tile) {
+            case SEER_TILE_G128x128_2: return launch_tile_f16<128, 128, 2>(d, st);
+            case SEER_TILE_G128x64_3: return launch_tile_f16<128, 64, 3>(d, st);
+            case SEER_TILE_G64x64_5: return launch_tile_f16<64, 64, 5>(d, st);
+            case SEER_TILE_64x64: return launch_tile_f16<64, 64, 0>(d, st);
+            default: return d.K / BK >= 3 ? launch_tile_f16<64, 64, 3>(d, st) : launch_tile_f16<64, 64, 0>(d, st);
+        }
+    }
     return dispatch_tile(tile, [&](auto t) {
         using T = decltype(t);
         return launch_tile<T::BM, T::BN, T::NS, T::WM, T::WN>(d, st);

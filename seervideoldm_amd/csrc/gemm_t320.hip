@@ -622,7 +622,7 @@ std::once_flag g_t320_once;
 // what the kernel handles (gemm.hip decides WHEN to use it)
 bool seer_gemm_t320_eligible(const seer_gemm_desc& d) {
     if (d.N % 320 || d.K % 64 || d.M < 1) return false;
-    if (d.epilogue & (SEER_EPI_OUT_F32 | SEER_EPI_TRANS_OUT | SEER_EPI_SILU)) return false;
+    if (d.epilogue & (SEER_EPI_OUT_F32 | SEER_EPI_TRANS_OUT | SEER_EPI_SILU | SEER_EPI_F16)) return false;
     const bool geglu = (d.epilogue & SEER_EPI_GEGLU) != 0;
     if (geglu && (d.mode == SEER_GEMM_CONV3X3 || (d.epilogue & (SEER_EPI_ROTARY | SEER_EPI_COLSCALE)))) return false;
     if (d.ldc % 8 || (reinterpret_cast<uintptr_t>(d.C) & 15)) return false;

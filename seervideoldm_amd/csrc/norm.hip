@@ -21,6 +21,7 @@ struct GnGeom {
 // Statistics are DETERMINISTIC (no float atomics): every thread parks its per-column partial sums in LDS, `groups`
 // threads then add the contributions of their group in a fixed order and the block writes its partial
 // (sum, sumsq)[groups] to `partials[b][blk]`; gn_finalize_kernel adds the per-block partials in block order.
+template <bool F16>
 __global__ void __launch_bounds__(256) gn_stats_kernel(const bf16* __restrict__ x1, const bf16* __restrict__ x2,
                                                        GnGeom g, int64_t rows_per_batch, int groups,
                                                        float* __restrict__ partials) {
@@ -48,7 +49,7 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const bf16* __restrict__ 
             for (int64_t r = r0 + rl; r < r1; r += rows_par) {
                 const u32x4 v = *reinterpret_cast<const u32x4*>(src + ((int64_t)b * rows_per_batch + r) * ld);
                 float f[8];
-                unpack8(v, f);
+                unpack8t<F16>(v, f);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     if (e < split) { sa += f[e]; qa += f[e] * f[e]; }
@@ -150,6 +151,7 @@ __global__ void __launch_bounds__(256) gn_colsum_finalize_kernel(GnColsumSrc s1,
     }
 }
 
+template <bool F16>
 __global__ void __launch_bounds__(256) gn_apply_kernel(const bf16* __restrict__ x1, const bf16* __restrict__ x2,
                                                        GnGeom g, int64_t rows_per_batch, int groups,
                                                        const float* __restrict__ stats, float inv_count, float eps,
@@ -210,14 +212,14 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const bf16* __restrict__ 
             const int64_t row = (int64_t)b * rows_per_batch + r;
             const u32x4 v = *reinterpret_cast<const u32x4*>(src + row * ld);
             float f[8];
-            unpack8(v, f);
+            unpack8t<F16>(v, f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float o = f[e] * sc[e] + sh[e];
                 if (silu) o = silu_f(o);
                 f[e] = o;
             }
-            store16_out(y + row * C + c0, pack8(f));
+            store16_out(y + row * C + c0, pack8t<F16>(f));
         }
     }
 }
@@ -279,7 +281,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const bf16* __restrict__
 }
 
 // row softmax(x * scale): one wave per row, n <= 64*8*MAXC
-template <int MAXC, bool IN_F32>
+template <int MAXC, bool IN_F32, bool F16 = false>
 __global__ void __launch_bounds__(256) softmax_rows_kernel(const void* __restrict__ xv, int64_t rows, int n, int ld,
                                                            float scale, bf16* __restrict__ y, int ldy) {
     const int lane = threadIdx.x & 63;
@@ -299,7 +301,7 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(const void* __restric
                 for (int e = 0; e < 4; ++e) { f[i][e] = a[e]; f[i][4 + e] = b[e]; }
             } else {
                 const u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16*>(xv) + r * ld + ch * 8);
-                unpack8(v, f[i]);
+                unpack8t<F16>(v, f[i]);
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) { f[i][e] *= scale; mx = fmaxf(mx, f[i][e]); }
@@ -323,7 +325,7 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(const void* __restric
             float o[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = f[i][e] * inv;
-            *reinterpret_cast<u32x4*>(y + r * ldy + ch * 8) = pack8(o);
+            *reinterpret_cast<u32x4*>(y + r * ldy + ch * 8) = pack8t<F16>(o);
         }
     }
 }
@@ -358,9 +360,18 @@ extern "C" int64_t seer_groupnorm_workspace_floats(int32_t C, int32_t batch, int
     return (int64_t)batch * g.nblk * groups * 2;
 }
 
+extern "C" int seer_groupnorm_stats_dt(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t batch,
+                                       int64_t rows_per_batch, int32_t groups, float* stats, float* workspace,
+                                       int32_t dtype, void* stream);
 extern "C" int seer_groupnorm_stats(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t batch,
                                     int64_t rows_per_batch, int32_t groups, float* stats, float* workspace,
                                     void* stream) {
+    return seer_groupnorm_stats_dt(x1, C1, x2, C2, batch, rows_per_batch, groups, stats, workspace, SEER_DT_BF16, stream);
+}
+extern "C" int seer_groupnorm_stats_dt(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t batch,
+                                       int64_t rows_per_batch, int32_t groups, float* stats, float* workspace,
+                                       int32_t dtype, void* stream) {
+    if (dtype != SEER_DT_BF16 && dtype != SEER_DT_F16) return SEER_EINVAL;
     GnGeom g;
     if (!x1 || !stats || !workspace || batch <= 0 || rows_per_batch <= 0) return SEER_EINVAL;
     if (!x2) C2 = 0;
@@ -369,8 +380,12 @@ extern "C" int seer_groupnorm_stats(const void* x1, int32_t C1, const void* x2, 
     const int cpp = g.ncols < 256 ? g.ncols : 256;
     const size_t lds = (size_t)(256 / cpp) * g.ncols * 4 * sizeof(float);
     dim3 grid((unsigned)g.nblk, batch);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), lds, st, reinterpret_cast<const bf16*>(x1),
-                       reinterpret_cast<const bf16*>(x2), g, rows_per_batch, groups, workspace);
+    if (dtype == SEER_DT_F16)
+        hipLaunchKernelGGL(gn_stats_kernel<true>, grid, dim3(256), lds, st, reinterpret_cast<const bf16*>(x1),
+                           reinterpret_cast<const bf16*>(x2), g, rows_per_batch, groups, workspace);
+    else
+        hipLaunchKernelGGL(gn_stats_kernel<false>, grid, dim3(256), lds, st, reinterpret_cast<const bf16*>(x1),
+                           reinterpret_cast<const bf16*>(x2), g, rows_per_batch, groups, workspace);
     SEER_LAUNCH_CHECK();
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)((batch * groups * 2 + 3) / 4)), dim3(256), 0, st, workspace, g.nblk, groups,
                        batch, stats);
@@ -392,18 +407,35 @@ extern "C" int seer_groupnorm_stats_from_colsums(const float* cs1, int32_t C1, i
     return SEER_OK;
 }
 
+extern "C" int seer_groupnorm_apply_dt(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t batch,
+                                       int64_t rows_per_batch, int32_t groups, const float* stats, double count,
+                                       float eps, const float* gamma, const float* beta, int32_t silu, void* y,
+                                       int32_t dtype, void* stream);
 extern "C" int seer_groupnorm_apply(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t batch,
                                     int64_t rows_per_batch, int32_t groups, const float* stats, double count,
                                     float eps, const float* gamma, const float* beta, int32_t silu, void* y,
                                     void* stream) {
+    return seer_groupnorm_apply_dt(x1, C1, x2, C2, batch, rows_per_batch, groups, stats, count, eps, gamma, beta, silu, y,
+                                   SEER_DT_BF16, stream);
+}
+extern "C" int seer_groupnorm_apply_dt(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t batch,
+                                       int64_t rows_per_batch, int32_t groups, const float* stats, double count,
+                                       float eps, const float* gamma, const float* beta, int32_t silu, void* y,
+                                       int32_t dtype, void* stream) {
+    if (dtype != SEER_DT_BF16 && dtype != SEER_DT_F16) return SEER_EINVAL;
     GnGeom g;
     if (!x1 || !stats || !gamma || !beta || !y || batch <= 0 || rows_per_batch <= 0 || count <= 0) return SEER_EINVAL;
     if (!x2) C2 = 0;
     if (!gn_geom(C1, C2, groups, batch, rows_per_batch, &g)) return SEER_EINVAL;
     dim3 grid((unsigned)g.nblk, batch);
-    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       reinterpret_cast<const bf16*>(x1), reinterpret_cast<const bf16*>(x2), g, rows_per_batch, groups,
-                       stats, (float)(1.0 / count), eps, gamma, beta, silu, reinterpret_cast<bf16*>(y));
+    if (dtype == SEER_DT_F16)
+        hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           reinterpret_cast<const bf16*>(x1), reinterpret_cast<const bf16*>(x2), g, rows_per_batch, groups,
+                           stats, (float)(1.0 / count), eps, gamma, beta, silu, reinterpret_cast<bf16*>(y));
+    else
+        hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           reinterpret_cast<const bf16*>(x1), reinterpret_cast<const bf16*>(x2), g, rows_per_batch, groups,
+                           stats, (float)(1.0 / count), eps, gamma, beta, silu, reinterpret_cast<bf16*>(y));
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }
@@ -424,8 +456,15 @@ extern "C" int seer_layernorm(const void* x, int64_t rows, int32_t C, int32_t ld
     return SEER_OK;
 }
 
+extern "C" int seer_softmax_rows_dt(const void* x, int32_t x_is_f32, int64_t rows, int32_t n, int32_t ld, float scale,
+                                    void* y, int32_t ldy, int32_t dtype, void* stream);
 extern "C" int seer_softmax_rows(const void* x, int32_t x_is_f32, int64_t rows, int32_t n, int32_t ld, float scale,
                                  void* y, int32_t ldy, void* stream) {
+    return seer_softmax_rows_dt(x, x_is_f32, rows, n, ld, scale, y, ldy, SEER_DT_BF16, stream);
+}
+extern "C" int seer_softmax_rows_dt(const void* x, int32_t x_is_f32, int64_t rows, int32_t n, int32_t ld, float scale,
+                                    void* y, int32_t ldy, int32_t dtype, void* stream) {
+    if (dtype != SEER_DT_BF16 && dtype != SEER_DT_F16) return SEER_EINVAL;
     if (!x || !y || rows <= 0 || n <= 0 || n % 8 || ld % 8 || ldy % 8) return SEER_EINVAL;
     if (n > 64 * 8 * 8) return SEER_ENOSYS;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -433,7 +472,10 @@ extern "C" int seer_softmax_rows(const void* x, int32_t x_is_f32, int64_t rows, 
     dim3 grid((unsigned)((rows + 3) / 4));
 #define SEER_SM(MC)                                                                                                   \
     do {                                                                                                              \
-        if (x_is_f32) hipLaunchKernelGGL((softmax_rows_kernel<MC, true>), grid, dim3(256), 0, st, x, rows, n, ld, scale, yb, ldy); \
+        if (dtype == SEER_DT_F16) {                                                                                   \
+            if (x_is_f32) hipLaunchKernelGGL((softmax_rows_kernel<MC, true, true>), grid, dim3(256), 0, st, x, rows, n, ld, scale, yb, ldy); \
+            else hipLaunchKernelGGL((softmax_rows_kernel<MC, false, true>), grid, dim3(256), 0, st, x, rows, n, ld, scale, yb, ldy);         \
+        } else if (x_is_f32) hipLaunchKernelGGL((softmax_rows_kernel<MC, true>), grid, dim3(256), 0, st, x, rows, n, ld, scale, yb, ldy); \
         else hipLaunchKernelGGL((softmax_rows_kernel<MC, false>), grid, dim3(256), 0, st, x, rows, n, ld, scale, yb, ldy);         \
     } while (0)
     if (n <= 1024) SEER_SM(2);

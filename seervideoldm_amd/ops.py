@@ -35,6 +35,21 @@ def _req(t: torch.Tensor, dtype, name: str):
         raise _lib.SeerHipError(f"{name}: tensor must be on a ROCm device (no CPU fallback)")
 
 
+f16 = torch.float16
+
+
+def _req16(t: torch.Tensor, name: str, like: Optional[torch.Tensor] = None) -> int:
+    """16-bit activations / weights: bf16 (the UNet path) or IEEE half (the VAE path, SEER_EPI_F16 / SEER_DT_F16); all 16-bit
+    operands of one launch share the type.  Returns the SEER_DT_* code."""
+    if t.dtype not in (bf16, f16):
+        raise TypeError(f"{name}: expected torch.bfloat16 or torch.float16, got {t.dtype}")
+    if like is not None and t.dtype != like.dtype:
+        raise TypeError(f"{name}: {t.dtype} next to {like.dtype}: the 16-bit operands of a launch share one type")
+    if not t.is_cuda:
+        raise _lib.SeerHipError(f"{name}: tensor must be on a ROCm device (no CPU fallback)")
+    return _lib.SEER_DT_F16 if t.dtype == f16 else _lib.SEER_DT_BF16
+
+
 class ColSums:
     """Per-tile column sums a GEMM / conv left next to its output (seer_gemm_desc::colsum): buf [phases, tiles, C, 2] fp32 =
     (sum, sum of squares) of the stored bf16 values over each tile's rows.  groupnorm_stats_from_colsums turns them into
@@ -55,7 +70,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias=None, residual=None, rowvec=N
     rotary = (cos_sin table, tokens_per_batch, pos_offset, head_dim, rot_dim, cols): rotate columns < cols in the epilogue.
     col_scale = (factor, cols): multiply output columns < cols by factor (the q columns of a projection carry the softmax
     scale * log2(e) for attention(..., q_prescaled=True))."""
-    _req(a, bf16, "a"); _req(w, bf16, "w")
+    dt = _req16(a, "a"); _req16(w, "w", a)
     assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.is_contiguous()
     M, K1 = a.shape
     N, K = w.shape
@@ -63,7 +78,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias=None, residual=None, rowvec=N
     d.A, d.W = _p(a), _p(w)
     d.lda = a.stride(0)
     if a2 is not None:
-        _req(a2, bf16, "a2")
+        _req16(a2, "a2", a)
         assert a2.shape[0] == M and a2.stride(1) == 1 and K1 + a2.shape[1] == K
         d.A2, d.lda2 = _p(a2), a2.stride(0)
     else:
@@ -71,13 +86,13 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias=None, residual=None, rowvec=N
     d.M, d.N, d.K, d.K1 = M, N, K, K1
     n_out = N // 2 if geglu else N
     if out is None:
-        out = torch.empty((M, n_out), device=a.device, dtype=torch.float32 if out_f32 else bf16)
+        out = torch.empty((M, n_out), device=a.device, dtype=torch.float32 if out_f32 else a.dtype)
     assert out.shape == (M, n_out) and out.stride(1) == 1
     d.C, d.ldc = _p(out), out.stride(0)
     if bias is not None:
         _req(bias, torch.float32, "bias"); d.bias = _p(bias)
     if residual is not None:
-        _req(residual, bf16, "residual")
+        _req16(residual, "residual", a)
         assert residual.shape == (M, n_out) and residual.stride(1) == 1
         d.residual, d.ldr = _p(residual), residual.stride(0)
     if rowvec is not None:
@@ -86,7 +101,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias=None, residual=None, rowvec=N
         d.rowvec, d.rowvec_ld, d.rows_per_batch = _p(rowvec), rowvec.stride(0), rows_per_batch
     d.mode = _lib.SEER_GEMM_PLAIN
     d.epilogue = (_lib.SEER_EPI_GEGLU if geglu else 0) | (_lib.SEER_EPI_SILU if silu else 0) | \
-                 (_lib.SEER_EPI_OUT_F32 if (out.dtype == torch.float32) else 0)
+                 (_lib.SEER_EPI_OUT_F32 if (out.dtype == torch.float32) else 0) | (_lib.SEER_EPI_F16 if dt else 0)
+    assert out.dtype in (torch.float32, a.dtype)
     if rotary is not None:
         table, tpb, pos_off, hd, rd, cols = rotary
         _req(table, torch.float32, "rotary table")
@@ -154,7 +170,7 @@ def gemm_batched(a: torch.Tensor, w: torch.Tensor, *, trans_out=False, out: Opti
                  bias: Optional[torch.Tensor] = None, out_f32=False, tile=0, col_scale=None) -> torch.Tensor:
     """a [Bt, M, K], w [Bt, N, K] (or [N, K] shared) -> out [Bt, M, N] (or [Bt, N, M] with trans_out).
     col_scale = (factor, cols) as in gemm()."""
-    _req(a, bf16, "a"); _req(w, bf16, "w")
+    dt = _req16(a, "a"); _req16(w, "w", a)
     assert a.dim() == 3 and a.is_contiguous() and w.is_contiguous()
     Bt, M, K = a.shape
     N = w.shape[-2]
@@ -164,7 +180,7 @@ def gemm_batched(a: torch.Tensor, w: torch.Tensor, *, trans_out=False, out: Opti
     d.M, d.N, d.K, d.K1 = M, N, K, K
     if out is None:
         out = torch.empty((Bt, N, M) if trans_out else (Bt, M, N), device=a.device,
-                          dtype=torch.float32 if out_f32 else bf16)
+                          dtype=torch.float32 if out_f32 else a.dtype)
     d.C = _p(out)
     if bias is not None:
         _req(bias, torch.float32, "bias"); d.bias = _p(bias)
@@ -173,7 +189,8 @@ def gemm_batched(a: torch.Tensor, w: torch.Tensor, *, trans_out=False, out: Opti
     d.strideA = M * K
     d.strideW = N * K if w.dim() == 3 else 0
     d.strideC = M * N
-    d.epilogue = (_lib.SEER_EPI_TRANS_OUT if trans_out else 0) | (_lib.SEER_EPI_OUT_F32 if out.dtype == torch.float32 else 0)
+    d.epilogue = (_lib.SEER_EPI_TRANS_OUT if trans_out else 0) | (_lib.SEER_EPI_OUT_F32 if out.dtype == torch.float32 else 0) | \
+                 (_lib.SEER_EPI_F16 if dt else 0)
     if col_scale is not None:
         d.epilogue |= _lib.SEER_EPI_COLSCALE
         d.col_scale, d.col_scale_cols = float(col_scale[0]), int(col_scale[1])
@@ -187,7 +204,7 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, n_img: int, Hin: int, Win: int, *,
             tile=0, splits=0, pad_after_only=False, colsum_batch=0) -> torch.Tensor:
     """x: channels-last [n_img*Hin*Win, Cin] bf16; w: [Cout, 9*Cin] ((ky,kx,ci) order). Returns [n_img*Ho*Wo, Cout].
     pad_after_only: zero padding of one row / column only after the image (the VAE encoder's Downsample)."""
-    _req(x, bf16, "x"); _req(w, bf16, "w")
+    dt = _req16(x, "x"); _req16(w, "w", x)
     assert x.is_contiguous() and w.is_contiguous()
     Cin = x.shape[1]
     Cout, K = w.shape
@@ -200,18 +217,19 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, n_img: int, Hin: int, Win: int, *,
     d.A, d.W = _p(x), _p(w)
     d.M, d.N, d.K, d.K1 = M, Cout, K, K
     if out is None:
-        out = torch.empty((M, Cout), device=x.device, dtype=bf16)
+        out = torch.empty((M, Cout), device=x.device, dtype=x.dtype)
     d.C, d.ldc = _p(out), out.stride(0)
     if bias is not None:
         _req(bias, torch.float32, "bias"); d.bias = _p(bias)
     if residual is not None:
-        _req(residual, bf16, "residual")
+        _req16(residual, "residual", x)
         assert residual.shape == (M, Cout) and residual.stride(1) == 1
         d.residual, d.ldr = _p(residual), residual.stride(0)
     if rowvec is not None:
         _req(rowvec, torch.float32, "rowvec")
         d.rowvec, d.rowvec_ld, d.rows_per_batch = _p(rowvec), rowvec.stride(0), rows_per_batch
     d.mode = _lib.SEER_GEMM_CONV3X3
+    d.epilogue = _lib.SEER_EPI_F16 if dt else 0
     d.Hin, d.Win, d.Cin, d.Hout, d.Wout, d.stride, d.upsample = Hin, Win, Cin, Ho, Wo, stride, int(upsample)
     d.pad_after_only = int(pad_after_only)
     d.batch = 1
@@ -341,7 +359,9 @@ def rotary_inplace(x: torch.Tensor, col0_q: int, col0_k: int, heads: int, head_d
 def groupnorm_stats(x1: torch.Tensor, x2: Optional[torch.Tensor], batch: int, groups: int,
                     stats: torch.Tensor) -> torch.Tensor:
     """(sum, sumsq) per (b, g) -> stats [batch, groups, 2] fp32 (overwritten; deterministic two-stage reduction)."""
-    _req(x1, bf16, "x1")
+    dt = _req16(x1, "x1")
+    if x2 is not None:
+        _req16(x2, "x2", x1)
     assert x1.is_contiguous() and (x2 is None or x2.is_contiguous())
     rows = x1.shape[0] // batch
     C2 = 0 if x2 is None else x2.shape[1]
@@ -350,7 +370,7 @@ def groupnorm_stats(x1: torch.Tensor, x2: Optional[torch.Tensor], batch: int, gr
     if nws < 0:
         check(int(nws), "seer_groupnorm_workspace_floats")
     ws = torch.empty((nws,), device=x1.device, dtype=torch.float32)
-    check(lib.seer_groupnorm_stats(_p(x1), x1.shape[1], _p(x2), C2, batch, rows, groups, _p(stats), _p(ws),
+    check(lib.seer_groupnorm_stats_dt(_p(x1), x1.shape[1], _p(x2), C2, batch, rows, groups, _p(stats), _p(ws), dt,
                                    _stream()), "seer_groupnorm_stats")
     return stats
 
@@ -371,12 +391,14 @@ def groupnorm_apply(x1: torch.Tensor, x2: Optional[torch.Tensor], batch: int, gr
     rows = x1.shape[0] // batch
     C2 = 0 if x2 is None else x2.shape[1]
     Ct = x1.shape[1] + C2
+    dt = _req16(x1, "x1")
     if out is None:
-        out = torch.empty((x1.shape[0], Ct), device=x1.device, dtype=bf16)
+        out = torch.empty((x1.shape[0], Ct), device=x1.device, dtype=x1.dtype)
+    _req16(out, "out", x1)
     _req(gamma, torch.float32, "gamma"); _req(beta, torch.float32, "beta")
-    check(_lib.load().seer_groupnorm_apply(_p(x1), x1.shape[1], _p(x2), C2, batch, rows, groups, _p(stats),
-                                           float(count), float(eps), _p(gamma), _p(beta), int(silu), _p(out),
-                                           _stream()), "seer_groupnorm_apply")
+    check(_lib.load().seer_groupnorm_apply_dt(_p(x1), x1.shape[1], _p(x2), C2, batch, rows, groups, _p(stats),
+                                              float(count), float(eps), _p(gamma), _p(beta), int(silu), _p(out), dt,
+                                              _stream()), "seer_groupnorm_apply")
     return out
 
 
@@ -391,17 +413,18 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     return out
 
 
-def softmax_rows(x: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """softmax(scale * x) over the last dim; x bf16 or fp32 -> bf16."""
-    assert x.dtype in (bf16, torch.float32) and x.is_cuda
+def softmax_rows(x: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None, dtype=None) -> torch.Tensor:
+    """softmax(scale * x) over the last dim; x bf16 / fp16 / fp32 -> `dtype` (bf16 unless out / dtype say fp16)."""
+    assert x.dtype in (bf16, f16, torch.float32) and x.is_cuda
     x2 = x.reshape(-1, x.shape[-1])
     assert x2.is_contiguous()
     if out is None:
-        out = torch.empty(x.shape, device=x.device, dtype=bf16)
+        out = torch.empty(x.shape, device=x.device, dtype=dtype if dtype is not None else (x.dtype if x.dtype != torch.float32 else bf16))
     ldy = out.reshape(-1, out.shape[-1]).stride(0)        # `out` may be wider than x (zero-padded contraction of the next GEMM)
-    assert out.dtype == bf16 and out.shape[-1] >= x2.shape[1] and out.numel() // out.shape[-1] == x2.shape[0]
-    check(_lib.load().seer_softmax_rows(_p(x2), int(x.dtype == torch.float32), x2.shape[0], x2.shape[1], x2.stride(0),
-                                        float(scale), _p(out), ldy, _stream()), "seer_softmax_rows")
+    dt = _req16(out, "out", None if x.dtype == torch.float32 else x)
+    assert out.shape[-1] >= x2.shape[1] and out.numel() // out.shape[-1] == x2.shape[0]
+    check(_lib.load().seer_softmax_rows_dt(_p(x2), int(x.dtype == torch.float32), x2.shape[0], x2.shape[1], x2.stride(0),
+                                           float(scale), _p(out), ldy, dt, _stream()), "seer_softmax_rows")
     return out
 
 
@@ -439,14 +462,15 @@ def linear_smallm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]
     return y
 
 
-def conv_in(x: torch.Tensor, w_khwc: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
-    """x [B, Cin, F, H, W] fp32 -> [B*F*H*W, Cout] bf16 ; w_khwc fp32 [3,3,Cin,Cout]."""
+def conv_in(x: torch.Tensor, w_khwc: torch.Tensor, bias: torch.Tensor, dtype=bf16) -> torch.Tensor:
+    """x [B, Cin, F, H, W] fp32 -> [B*F*H*W, Cout] bf16 (or fp16) ; w_khwc fp32 [3,3,Cin,Cout]."""
     _req(x, torch.float32, "x"); _req(w_khwc, torch.float32, "w")
     assert x.is_contiguous()
     B, Cin, F, H, W = x.shape
     Cout = w_khwc.shape[-1]
-    y = torch.empty((B * F * H * W, Cout), device=x.device, dtype=bf16)
-    check(_lib.load().seer_conv_in(_p(x), B, Cin, F, H, W, _p(w_khwc), _p(bias), Cout, _p(y), _stream()),
+    y = torch.empty((B * F * H * W, Cout), device=x.device, dtype=dtype)
+    dt = _req16(y, "y")
+    check(_lib.load().seer_conv_in_dt(_p(x), B, Cin, F, H, W, _p(w_khwc), _p(bias), Cout, _p(y), dt, _stream()),
           "seer_conv_in")
     return y
 
@@ -455,10 +479,11 @@ def conv_out(x: torch.Tensor, w_ohwc: torch.Tensor, bias: torch.Tensor, B: int, 
     """x [B*F*H*W, C0] bf16 -> [B, Cout, F, H, W] fp32 ; w fp32 [Cout,3,3,C0] (direct kernel) or, for Cout % 4 == 0,
     bf16 [Cout, 9*C0] in conv3x3 packing: implicit-GEMM on the MFMA path, batched over B with a transposed fp32 store
     (the [Cout, F*H*W] planes of NCFHW are C^T of the per-sample GEMM)."""
-    _req(x, bf16, "x")
+    dt = _req16(x, "x")
     Cout = w_ohwc.shape[0]
     y = torch.empty((B, Cout, F, H, W), device=x.device, dtype=torch.float32)
-    if w_ohwc.dtype == bf16:
+    if w_ohwc.dtype in (bf16, f16):
+        _req16(w_ohwc, "w", x)
         C0 = x.shape[1]
         assert w_ohwc.dim() == 2 and w_ohwc.shape[1] == 9 * C0 and Cout % 4 == 0 and x.is_contiguous()
         M = F * H * W
@@ -469,14 +494,14 @@ def conv_out(x: torch.Tensor, w_ohwc: torch.Tensor, bias: torch.Tensor, B: int, 
         _req(bias, torch.float32, "bias")
         d.bias = _p(bias)
         d.mode = _lib.SEER_GEMM_CONV3X3
-        d.epilogue = _lib.SEER_EPI_TRANS_OUT | _lib.SEER_EPI_OUT_F32
+        d.epilogue = _lib.SEER_EPI_TRANS_OUT | _lib.SEER_EPI_OUT_F32 | (_lib.SEER_EPI_F16 if dt else 0)
         d.Hin, d.Win, d.Cin, d.Hout, d.Wout, d.stride, d.upsample = H, W, C0, H, W, 1, 0
         d.batch, d.strideA, d.strideW, d.strideC = B, M * C0, 0, Cout * M
         d.splits = 1
         _launch_gemm(d, x.device, "seer_gemm_bf16(conv_out)")
         return y
     _req(w_ohwc, torch.float32, "w")
-    check(_lib.load().seer_conv_out(_p(x), B, x.shape[1], F, H, W, _p(w_ohwc), _p(bias), Cout, _p(y), _stream()),
+    check(_lib.load().seer_conv_out_dt(_p(x), B, x.shape[1], F, H, W, _p(w_ohwc), _p(bias), Cout, _p(y), dt, _stream()),
           "seer_conv_out")
     return y
 

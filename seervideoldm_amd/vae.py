@@ -10,8 +10,11 @@ after the last row / column (encoder).  Parameters use the diffusers key layout 
 ...) so an SD-v1-5 `vae/diffusion_pytorch_model.bin` loads; `ldm_to_diffusers_vae` converts the
 vendored-ldm layout the CPU oracle uses.  A state dict may hold either half or both.
 
-Activations are channels-last bf16, accumulation fp32 (the reference runs its VAE in fp32: tolerance is stated in the
-parity tests).  The mid attention runs as batched MFMA GEMMs (q k^T -> fp32 scores -> row softmax -> p v) because d = 512
+Precision.  The reference never autocasts its VAE (inference_img.py:118: the VAE is not `prepare`d; it decodes in fp32).
+Activations and packed weights here are channels-last 16-bit with fp32 accumulation and fp32 GroupNorm / softmax
+statistics; `compute_dtype` picks the storage type: torch.float16 (default: 11 significand bits -- 8x tighter than bf16 at
+the same MFMA rate; the VAE's activations sit far inside fp16's range) or torch.bfloat16 (the UNet's type).  The parity
+tests state the bound for each.  The mid attention runs as batched MFMA GEMMs (q k^T -> fp32 scores -> row softmax -> p v) because d = 512
 is outside the flash kernel's head dims; V is produced transposed by its projection GEMM's epilogue.
 """
 from __future__ import annotations
@@ -151,8 +154,11 @@ class DiagonalGaussianDistribution:
 
 class AutoencoderKL(nn.Module):
     def __init__(self, in_channels=3, out_channels=3, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
-                 latent_channels=4, norm_num_groups=32, **ignored):
+                 latent_channels=4, norm_num_groups=32, compute_dtype=torch.float16, **ignored):
         super().__init__()
+        if compute_dtype not in (torch.float16, torch.bfloat16):
+            raise ValueError("AutoencoderKL.compute_dtype: torch.float16 or torch.bfloat16")
+        self.compute_dtype = compute_dtype
         self.config = _Config(in_channels=in_channels, out_channels=out_channels,
                               block_out_channels=tuple(block_out_channels), layers_per_block=layers_per_block,
                               latent_channels=latent_channels, norm_num_groups=norm_num_groups)
@@ -215,6 +221,7 @@ class AutoencoderKL(nn.Module):
     def prepare(self):
         dev = next(self.parameters()).device
         w = {}
+        bf16 = self.compute_dtype                      # storage type of every packed 16-bit weight below
         for k, v in self.state_dict().items():
             v = v.detach().to(dev, torch.float32)
             if k in ("decoder.conv_in.weight", "encoder.conv_in.weight"):
@@ -272,12 +279,12 @@ class AutoencoderKL(nn.Module):
         vt = ops.gemm_batched(h.reshape(N, HW, C), w[p + ".value.weight"], bias=w[p + ".value.bias"], trans_out=True)
         s = ops.gemm_batched(q, k, out_f32=True)                       # [N, HW, HW] fp32 scores
         if HW % 64 == 0:
-            pr = ops.softmax_rows(s, float(C) ** -0.5)                 # bf16 probabilities
+            pr = ops.softmax_rows(s, float(C) ** -0.5, dtype=self.compute_dtype)     # 16-bit probabilities
         else:       # small / odd latents (e.g. 8x12): the p @ v contraction needs a multiple of 64 -> zero-padded keys
             HWp = (HW + 63) // 64 * 64
-            pr = torch.zeros((N, HW, HWp), device=x.device, dtype=bf16)
+            pr = torch.zeros((N, HW, HWp), device=x.device, dtype=self.compute_dtype)
             ops.softmax_rows(s, float(C) ** -0.5, out=pr)
-            vp = torch.zeros((N, C, HWp), device=x.device, dtype=bf16)
+            vp = torch.zeros((N, C, HWp), device=x.device, dtype=self.compute_dtype)
             vp[:, :, :HW] = vt
             vt = vp
         o = ops.gemm_batched(pr, vt).reshape(N * HW, C)                # p @ v
@@ -300,7 +307,8 @@ class AutoencoderKL(nn.Module):
         if H % (1 << (nlev - 1)) or W % (1 << (nlev - 1)):
             raise ValueError("image height/width must be multiples of 2^(levels-1)")
         E = "encoder."
-        h = ops.conv_in(x.float().reshape(N, Cin, 1, H, W).contiguous(), w[E + "conv_in.weight"], w[E + "conv_in.bias"])
+        h = ops.conv_in(x.float().reshape(N, Cin, 1, H, W).contiguous(), w[E + "conv_in.weight"], w[E + "conv_in.bias"],
+                        dtype=self.compute_dtype)
         for i in range(nlev):
             for j in range(self.config.layers_per_block):
                 h = self._res(f"{E}down_blocks.{i}.resnets.{j}", h, N, H, W)
@@ -323,7 +331,7 @@ class AutoencoderKL(nn.Module):
         N, _, H, W = z.shape
         z = ops.conv1x1_nchw(z.float().contiguous(), w["post_quant_conv.weight"], w["post_quant_conv.bias"])
         D = "decoder."
-        x = ops.conv_in(z.reshape(N, z.shape[1], 1, H, W), w[D + "conv_in.weight"], w[D + "conv_in.bias"])
+        x = ops.conv_in(z.reshape(N, z.shape[1], 1, H, W), w[D + "conv_in.weight"], w[D + "conv_in.bias"], dtype=self.compute_dtype)
         x = self._mid(D, x, N, H, W)
         nlev = len(self.config.block_out_channels)
         for i in range(nlev):

@@ -235,22 +235,30 @@ def test_vae_decode_matches_oracle(device):
 def test_vae_decode_full_size_matches_oracle(device):
     """The decoder bench.py times and ddim_sample calls: the FULL SD-v1-5 VAE decoder (ch 128, ch_mult (1,2,4,4), two ResNets per
     level, 49.5 M parameters), one 32x32 latent -> 256x256 frame, against the fp32 oracle (622 GFLOP on the host cores).
-    Precision: the reference never autocasts its VAE (inference_img.py:118: the VAE is not `prepare`d, it decodes in fp32);
-    this path keeps activations in bf16 with fp32 accumulation like the UNet.  The bound is the UNet's calibrated one --
-    rel-L2 <= 3.0e-2 against fp32 -- and for the image itself, after ddim_sample's clamp((x+1)/2, 0, 1): mean |pixel error|
-    <= 2/255 of full scale (measured ~0.5/255)."""
+    Precision: the reference never autocasts its VAE (inference_img.py:118: the VAE is not `prepare`d, it decodes in fp32).
+    The default path stores activations and weights in fp16 (fp32 accumulation and statistics): the bounds below are for
+    THAT path against fp32 -- not the UNet's autocast calibration -- and the bf16-storage option is measured next to it (its
+    bound stays the UNet's: it is the same arithmetic the reference's own autocast mode would give a VAE).  After ddim_sample's
+    clamp((x+1)/2, 0, 1) the fp16 image is within 1/255 of the fp32 image at every pixel."""
     vsd = synth.synth_state_dict(synth.vae_param_shapes())
-    vae = AutoencoderKL()
-    vae.load_state_dict(ldm_to_diffusers_vae(vsd, 4), strict=True)
-    vae = vae.to(device)
     z = _randn((1, 4, 32, 32), 19)
     ref = O.vae_decode(vsd, z)
-    got = vae.decode(z.to(device)).sample
-    assert got.shape == (1, 3, 256, 256)
-    _check(got, ref, "vae decode, full SD decoder 32x32 -> 256x256")
-    px = (torch.clamp((got.cpu() + 1) / 2, 0, 1) - torch.clamp((ref + 1) / 2, 0, 1)).abs()
-    print(f"[parity] full-size VAE decode: mean |pixel error| {px.mean().item() * 255:.3f}/255, max {px.max().item() * 255:.2f}/255")
-    assert px.mean().item() <= 2 / 255
+    res = {}
+    for dt in (torch.float16, torch.bfloat16):
+        vae = AutoencoderKL(compute_dtype=dt)
+        vae.load_state_dict(ldm_to_diffusers_vae(vsd, 4), strict=True)
+        vae = vae.to(device)
+        got = vae.decode(z.to(device)).sample
+        assert got.shape == (1, 3, 256, 256) and torch.isfinite(got).all()
+        px = (torch.clamp((got.cpu() + 1) / 2, 0, 1) - torch.clamp((ref + 1) / 2, 0, 1)).abs()
+        res[dt] = (_rel(got, ref), px.mean().item() * 255, px.max().item() * 255)
+        print(f"[parity] full-size VAE decode, {dt}: rel_l2 {res[dt][0]:.4g}, mean |pixel error| {res[dt][1]:.3f}/255, "
+              f"max {res[dt][2]:.2f}/255")
+        del vae
+    r16, rb = res[torch.float16], res[torch.bfloat16]
+    assert r16[0] <= 5e-3 and r16[2] <= 1.0, r16            # fp16 storage vs the reference's fp32: every pixel within 1/255
+    assert rb[0] <= REL_L2 and rb[1] <= 2.0, rb             # bf16 storage: the UNet's calibrated bound
+    assert r16[0] < rb[0] / 3                               # ... and the reason fp16 is the default
 
 
 def test_return_attn_matches_oracle(device):
