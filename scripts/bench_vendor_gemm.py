@@ -36,6 +36,9 @@ SHAPES = [  # M, N, K, what
     (24576, 960, 320, "plain"), (6144, 1920, 640, "plain"), (1536, 3840, 1280, "plain"),
     (24576, 320, 320, "res"), (6144, 640, 640, "res"), (1536, 1280, 1280, "res"), (384, 1280, 1280, "res"),
     (4096, 4096, 4096, "plain"), (8192, 8192, 8192, "plain"),
+    # N a multiple of 320: AUTO takes the 256 x 320 tile kernel (gemm_t320.hip) where its cost model puts it ahead
+    (4096, 3840, 4096, "plain"), (8192, 7680, 8192, "plain"), (16384, 5120, 2560, "plain"),
+    (24576, 5120, 640, "geglu"), (6144, 10240, 1280, "geglu"), (98304, 320, 1280, "res"), (24576, 640, 2560, "res"),
 ]
 
 print(f"{'shape':28s} {'epilogue':8s} {'ours us':>9s} {'TF/s':>7s} | {'torch linear us':>15s} {'TF/s':>7s} | {'+ what torch still owes':s}")

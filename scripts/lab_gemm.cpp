@@ -156,8 +156,10 @@ int main(int argc, char** argv) {
             CK(hipMemcpy(hs.data(), dWs, 1 << 22, hipMemcpyDeviceToHost));
             for (int b : {0, 9}) for (int w : {0, 1, 2, 3, 4, 5, 6, 7}) {
                 const long long* t = hs.data() + ((size_t)b * 8 + w) * 64;
-                printf("  block %d wave %d hw_id %llx (10 ns ticks since start):", b, w, (unsigned long long)t[63]);
-                for (int i = 1; i < 63 && t[i]; ++i) printf(" %lld", t[i] - t[0]);
+                // LAB_STAMPS_ABS: every wave of a block relative to wave 0's first stamp (the clocks of one CU agree)
+                const long long base = getenv("LAB_STAMPS_ABS") ? hs[((size_t)b * 8) * 64] : t[0];
+                printf("  block %d wave %d hw_id %llx (ticks since start):", b, w, (unsigned long long)t[63]);
+                for (int i = getenv("LAB_STAMPS_ABS") ? 0 : 1; i < 63 && t[i]; ++i) printf(" %lld", t[i] - base);
                 printf("\n");
             }
         }

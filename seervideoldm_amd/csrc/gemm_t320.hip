@@ -38,6 +38,11 @@ constexpr int A_HALF = 128 * BK;                       // elements (16 KB)
 constexpr int B_HALF = 160 * BK;                       // elements (20 KB)
 constexpr int BUF = 2 * A_HALF + 2 * B_HALF;           // one K tile: [A r0 | A r1 | W c0 | W c1] = 72 KB
 constexpr int LDS_BYTES = 2 * BUF * 2 + 1024;          // two K tiles + 1 KB that absorbs the padding LDS-DMA pieces
+#ifdef SEER_T320_STAMPS
+constexpr int LDS_ALLOC = LDS_BYTES + 8 * 64 * 8;      // + the stamp area of the measurement build
+#else
+constexpr int LDS_ALLOC = LDS_BYTES;
+#endif
 constexpr int NQ = 40;                                 // accumulator quads (f32x4) per lane: 4 row fragments x 10 column fragments
 constexpr int SMAX = 16;                               // K slices per tile, at most
 constexpr int QMAX = 20;                               // quads of one slice's share (S >= 2)
@@ -55,10 +60,13 @@ __global__ void __launch_bounds__(NT) seer_gemm_t320_kernel(const seer_gemm_desc
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16* const smem_b = reinterpret_cast<bf16*>(smem);
     bf16* const dummy = smem_b + 2 * BUF;
+    // LDS-DMA destinations as LDS-address-space byte offsets from the start (a generic -> LDS cast per piece costs a null check)
+    typedef __attribute__((address_space(3))) unsigned char lds_byte;
+    lds_byte* const lds3 = (lds_byte*)smem;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: LDS-DMA destinations and region offsets live in SGPRs
     const int wm = wave >> 1, wn = wave & 1;
     const int grp = wave >> 2;                         // 1: runs one barrier behind
     const int frow = lane & 15, fq = lane >> 4;
@@ -134,6 +142,17 @@ __global__ void __launch_bounds__(NT) seer_gemm_t320_kernel(const seer_gemm_desc
         const int col = (lc / 80) * 160 + (lc % 80);
         b_rel[t] = pc < 20 ? (unsigned)(col * p.K + schunk) * 2u : (unsigned)schunk * 2u;   // (a padding piece re-reads row 0)
     }
+    // plain: LDS-DMA as buffer loads -- wave-uniform resource (the tile's first row), per-lane byte offset that is constant over K,
+    // scalar offset that advances with K: one s_mov m0 + one buffer_load per piece, no per-piece address arithmetic.  (The loop is
+    // bound by instruction ISSUE: in-kernel stamps, profiles/r04_t320_stamps.log -- a phase's 20 MFMAs take 160 issue cycles of
+    // their 320, the partner wave's reads + LDS-DMA + address arithmetic have to fit in the other 160.)
+    unsigned a_voff[4];                                // (row * lda + chunk) * 2 for the source the K loop is in
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a_voff[c] = (unsigned)(a_row[c] * p.lda + schunk) * 2u;
+    const __amdgpu_buffer_rsrc_t a1_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(A + (int64_t)m0 * p.lda), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t a2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(A2 ? A2 + (int64_t)m0 * p.lda2 : A), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(W + (int64_t)n0 * p.K), 0, 0x7fffffff, 0x00020000);
+    int a_second = 0;                                  // a_voff holds the offsets of A2 (wave-uniform)
     // conv: the input tensor as a raw buffer (bytes; eligibility keeps it under 2 GB)
     const unsigned a_bytes = CONV ? (unsigned)((int64_t)(p.M / ((p.upsample == 2 ? p.Hin * p.Win : p.Hout * p.Wout))) * p.Hin * p.Win * p.Cin * 2) : 0u;
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(A), 0, (int)a_bytes, 0x00020000);
@@ -147,7 +166,7 @@ __global__ void __launch_bounds__(NT) seer_gemm_t320_kernel(const seer_gemm_desc
         if (u >= T) return;
 #if !(SEER_T320_PROBE & 1)
         const int kbase = (kt0 + u) * BK;
-        bf16* dst = smem_b + (u & 1) * BUF + rr * A_HALF + (16 * wave) * BK;
+        lds_byte* const dst = lds3 + (((u & 1) * BUF + rr * A_HALF + (16 * wave) * BK) * 2);
         if constexpr (CONV) {
             // LDS-DMA through a buffer resource over the input tensor: a lane whose tap falls outside the image asks for the byte
             // just past the tensor and the bounds check returns zeros -- no zero page, no 64-bit address select, no branch
@@ -160,19 +179,19 @@ __global__ void __launch_bounds__(NT) seer_gemm_t320_kernel(const seer_gemm_desc
             for (int c = 0; c < 2; ++c) {
                 const bool ok = ((a_ok[rr] >> (9 * c + tap)) & 1u) != 0u;
                 const unsigned voff = ok ? (unsigned)(a_pix[rr * 2 + c] + tap_b) : a_bytes;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(dst + 8 * c * BK), 16, voff,
-                                                         ci0 * 2, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, dst + 8 * c * BK * 2, 16, voff, ci0 * 2, 0, 0);
             }
         } else {
             const bool second = kbase >= p.K1;
-            const unsigned char* base = second ? reinterpret_cast<const unsigned char*>(A2 + (int64_t)m0 * p.lda2 + (kbase - p.K1))
-                                               : reinterpret_cast<const unsigned char*>(A + (int64_t)m0 * p.lda + kbase);
-            const int ld = second ? p.lda2 : p.lda;
+            if ((int)second != __builtin_amdgcn_readfirstlane(a_second)) {                 // (once per tile, at the seam of a two-source K: the skip concat)
+                a_second = (int)second;
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const unsigned voff = (unsigned)(a_row[rr * 2 + c] * ld + schunk) * 2u;
-                lds_dma16(base + voff, dst + 8 * c * BK);
+                for (int c = 0; c < 4; ++c) a_voff[c] = (unsigned)(a_row[c] * (second ? p.lda2 : p.lda) + schunk) * 2u;
             }
+            const int soff = (second ? kbase - p.K1 : kbase) * 2;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? a2_rsrc : a1_rsrc, dst + 8 * c * BK * 2, 16, a_voff[rr * 2 + c], soff, 0, 0);
         }
 #endif
     };
@@ -180,12 +199,13 @@ __global__ void __launch_bounds__(NT) seer_gemm_t320_kernel(const seer_gemm_desc
         if (u >= T) return;
 #if !(SEER_T320_PROBE & 1)
         const int kbase = (kt0 + u) * BK;
-        bf16* dst = smem_b + (u & 1) * BUF + 2 * A_HALF + cc * B_HALF + (8 * wave) * BK;
-        const unsigned char* wbase = reinterpret_cast<const unsigned char*>(W + (int64_t)(n0 + 80 * cc) * p.K + kbase);
+        lds_byte* const dst = lds3 + (((u & 1) * BUF + 2 * A_HALF + cc * B_HALF + (8 * wave) * BK) * 2);
+        const int soff = (80 * cc * p.K + kbase) * 2;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) lds_dma16(wbase + b_rel[t], dst + 64 * t * BK);
+        for (int t = 0; t < 2; ++t)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, dst + 64 * t * BK * 2, 16, b_rel[t], soff, 0, 0);
         // third piece: waves 4..7 have none -- theirs lands in the spare 1 KB, so that every wave counts 3 per W region
-        lds_dma16(wbase + b_rel[2], wave < 4 ? dst + 128 * BK : dummy);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, wave < 4 ? dst + 128 * BK * 2 : lds3 + 2 * BUF * 2, 16, b_rel[2], soff, 0, 0);
 #endif
     };
 
@@ -218,6 +238,20 @@ __global__ void __launch_bounds__(NT) seer_gemm_t320_kernel(const seer_gemm_desc
         __builtin_amdgcn_sched_barrier(0);
     };
 
+#ifdef SEER_T320_STAMPS
+    // measurement build (scripts/run_r04_t320_stamps.sh): s_memtime (shader cycles) when the wave ARRIVES at each of the two
+    // barriers of a phase (reads landed + LDS-DMA issued | MFMAs issued), K tiles 4..10, lane 0 of every wave of blocks 0..15, parked in the spare LDS behind the K-loop buffers and copied to desc.workspace
+    // [block][wave][64] at the end (slot 63: hardware id).  Unsplit launches only.
+    long long* const st_lds = reinterpret_cast<long long*>(smem + LDS_BYTES) + wave * 64;
+    int st_n = 0;
+    const bool st_on = blockIdx.x < 16 && lane == 0 && p.workspace != nullptr;
+#define TSTAMP(u_)                                                                                     \
+    do {                                                                                               \
+        if (st_on && (u_) >= 4 && (u_) < 11 && st_n < 62) st_lds[st_n++] = (long long)__builtin_readcyclecounter();              \
+    } while (0)
+#else
+#define TSTAMP(u_) do { } while (0)
+#endif
     f32x4 acc[4][10];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -238,13 +272,20 @@ __global__ void __launch_bounds__(NT) seer_gemm_t320_kernel(const seer_gemm_desc
                     acc[2 * (R) + i][5 * (C) + j] =                                                                          \
                         __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[2 * (R) + i][5 * (C) + j], 0, 0, 0);
 #endif
+#ifndef SEER_T320_PRIO
+#define SEER_T320_PRIO 1       // wave priority while it multiplies: 1 = raised (the template's form), 0 = left alone, -1 = raised while it LOADS instead
+#endif
 #define SEER_T320_MMA(R, C)                                                                                                  \
         do {                                                                                                                 \
+            TSTAMP(u);                                                                                                       \
+            if (SEER_T320_PRIO < 0) __builtin_amdgcn_s_setprio(0);                                                           \
             barrier();                                                                                                       \
-            __builtin_amdgcn_s_setprio(1);                                                                                   \
+            if (SEER_T320_PRIO > 0) __builtin_amdgcn_s_setprio(1);                                                           \
             SEER_T320_MFMA(R, C)                                                                                             \
-            __builtin_amdgcn_s_setprio(0);                                                                                   \
+            if (SEER_T320_PRIO > 0) __builtin_amdgcn_s_setprio(0);                                                           \
+            TSTAMP(u);                                                                                                       \
             barrier();                                                                                                       \
+            if (SEER_T320_PRIO < 0) __builtin_amdgcn_s_setprio(1);                                                           \
         } while (0)
 
     // prologue: K tile 0 whole (10 pieces per wave), K tile 1 except its A r0 (8 pieces; A r0 goes out in phase 0 of tile 0)
@@ -253,7 +294,9 @@ __global__ void __launch_bounds__(NT) seer_gemm_t320_kernel(const seer_gemm_desc
     if (T > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     barrier();
+#ifndef SEER_T320_NOSTAGGER
     if (grp == 1) barrier();                           // waves 4..7 run one barrier behind from here on
+#endif
     for (int u = 0; u < T; ++u) {
         // phase 0: quadrant (r0, c0)
         read_b(u, 0);
@@ -282,7 +325,11 @@ __global__ void __launch_bounds__(NT) seer_gemm_t320_kernel(const seer_gemm_desc
     }
 #undef SEER_T320_MMA
 #undef SEER_T320_MFMA
+#ifndef SEER_T320_NOSTAGGER
     if (grp == 0) barrier();                           // re-align the two halves: every wave is done with the K-loop LDS
+#else
+    barrier();
+#endif
 
     // =========================================================================================================================
     // epilogue.  acc[i][j][r] = C[m0 + 64 wm + 16 i + frow][n0 + 160 wn + 16 j + 4 fq + r]
@@ -612,6 +659,14 @@ __global__ void __launch_bounds__(NT) seer_gemm_t320_kernel(const seer_gemm_desc
             }
         }
     }
+#ifdef SEER_T320_STAMPS
+    if (st_on) {
+        long long* o = reinterpret_cast<long long*>(p.workspace) + ((int64_t)blockIdx.x * 8 + wave) * 64;
+        for (int i = 0; i < 62; ++i) o[i] = i < st_n ? st_lds[i] : 0;
+        o[62] = 0;
+        o[63] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));       // HW_REG_HW_ID
+    }
+#endif
 }
 
 std::once_flag g_t320_once;
@@ -657,11 +712,11 @@ int64_t seer_gemm_t320_sync_bytes(const seer_gemm_desc& d, int splits) {
 int seer_gemm_t320_launch(const seer_gemm_desc& d0, int splits, hipStream_t st) {
     seer_gemm_desc d = d0;
     std::call_once(g_t320_once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_t320_kernel<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_t320_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_t320_kernel<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_t320_kernel<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_t320_kernel<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_t320_kernel<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_t320_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_t320_kernel<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_t320_kernel<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_t320_kernel<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
     });
     const bool conv = d.mode == SEER_GEMM_CONV3X3;
     const bool geglu = (d.epilogue & SEER_EPI_GEGLU) != 0;
@@ -673,14 +728,14 @@ int seer_gemm_t320_launch(const seer_gemm_desc& d0, int splits, hipStream_t st) 
         if (!d.sync || d.sync_bytes < seer_gemm_t320_sync_bytes(d, splits)) return SEER_EINVAL;
         d.splits = splits;
         dim3 grid(tiles * splits, 1, 1);
-        if (conv) hipLaunchKernelGGL((seer_gemm_t320_kernel<true, false, true>), grid, dim3(NT), LDS_BYTES, st, d);
-        else hipLaunchKernelGGL((seer_gemm_t320_kernel<false, false, true>), grid, dim3(NT), LDS_BYTES, st, d);
+        if (conv) hipLaunchKernelGGL((seer_gemm_t320_kernel<true, false, true>), grid, dim3(NT), LDS_ALLOC, st, d);
+        else hipLaunchKernelGGL((seer_gemm_t320_kernel<false, false, true>), grid, dim3(NT), LDS_ALLOC, st, d);
     } else {
         d.splits = 1;
         dim3 grid(tiles, 1, batch);
-        if (conv) hipLaunchKernelGGL((seer_gemm_t320_kernel<true, false, false>), grid, dim3(NT), LDS_BYTES, st, d);
-        else if (geglu) hipLaunchKernelGGL((seer_gemm_t320_kernel<false, true, false>), grid, dim3(NT), LDS_BYTES, st, d);
-        else hipLaunchKernelGGL((seer_gemm_t320_kernel<false, false, false>), grid, dim3(NT), LDS_BYTES, st, d);
+        if (conv) hipLaunchKernelGGL((seer_gemm_t320_kernel<true, false, false>), grid, dim3(NT), LDS_ALLOC, st, d);
+        else if (geglu) hipLaunchKernelGGL((seer_gemm_t320_kernel<false, true, false>), grid, dim3(NT), LDS_ALLOC, st, d);
+        else hipLaunchKernelGGL((seer_gemm_t320_kernel<false, false, false>), grid, dim3(NT), LDS_ALLOC, st, d);
     }
     SEER_LAUNCH_CHECK();
     return SEER_OK;
