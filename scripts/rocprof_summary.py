@@ -45,9 +45,9 @@ def main():
     print("| instantiation | calls | avg us | total ms |")
     print("|---|---:|---:|---:|")
     for n, c, t in sorted(inst, key=lambda x: -x[2]):
-        if "seer_gemm_kernel" in n:
-            m = re.search(r"seer_gemm_kernel<([^>]*)>", n)
-            print(f"| `<{m.group(1) if m else '?'}>` | {c} | {t / c / 1e3:.2f} | {t / 1e6:.3f} |")
+        if "seer_gemm_kernel" in n or "seer_gemm_t320_kernel" in n:
+            m = re.search(r"seer_gemm(_t320)?_kernel<([^>]*)>", n)
+            print(f"| `{'t320' if m and m.group(1) else ''}<{m.group(2) if m else '?'}>` | {c} | {t / c / 1e3:.2f} | {t / 1e6:.3f} |")
 
 
 if __name__ == "__main__":
