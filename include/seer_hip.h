@@ -266,6 +266,14 @@ int seer_groupnorm_stats_from_colsums(const float* cs1, int32_t C1, int32_t phas
 int seer_groupnorm_apply(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t batch,
                          int64_t rows_per_batch, int32_t groups, const float* stats, double count, float eps,
                          const float* gamma, const float* beta, int32_t silu, void* y, void* stream);
+/* seer_groupnorm_stats_from_colsums + seer_groupnorm_apply in ONE launch: every block re-derives the statistics of the groups it
+ * normalises from the producers' column sums (same arguments as the two calls; bf16 activations).  Single-process runs only: a
+ * frame-sharded run has to all-reduce the statistics between the two steps and keeps the two calls.  SEER_ENOSYS when the
+ * channel layout does not slice into whole groups of 64..128 channels (the caller then makes the two calls). */
+int seer_groupnorm_apply_from_colsums(const void* x1, int32_t C1, const void* x2, int32_t C2, const float* cs1, int32_t phases1,
+                                      int32_t tiles1, const float* cs2, int32_t phases2, int32_t tiles2, int32_t batch,
+                                      int64_t rows_per_batch, int32_t groups, double count, float eps, const float* gamma,
+                                      const float* beta, int32_t silu, void* y, void* stream);
 /* the same two with the storage type of x1 / x2 / y chosen by `dtype` (SEER_DT_*): the VAE's nn.GroupNorm(32, eps 1e-6)
  * (ldm/modules/diffusionmodules/model.py:38-40) on fp16 activations */
 int seer_groupnorm_stats_dt(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t batch,

@@ -24,6 +24,7 @@ SEER_EPI_TRANS_OUT = 8
 SEER_EPI_ROTARY = 16
 SEER_EPI_COLSCALE = 32
 SEER_EPI_F16 = 64
+SEER_ENOSYS = -38
 SEER_DT_BF16, SEER_DT_F16 = 0, 1
 SEER_ATTN_Q_PRESCALED = 1
 SEER_TILE_AUTO, SEER_TILE_128x128, SEER_TILE_64x64, SEER_TILE_128x64 = 0, 1, 2, 3
@@ -97,6 +98,8 @@ SIGNATURES = {
     "seer_groupnorm_stats": ([_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _vp], C.c_int),
     "seer_groupnorm_stats_from_colsums": ([_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp], C.c_int),
     "seer_groupnorm_apply": ([_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _f64, _f32, _vp, _vp, _i32, _vp, _vp], C.c_int),
+    "seer_groupnorm_apply_from_colsums": ([_vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i64, _i32, _f64, _f32, _vp, _vp,
+                                           _i32, _vp, _vp], C.c_int),
     "seer_groupnorm_stats_dt": ([_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _i32, _vp], C.c_int),
     "seer_groupnorm_apply_dt": ([_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _f64, _f32, _vp, _vp, _i32, _vp, _i32, _vp], C.c_int),
     "seer_softmax_rows_dt": ([_vp, _i32, _i64, _i32, _i32, _f32, _vp, _i32, _i32, _vp], C.c_int),

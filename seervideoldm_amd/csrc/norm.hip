@@ -224,6 +224,162 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const bf16* __restrict__ 
     }
 }
 
+// GroupNorm apply with the statistics taken from the producers' column sums INSIDE the launch (no seer_groupnorm_stats_from_colsums
+// launch in front: 75 of the 77 GroupNorms of a step paid a 5.6 us latency-bound launch + a graph-node boundary for a 512-byte
+// result).  A block owns a SLICE of whole groups (sc = 80 or 120 channels: >= 128 B of every row it touches) and a row range; it
+// first re-derives the (mean, rstd) of its own groups from the (tile, channel) partials of that slice -- thread <-> one channel of
+// the slice and one tile lane, fixed order, parked in LDS, one thread per group adds them in order: deterministic, no atomics --
+// and then streams its rows.  The partials of a slice are tpb * sc * 8 bytes (82 KB at the 32x32 level, L2-resident) and every
+// row block of the slice re-reads them: the grid is sized to ~2 blocks per CU so that the redundancy stays ~40 MB per launch.
+struct GnCsGeom {
+    int C1, C2, cpg, groups;
+    int sc;             // channels per slice (a whole number of groups, a multiple of 8)
+    int nslice, nrowblk;
+    int rpb;            // rows per row block
+};
+__global__ void __launch_bounds__(256) gn_apply_cs_kernel(const bf16* __restrict__ x1, const bf16* __restrict__ x2, GnColsumSrc s1,
+                                                          GnColsumSrc s2, GnCsGeom g, int batch, int64_t rows_per_batch,
+                                                          float inv_count, float eps, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int silu, bf16* __restrict__ y) {
+    __shared__ float part[12][128][2];                  // [tile lane][channel of the slice][sum, sumsq]
+    __shared__ float mean_s[16], rstd_s[16];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int slice = blockIdx.x % g.nslice, rb = blockIdx.x / g.nslice;
+    const int c_lo = slice * g.sc;                      // first concat channel of the slice
+    // ---- statistics of the slice's groups.  thread <-> (tile lane, quad of 4 channels): 32 contiguous bytes of a partial row per
+    // item, 8..12 tile lanes, four items (eight 16-byte loads) in flight -- three dependent rounds at the 32x32 level instead of
+    // the eleven a channel-per-thread form needs
+    const int nq = g.sc / 4;                            // channel quads in the slice (20 or 30)
+    const int ntl = 256 / nq;                           // tile lanes (12 or 8)
+    {
+        const int tl = tid / nq, cq = tid - tl * nq;
+        if (tl < ntl) {
+            const int c = c_lo + cq * 4;
+            const GnColsumSrc& s = c < s1.C ? s1 : s2;
+            const int cl = c < s1.C ? c : c - s1.C;
+            const int tpb = s.tiles / batch;
+            const int items = s.phases * tpb;
+            const float* base = s.cs + ((int64_t)b * tpb * s.C + cl) * 2;
+            f32x4 a01 = {0.f, 0.f, 0.f, 0.f}, a23 = {0.f, 0.f, 0.f, 0.f};     // (s, q) of channels 0, 1 | 2, 3
+            auto at = [&](int i) -> const float* {
+                const int ph = i / tpb, t = i - ph * tpb;
+                return base + ((int64_t)ph * s.tiles + t) * s.C * 2;
+            };
+            int i = tl;
+            for (; i + 3 * ntl < items; i += 4 * ntl) {
+                const float *p0 = at(i), *p1 = at(i + ntl), *p2 = at(i + 2 * ntl), *p3 = at(i + 3 * ntl);
+                const f32x4 u0 = *reinterpret_cast<const f32x4*>(p0), w0 = *reinterpret_cast<const f32x4*>(p0 + 4);
+                const f32x4 u1 = *reinterpret_cast<const f32x4*>(p1), w1 = *reinterpret_cast<const f32x4*>(p1 + 4);
+                const f32x4 u2 = *reinterpret_cast<const f32x4*>(p2), w2 = *reinterpret_cast<const f32x4*>(p2 + 4);
+                const f32x4 u3 = *reinterpret_cast<const f32x4*>(p3), w3 = *reinterpret_cast<const f32x4*>(p3 + 4);
+                a01 += u0; a23 += w0;
+                a01 += u1; a23 += w1;
+                a01 += u2; a23 += w2;
+                a01 += u3; a23 += w3;
+            }
+            for (; i < items; i += ntl) {
+                const float* p0 = at(i);
+                a01 += *reinterpret_cast<const f32x4*>(p0);
+                a23 += *reinterpret_cast<const f32x4*>(p0 + 4);
+            }
+            *reinterpret_cast<f32x4*>(&part[tl][cq * 4][0]) = a01;
+            *reinterpret_cast<f32x4*>(&part[tl][cq * 4 + 2][0]) = a23;
+        }
+    }
+    __syncthreads();
+    const int gs = g.sc / g.cpg;                        // groups in the slice
+    // tile lanes first (one thread per channel, fixed order), then one WAVE per group: lane l adds channels l, l + 64 of the
+    // group and the 64 lane sums meet in the fixed butterfly of wave_sum -- the serial form (one thread walking cpg x tile-lane
+    // LDS entries) cost 12 us on its own at cpg = 40..80
+    if (tid < g.sc) {
+        float sm = 0.f, sq = 0.f;
+        for (int tl = 0; tl < ntl; ++tl) {
+            sm += part[tl][tid][0];
+            sq += part[tl][tid][1];
+        }
+        part[0][tid][0] = sm;
+        part[0][tid][1] = sq;
+    }
+    __syncthreads();
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+        for (int gi = wv; gi < gs; gi += 4) {
+            float sm = 0.f, sq = 0.f;
+            for (int ch = lane; ch < g.cpg; ch += 64) {
+                sm += part[0][gi * g.cpg + ch][0];
+                sq += part[0][gi * g.cpg + ch][1];
+            }
+            sm = wave_sum(sm);
+            sq = wave_sum(sq);
+            if (lane == 0) {
+                const float mean = sm * inv_count;
+                float var = sq * inv_count - mean * mean;
+                var = var > 0.f ? var : 0.f;
+                mean_s[gi] = mean;
+                rstd_s[gi] = rsqrtf(var + eps);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- apply: thread -> (row lane, 16-byte chunk of the slice)
+    const int cps = g.sc / 8;
+    const int rows_par = 256 / cps;
+    const int rl = tid / cps, cl = tid - rl * cps;
+    if (rl >= rows_par) return;
+    const int C = g.C1 + g.C2;
+    const int c0 = c_lo + cl * 8;                       // first concat channel of this thread's chunk
+    const bool first = c0 < g.C1;
+    const bf16* src = first ? x1 + c0 : x2 + (c0 - g.C1);
+    const int ld = first ? g.C1 : g.C2;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int grp = (cl * 8 + e) / g.cpg;
+        const float a = rstd_s[grp] * gamma[c0 + e];
+        sc[e] = a;
+        sh[e] = beta[c0 + e] - mean_s[grp] * a;
+    }
+    const int64_t r0 = (int64_t)rb * g.rpb;
+    const int64_t r1 = min(r0 + g.rpb, rows_per_batch);
+#pragma unroll 4
+    for (int64_t r = r0 + rl; r < r1; r += rows_par) {
+        const int64_t row = (int64_t)b * rows_per_batch + r;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(src + row * ld);
+        float f[8];
+        unpack8(v, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float o = f[e] * sc[e] + sh[e];
+            if (silu) o = silu_f(o);
+            f[e] = o;
+        }
+        store16_out(y + row * C + c0, pack8(f));
+    }
+}
+
+// slice geometry for gn_apply_cs_kernel; false: this GroupNorm keeps the two-launch form
+bool gn_cs_geom(int C1, int C2, int groups, int batch, int64_t rows_per_batch, GnCsGeom* g) {
+    const int C = C1 + C2;
+    if (C1 <= 0 || C2 < 0 || groups <= 0 || groups > 64 || C % groups || C1 % 8 || C2 % 8) return false;
+    g->C1 = C1; g->C2 = C2; g->groups = groups; g->cpg = C / groups;
+    int sc = 0;
+    for (int k = 1; k * g->cpg <= 128; ++k)
+        if (k * g->cpg >= 64 && (k * g->cpg) % 8 == 0 && groups % k == 0) { sc = k * g->cpg; break; }
+    if (!sc || sc / g->cpg > 16) return false;
+    g->sc = sc;
+    g->nslice = C / sc;
+    int nrb = 512 / (batch * g->nslice);
+    if (nrb < 1) nrb = 1;
+    const int rows_par = 256 / (sc / 8);
+    int64_t rpb = (rows_per_batch + nrb - 1) / nrb;
+    rpb = (rpb + rows_par - 1) / rows_par * rows_par;
+    if (rpb < rows_par) rpb = rows_par;
+    g->rpb = (int)rpb;
+    g->nrowblk = (int)((rows_per_batch + rpb - 1) / rpb);
+    return true;
+}
+
 // LayerNorm: one wave per row, the row lives in registers (<= 3 chunks of 8 per lane: C <= 1536), two-pass statistics.
 template <int MAXC>
 __global__ void __launch_bounds__(256) layernorm_kernel(const bf16* __restrict__ x, int64_t rows, int C, int ldx,
@@ -436,6 +592,34 @@ extern "C" int seer_groupnorm_apply_dt(const void* x1, int32_t C1, const void* x
         hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                            reinterpret_cast<const bf16*>(x1), reinterpret_cast<const bf16*>(x2), g, rows_per_batch, groups,
                            stats, (float)(1.0 / count), eps, gamma, beta, silu, reinterpret_cast<bf16*>(y));
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int seer_groupnorm_apply_from_colsums(const void* x1, int32_t C1, const void* x2, int32_t C2, const float* cs1,
+                                                 int32_t phases1, int32_t tiles1, const float* cs2, int32_t phases2,
+                                                 int32_t tiles2, int32_t batch, int64_t rows_per_batch, int32_t groups,
+                                                 double count, float eps, const float* gamma, const float* beta,
+                                                 int32_t silu, void* y, void* stream) {
+    if (!x1 || !cs1 || !gamma || !beta || !y || batch <= 0 || rows_per_batch <= 0 || count <= 0) return SEER_EINVAL;
+    if (phases1 <= 0 || tiles1 <= 0 || tiles1 % batch) return SEER_EINVAL;
+    if (!x2) C2 = 0;
+    if (C2 > 0 && (!cs2 || phases2 <= 0 || tiles2 <= 0 || tiles2 % batch)) return SEER_EINVAL;
+    GnCsGeom g;
+    if (!gn_cs_geom(C1, C2, groups, batch, rows_per_batch, &g)) return SEER_ENOSYS;
+    // Where the one-launch form wins (profiles/r04_gn_fused.log, inside a hipGraph): few partials per batch element and a small
+    // tensor -- the 16x16 level down.  At the 32x32 level every one of ~512 blocks re-reads 82 KB of partials (42 MB per launch)
+    // and the two launches are faster (11.3 vs 13.3 us); the caller keeps them there.
+    {
+        const int64_t parts = (int64_t)phases1 * (tiles1 / batch) > (C2 ? (int64_t)phases2 * (tiles2 / batch) : 0)
+                                  ? (int64_t)phases1 * (tiles1 / batch) : (int64_t)phases2 * (tiles2 / batch);
+        if (parts > 32 || rows_per_batch * (int64_t)(C1 + C2) > (int64_t)4200000) return SEER_ENOSYS;
+    }
+    const GnColsumSrc s1{cs1, C1, phases1, tiles1}, s2{cs2, C2, C2 ? phases2 : 0, C2 ? tiles2 : 0};
+    dim3 grid((unsigned)(g.nslice * g.nrowblk), batch);
+    hipLaunchKernelGGL(gn_apply_cs_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const bf16*>(x1), reinterpret_cast<const bf16*>(x2), s1, s2, g, batch, rows_per_batch,
+                       (float)(1.0 / count), eps, gamma, beta, silu, reinterpret_cast<bf16*>(y));
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }

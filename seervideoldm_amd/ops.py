@@ -402,6 +402,27 @@ def groupnorm_apply(x1: torch.Tensor, x2: Optional[torch.Tensor], batch: int, gr
     return out
 
 
+def groupnorm_apply_from_colsums(x1: torch.Tensor, x2: Optional[torch.Tensor], cs1: ColSums, cs2: Optional[ColSums], batch: int,
+                                 groups: int, count: float, eps: float, gamma: torch.Tensor, beta: torch.Tensor, silu: bool,
+                                 out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """groupnorm_stats_from_colsums + groupnorm_apply as one launch (single-process engines).  Returns None when this channel
+    layout has to stay on the two calls (SEER_ENOSYS)."""
+    _req(x1, bf16, "x1")
+    rows = x1.shape[0] // batch
+    C2 = 0 if x2 is None else x2.shape[1]
+    if out is None:
+        out = torch.empty((x1.shape[0], x1.shape[1] + C2), device=x1.device, dtype=bf16)
+    _req(gamma, torch.float32, "gamma"); _req(beta, torch.float32, "beta")
+    rc = _lib.load().seer_groupnorm_apply_from_colsums(
+        _p(x1), x1.shape[1], _p(x2), C2, _p(cs1.buf), cs1.phases, cs1.tiles, _p(cs2.buf) if cs2 is not None else None,
+        cs2.phases if cs2 is not None else 0, cs2.tiles if cs2 is not None else 0, batch, rows, groups, float(count), float(eps),
+        _p(gamma), _p(beta), int(silu), _p(out), _stream())
+    if rc == _lib.SEER_ENOSYS:
+        return None
+    check(rc, "seer_groupnorm_apply_from_colsums")
+    return out
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _req(x, bf16, "x")

@@ -80,6 +80,12 @@ class TimedOps:
                 nb = 4 * (cs1.buf.numel() + (0 if cs2 is None else cs2.buf.numel()))
                 return self._timed("groupnorm_stats", 0.0, nb, base, cs1, cs2, *a, **k)
             return f
+        if name == "groupnorm_apply_from_colsums":
+            # statistics + apply in one launch: timed as the apply it replaces (bytes: one read + one write of the activations)
+            def f(x1, x2, *a, **k):
+                nb = 4 * (x1.numel() + (0 if x2 is None else x2.numel()))
+                return self._timed("groupnorm_apply", 0.0, nb, base, x1, x2, *a, **k)
+            return f
         if name in ("groupnorm_apply",):
             return self._bw(name, lambda x1, x2, *a, **k: 4 * (x1.numel() + (0 if x2 is None else x2.numel())))
         if name in ("layernorm",):

@@ -208,6 +208,8 @@ class _Engine:
         # engine (single-process and sharded: a shard all-reduces the same (sum, sumsq) either way).  `model.gn_colsums = False`
         # before prepare() keeps the two-stage reduction everywhere (A/B runs, tests).
         self.gn_colsums = bool(getattr(model, "gn_colsums", True))
+        # statistics from column sums INSIDE the apply launch (model.gn_fused = False / SEER_GN_FUSED=0: the two-launch form, A/B runs)
+        self.gn_fused = bool(getattr(model, "gn_fused", os.environ.get("SEER_GN_FUSED", "1") != "0"))
         self.gn_from_colsums = 0
         self.w: Dict[str, torch.Tensor] = {}
         self._pack(sd)
@@ -304,12 +306,20 @@ class _Engine:
         # has them: no pass over the activations; otherwise the two-stage reduction over x1 | x2
         cs1 = getattr(x1, "colsums", None)
         cs2 = getattr(x2, "colsums", None) if x2 is not None else None
+        C = x1.shape[1] + (0 if x2 is None else x2.shape[1])
         if self.gn_colsums and cs1 is not None and (x2 is None or cs2 is not None):
+            if self.shard is None and self.gn_fused:
+                # one launch: every apply block re-derives the statistics of its own groups from the column sums (no frame
+                # shards: a sharded run all-reduces the statistics between the two steps)
+                y = ops.groupnorm_apply_from_colsums(x1, x2, cs1, cs2, B, self.G, rows_pb * (C // self.G), eps,
+                                                     self.w[name + ".weight"], self.w[name + ".bias"], silu)
+                if y is not None:
+                    self.gn_from_colsums += 1
+                    return y
             ops.groupnorm_stats_from_colsums(cs1, cs2, B, self.G, stats)
             self.gn_from_colsums += 1
         else:
             ops.groupnorm_stats(x1, x2, B, self.G, stats)
-        C = x1.shape[1] + (0 if x2 is None else x2.shape[1])
         count = rows_pb * (C // self.G)
         if self.shard is not None:
             count = self.shard.reduce_gn_stats(stats, count, sync=self.sync_point)

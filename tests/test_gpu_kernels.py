@@ -905,3 +905,40 @@ def test_cfg_ddim_step(device):
     img = _rand((1000,), device, 4) * 2
     ref = ((img + 1) / 2).clamp(0, 1)
     assert torch.allclose(ops.clamp01_(img.clone()), ref)
+
+
+@pytest.mark.parametrize("C1,C2,rows,tile", [(320, 0, 1536, 0), (640, 0, 768, 0), (1280, 0, 512, 0), (640, 320, 768, 0), (1280, 1280, 256, 0),
+                                             (320, 320, 1536, 0), (1280, 640, 512, 0), (320, 0, 2048, 22), (1280, 0, 1024, 22),
+                                             (640, 0, 3072, 0), (640, 640, 3072, 0)])
+def test_groupnorm_apply_from_colsums(device, C1, C2, rows, tile):
+    """One launch = seer_groupnorm_stats_from_colsums + seer_groupnorm_apply: every block re-derives the statistics of its own
+    groups from the producers' column sums (resnet.py:179,197 / attention.py:133 normalise the 5-D tensor per (batch, group)).
+    Against F.group_norm in fp32 on the stored bf16 activations and against the two-launch form (a different fp32 order of the
+    same additions: equal to rounding); channel widths incl. both skip-concat layouts (group width 30 and 60), column sums from the
+    64-row partials of the 256 x 320 tile."""
+    from seervideoldm_amd import ops
+    B, G = 2, 32
+    M = B * rows
+
+    def produce(C, seed):
+        a = _rand((M, 320), device, seed).to(bf16)
+        w = _rand((C, 320), device, seed + 1, 320 ** -0.5).to(bf16)
+        y = ops.gemm(a, w, bias=_rand((C,), device, seed + 2), tile=tile, splits=1 if tile else 0, colsum_batch=B)
+        assert y.colsums is not None
+        return y
+    x1 = produce(C1, 1)
+    x2 = produce(C2, 11) if C2 else None
+    C = C1 + C2
+    gamma, beta = _rand((C,), device, 21) + 1.0, _rand((C,), device, 22)
+    count = rows * (C // G)
+    got = ops.groupnorm_apply_from_colsums(x1, x2, x1.colsums, x2.colsums if C2 else None, B, G, count, 1e-5, gamma, beta, True)
+    assert got is not None, "these layouts slice into whole groups of 64..128 channels and are small enough for the one-launch form"
+    stats = torch.zeros((B, G, 2), device=device, dtype=torch.float32)
+    ops.groupnorm_stats_from_colsums(x1.colsums, x2.colsums if C2 else None, B, G, stats)
+    two = ops.groupnorm_apply(x1, x2, B, G, stats, count, 1e-5, gamma, beta, True)
+    xc = x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], 1)
+    ref = Fn.silu(Fn.group_norm(xc.reshape(B, rows, C).permute(0, 2, 1), G, gamma, beta, 1e-5)).permute(0, 2, 1).reshape(M, C)
+    _close(got, ref, rtol=1e-2, atol=1e-2, what=f"fused groupnorm C {C1}+{C2}")
+    assert (got.float() - two.float()).abs().max().item() <= 2 ** -6 * ref.abs().max().item()      # at most a bf16 ulp apart
+    again = ops.groupnorm_apply_from_colsums(x1, x2, x1.colsums, x2.colsums if C2 else None, B, G, count, 1e-5, gamma, beta, True)
+    assert torch.equal(got, again), "fixed order of additions: bit-identical from launch to launch"

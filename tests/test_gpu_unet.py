@@ -102,7 +102,15 @@ def test_segmented_graph_replay(device):
     x = _randn((2, 4, 3, 16, 16), 11).to(device)
     ctx = _randn((2, 3, 77, cfg["cross_attention_dim"]), 12).to(device)
     t = torch.tensor([301, 301], device=device)
-    ref = m(x, t, ctx).clone()              # (sharded engines take GroupNorm statistics from column sums like this one)
+    # (sharded engines take GroupNorm statistics from column sums like this one -- in the two-launch form: the statistics are
+    #  all-reduced between the launches; the reference engine is built the same way so that the comparison stays bit for bit)
+    m._engine = None
+    m.gn_fused = False
+    try:
+        ref = m(x, t, ctx).clone()
+    finally:
+        del m.gn_fused
+        m._engine = None
     shard = parallel.attach(m, 1, 0)
     shard.debug_boundaries = True
     try:
