@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
     [[maybe_unused]] int nst_ = 0;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: LDS-DMA destinations stay in SGPRs
     const int wm = wave / WN, wn = wave % WN;
     PSTAMP();
     PSPAN(0);
@@ -204,6 +204,38 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
             a_ox[i] = (gm - m0) * p.lda2;
         }
     }
+    // LDS-direct conv gather without per-piece address arithmetic (not the nearest-2x read-through form, whose source pixel is not
+    // affine in the tap): a_pix = byte offset of tap (0, 0) of the piece row's pixel, this lane's chunk included; bit 9 i + tap of
+    // a_okb[i / 3]: tap inside the image.  A K tile then costs one scalar tap offset and, per piece, a select between
+    // a_pix + tap offset and an offset past the end of the tensor, which the buffer bounds check turns into zeros -- no 64-bit
+    // address, no zero page, no branch, no division (round 4: the loop is bound by instruction issue, profiles/r04_t320_stamps.log)
+    [[maybe_unused]] int a_pix[A_CH];
+    [[maybe_unused]] unsigned a_okb[(A_CH + 2) / 3] = {};
+    [[maybe_unused]] unsigned a_bytes = 0;
+    bool conv_fast = false;
+    if constexpr (CONV && NS >= 2) {
+        const int64_t hw_out = p.upsample == 2 ? (int64_t)p.Hin * p.Win : (int64_t)p.Hout * p.Wout;
+        const int64_t in_bytes = (p.M / hw_out) * p.Hin * p.Win * p.Cin * 2;
+        conv_fast = p.upsample != 1 && in_bytes < ((int64_t)1 << 31) && (int64_t)p.K * p.Cin < ((int64_t)1 << 32);
+        a_bytes = (unsigned)in_bytes;
+        if (conv_fast) {
+            const int ksz = p.upsample == 2 ? 2 : 3;
+            const int sch = ((tid & 7) ^ (srow & 7)) * 8;
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) {
+                const int iy0 = a_oy[i], ix0 = a_ox[i];
+                a_pix[i] = (int)(a_off[i] + ((int64_t)iy0 * p.Win + ix0) * p.Cin + sch) * 2;
+                unsigned bits = 0u;
+                for (int ky = 0; ky < ksz; ++ky)
+                    for (int kx = 0; kx < ksz; ++kx)
+                        if (iy0 + ky >= 0 && iy0 + ky < p.Hin && ix0 + kx >= 0 && ix0 + kx < p.Win) bits |= 1u << (ky * ksz + kx);
+                a_okb[i / 3] |= bits << (9 * (i % 3));
+            }
+        }
+    }
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(A), 0, (int)a_bytes, 0x00020000);
+    const unsigned cin_magic = CONV ? 0xFFFFFFFFu / (unsigned)(p.Cin > 0 ? p.Cin : 1) + 1u : 0u;     // tap = umulhi(kbase, magic)
+
     int64_t b_off[B_CH];
     int b_rel[B_CH];                  // (gn - n0) * K: the W row relative to the tile's first, in elements
 #pragma unroll
@@ -516,6 +548,20 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
             bf16* as = smem_b + stage * STAGE + (8 * wave) * BK;      // this wave's 8-row group (wave-uniform)
             bf16* bs = smem_b + stage * STAGE + BM * BK + (8 * wave) * BK;
             if constexpr (CONV) {
+                if (conv_fast) {
+                    const int tap = (int)__umulhi((unsigned)kbase, cin_magic);
+                    const int ci0 = kbase - tap * p.Cin;
+                    const int ksz = p.upsample == 2 ? 2 : 3;
+                    const int ky = tap / ksz, kx = tap - ky * ksz;
+                    const int tap_b = (ky * p.Win + kx) * p.Cin * 2;
+#pragma unroll
+                    for (int i = 0; i < A_CH; ++i) {
+                        const bool ok = ((a_okb[i / 3] >> (9 * (i % 3) + tap)) & 1u) != 0u;
+                        const unsigned voff = ok ? (unsigned)(a_pix[i] + tap_b) : a_bytes;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(as + RPP * i * BK), 16, voff,
+                                                                 ci0 * 2, 0, 0);
+                    }
+                } else {
                 const int tap = kbase / p.Cin;
                 const int ci0 = kbase - tap * p.Cin;
                 const int ksz = p.upsample == 2 ? 2 : 3;
@@ -532,6 +578,7 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
                                          : reinterpret_cast<const bf16*>(seer_zero_page);
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                      (__attribute__((address_space(3))) void*)(as + RPP * i * BK), 16, 0, 0);
+                }
                 }
             } else {
                 const bool second = kbase >= p.K1;
