@@ -89,6 +89,15 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    # hipcc can drop the HOST stub of a kernel template instantiation without a diagnostic (seen with un-cast integer arguments of
+    # __builtin_amdgcn_raw_ptr_buffer_load_lds, round 4): the library then links and only fails when it is loaded
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    r = subprocess.run([nm, "-u", str(LIB)], capture_output=True, text=True)
+    missing = [l.split()[-1] for l in r.stdout.splitlines() if "__device_stub__" in l]
+    if missing:
+        LIB.unlink()
+        raise RuntimeError("kernel launch stubs missing from the library (host side of these instantiations was not emitted):\n"
+                           + "\n".join(missing[:10]))
     stamp.write_text(dig)
     return LIB
 

@@ -235,6 +235,10 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
     }
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(A), 0, (int)a_bytes, 0x00020000);
     const unsigned cin_magic = CONV ? 0xFFFFFFFFu / (unsigned)(p.Cin > 0 ? p.Cin : 1) + 1u : 0u;     // tap = umulhi(kbase, magic)
+    // plain operands of the LDS-direct ring as buffer resources over the tile's rows (see issue_tile)
+    const __amdgpu_buffer_rsrc_t r_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(A + (CONV ? 0 : (int64_t)m0 * p.lda)), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_a2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(A2 && !CONV ? A2 + (int64_t)m0 * p.lda2 : A), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(W + (int64_t)n0 * p.K), 0, 0x7fffffff, 0x00020000);
 
     int64_t b_off[B_CH];
     int b_rel[B_CH];                  // (gn - n0) * K: the W row relative to the tile's first, in elements
@@ -543,6 +547,21 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
         // XOR swizzle goes on the SOURCE chunk (slot ^ row&7), the LDS image stays lane-linear (cdna guide, rule 21).
         constexpr int LPT = A_CH + B_CH;           // global_load_lds per wave per K tile
         const int schunk = ((tid & 7) ^ (srow & 7)) * 8;
+        // plain operands as buffer loads: wave-uniform resource at the tile's first row, per-lane byte offset that is constant
+        // over K (hoisted here), scalar offset that advances with K -- per piece one M0 write and one buffer_load ... lds.
+        // (The offset arguments are cast to int explicitly: without the casts hipcc (ROCm 7.2) silently drops the HOST stub of every
+        //  instantiation that reaches this call -- no diagnostic, undefined __device_stub__ symbols at load time.)
+        unsigned av1[A_CH], av2[A_CH], bv[B_CH];
+        if constexpr (!CONV) {
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) {
+                av1[i] = (unsigned)(a_oy[i] + schunk) * 2u;
+                av2[i] = (unsigned)(a_ox[i] + schunk) * 2u;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) bv[i] = (unsigned)(b_rel[i] + schunk) * 2u;
+
         auto issue_tile = [&](int kt, int stage) {
             const int kbase = kt * BK;
             bf16* as = smem_b + stage * STAGE + (8 * wave) * BK;      // this wave's 8-row group (wave-uniform)
@@ -581,23 +600,21 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
                 }
                 }
             } else {
-                const bool second = kbase >= p.K1;
-                const unsigned char* base = second ? reinterpret_cast<const unsigned char*>(A2 + (int64_t)m0 * p.lda2 + (kbase - p.K1))
-                                                   : reinterpret_cast<const unsigned char*>(A + (int64_t)m0 * p.lda + kbase);
+                if (kbase >= p.K1) {               // (wave-uniform: the second source of a skip concat)
 #pragma unroll
-                for (int i = 0; i < A_CH; ++i) {
-                    const unsigned voff = (unsigned)((second ? a_ox[i] : a_oy[i]) + schunk) * 2u;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + voff),
-                                                     (__attribute__((address_space(3))) void*)(as + RPP * i * BK), 16, 0, 0);
+                    for (int i = 0; i < A_CH; ++i)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_a2, (__attribute__((address_space(3))) void*)(as + RPP * i * BK), 16, (int)av2[i],
+                                                                 (int)((kbase - p.K1) * 2), 0, 0);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < A_CH; ++i)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_a1, (__attribute__((address_space(3))) void*)(as + RPP * i * BK), 16, (int)av1[i],
+                                                                 (int)(kbase * 2), 0, 0);
                 }
             }
-            const unsigned char* wbase = reinterpret_cast<const unsigned char*>(W + (int64_t)n0 * p.K + kbase);
 #pragma unroll
-            for (int i = 0; i < B_CH; ++i) {
-                const unsigned voff = (unsigned)(b_rel[i] + schunk) * 2u;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbase + voff),
-                                                 (__attribute__((address_space(3))) void*)(bs + RPP * i * BK), 16, 0, 0);
-            }
+            for (int i = 0; i < B_CH; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (__attribute__((address_space(3))) void*)(bs + RPP * i * BK), 16, (int)bv[i], (int)(kbase * 2), 0, 0);
         };
 #if SEER_GEMM_EARLY_REFILL
         // Early refill: a stage is only occupied from "landed" to "fragments in registers".  Per K tile: wait for the tile,
