@@ -1389,7 +1389,7 @@ int resolve_tile(const seer_gemm_desc& d) {
 // rounds = ceil(tiles * S / 256 CUs); slab bytes = 2 * tiles * S * 320 KB when S > 1 -- the partial tiles of a split launch go
 // through the fabric (write-through stores, sc1 loads) at HBM-like rates whatever the split, which is what keeps the big tile
 // away from the few-tile shapes of a 32x32-latent step: 256 workgroups x 320 KB x 2 = 164 MB = 38 us per split launch.
-// The smaller tiles are priced at the best rate they reach on these shape classes (0.80-0.95 PFLOP/s): the big tile is only
+// The smaller tiles are priced at the best rate they reach on these shape classes (0.78-1.1 PFLOP/s): the big tile is only
 // chosen where it beats that optimistic figure.
 double t320_model_us(const seer_gemm_desc& d, int S) {
     const int nb = (d.mode == SEER_GEMM_CONV3X3 && d.upsample == 2) ? 4 : (d.batch > 1 ? d.batch : 1);
@@ -1446,7 +1446,9 @@ int t320_plan(const seer_gemm_desc& d, bool assume_buffers = false) {
     (void)can_split;
     const int s = t320_best_split(d, false, &t);
     const double flops = 2.0 * d.M * d.N * (double)d.K * (phases ? 4 : d.batch > 1 ? d.batch : 1);
-    const double rate = d.mode == SEER_GEMM_CONV3X3 ? 0.80e9 : geglu ? 0.78e9 : 0.85e9;      // FLOP per us (0.78-0.85 PFLOP/s)
+    // FLOP per us.  (Convs: since the small tiles' gather lost its address arithmetic they reach 1.0-1.2 PFLOP/s on long-K convs
+    // with many rows -- profiles/r04_t320_recalibration.log -- and the big tile is rarely ahead there.)
+    const double rate = d.mode == SEER_GEMM_CONV3X3 ? 1.10e9 : geglu ? 0.78e9 : 0.85e9;
     if (!(t < flops / rate)) return 0;
     if (!assume_buffers && s > 1 && !t320_buffers_ok(d, s)) return 0;         // no room to split: the smaller tiles take it
     return s;
