@@ -127,7 +127,19 @@ typedef struct seer_gemm_desc {
      * the launch falls back to the two-launch split-K of the smaller tiles. */
     void* sync;
     int64_t sync_bytes;
+    /* the same column sums, ACCUMULATED per batch element in 64-bit fixed point instead of written per tile:
+     * colsum_fx[rep][b][2][N] (planes: sum, sum of squares) += round(partial * 2^SEER_GN_FX_SHIFT) by integer atomic adds, b = (first
+     * row of the partial) / colsum_fx_rows, rep = (index of the partial) % colsum_fx_reps (replicas keep the adds per address
+     * low: an atomic on one address retires every ~12 ns).  Integer addition commutes, so the totals do not depend on the
+     * order the tiles finish in (bit-identical from run to run, like the per-tile form).  ZERO the buffer before the first launch
+     * that adds to it; every launch whose rows belong to the same tensor (the four phases of an upsample == 2 conv) adds to the
+     * same buffer.  colsum_fx_reps and the row granularity come from seer_gemm_colsum_fx_layout; set colsum OR colsum_fx.  The
+     * consumer is seer_groupnorm_apply_fx: one launch, no statistics pass and no finalize pass.  Range: |sum|, sum of squares
+     * < 2^43 per (batch element, column). */
+    int64_t* colsum_fx;
+    int32_t colsum_fx_rows, colsum_fx_reps;
 } seer_gemm_desc;
+#define SEER_GN_FX_SHIFT 20
 
 #define SEER_TILE_AUTO 0
 #define SEER_TILE_128x128 1
@@ -164,6 +176,10 @@ int64_t seer_gemm_workspace_bytes(const seer_gemm_desc* desc /* host */);
 /* rows per partial of the column sums this exact launch (same tile / splits / workspace fields) would write to desc->colsum,
  * or 0 when it cannot produce them; the buffer is [z][ceil(M / rows)][N][2] floats */
 int32_t seer_gemm_colsum_rows(const seer_gemm_desc* desc /* host */);
+/* colsum_fx form of this exact launch for tensors of rows_per_batch rows per batch element: returns the rows one partial covers
+ * (rows_per_batch must be a multiple; 0: the launch cannot accumulate column sums) and sets *reps = the replica count to
+ * allocate and pass as colsum_fx_reps */
+int32_t seer_gemm_colsum_fx_layout(const seer_gemm_desc* desc /* host */, int32_t rows_per_batch, int32_t* reps);
 /* bytes of zeroed counter memory (desc->sync) the call would use to reduce its K slices inside the launch (0: none) */
 int64_t seer_gemm_sync_bytes(const seer_gemm_desc* desc /* host */);
 
@@ -274,6 +290,12 @@ int seer_groupnorm_apply_from_colsums(const void* x1, int32_t C1, const void* x2
                                       int32_t tiles1, const float* cs2, int32_t phases2, int32_t tiles2, int32_t batch,
                                       int64_t rows_per_batch, int32_t groups, double count, float eps, const float* gamma,
                                       const float* beta, int32_t silu, void* y, void* stream);
+/* GroupNorm apply whose statistics are the fixed-point column sums the producers ACCUMULATED (seer_gemm_desc::colsum_fx):
+ * fx1 [reps1][batch][2][C1], fx2 [reps2][batch][2][C2] int64 (NULL with C2 = 0).  One launch per GroupNorm; every block converts the sums of
+ * the groups it normalises (double precision) and streams its rows.  SEER_ENOSYS as above. */
+int seer_groupnorm_apply_fx(const void* x1, int32_t C1, const void* x2, int32_t C2, const int64_t* fx1, int32_t reps1,
+                            const int64_t* fx2, int32_t reps2, int32_t batch, int64_t rows_per_batch, int32_t groups, double count, float eps, const float* gamma,
+                            const float* beta, int32_t silu, void* y, void* stream);
 /* the same two with the storage type of x1 / x2 / y chosen by `dtype` (SEER_DT_*): the VAE's nn.GroupNorm(32, eps 1e-6)
  * (ldm/modules/diffusionmodules/model.py:38-40) on fp16 activations */
 int seer_groupnorm_stats_dt(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t batch,

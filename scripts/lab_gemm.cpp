@@ -137,6 +137,11 @@ int main(int argc, char** argv) {
             d.colsum = dCs;
             if (seer_gemm_colsum_rows(&d) <= 0) d.colsum = nullptr;
         }
+        if (getenv("LAB_COLSUM_FX") && !s.geglu) {   // ... accumulated per batch element (2) in fixed point instead
+            d.colsum = nullptr;
+            int32_t reps = 1;
+            if (seer_gemm_colsum_fx_layout(&d, d.M / 2, &reps) > 0) { d.colsum_fx = (int64_t*)dCs; d.colsum_fx_rows = d.M / 2; d.colsum_fx_reps = reps; }
+        }
         const bool stamps = getenv("LAB_STAMPS") != nullptr;
         if (stamps) { d.workspace = dWs; d.workspace_bytes = 777; CK(hipMemset(dWs, 0, 1 << 22)); }
         int rc = 0;

@@ -13,7 +13,7 @@ _PKG = Path(__file__).resolve().parent
 _LIB_PATH = _PKG / "lib" / "libseer_hip.so"
 _lib = None
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 SEER_GEMM_PLAIN = 0
 SEER_GEMM_CONV3X3 = 1
@@ -52,6 +52,7 @@ class GemmDesc(C.Structure):
         ("pad_after_only", C.c_int32),
         ("col_scale_cols", C.c_int32), ("col_scale", C.c_float),
         ("colsum", C.c_void_p), ("sync", C.c_void_p), ("sync_bytes", C.c_int64),
+        ("colsum_fx", C.c_void_p), ("colsum_fx_rows", C.c_int32), ("colsum_fx_reps", C.c_int32),
     ]
 
 
@@ -100,6 +101,8 @@ SIGNATURES = {
     "seer_groupnorm_apply": ([_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _f64, _f32, _vp, _vp, _i32, _vp, _vp], C.c_int),
     "seer_groupnorm_apply_from_colsums": ([_vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i64, _i32, _f64, _f32, _vp, _vp,
                                            _i32, _vp, _vp], C.c_int),
+    "seer_groupnorm_apply_fx": ([_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i64, _i32, _f64, _f32, _vp, _vp, _i32, _vp, _vp], C.c_int),
+    "seer_gemm_colsum_fx_layout": ([C.POINTER(GemmDesc), _i32, C.POINTER(C.c_int32)], C.c_int32),
     "seer_groupnorm_stats_dt": ([_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _i32, _vp], C.c_int),
     "seer_groupnorm_apply_dt": ([_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _f64, _f32, _vp, _vp, _i32, _vp, _i32, _vp], C.c_int),
     "seer_softmax_rows_dt": ([_vp, _i32, _i64, _i32, _i32, _f32, _vp, _i32, _i32, _vp], C.c_int),

@@ -633,7 +633,27 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
                 for (int i = 0; i < TM; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(as + (i * 16 + frow) * BK + sw);
             }
         };
+#if SEER_GEMM_PROBE & 8
+        // probe build: the same operand registers through 32x32x16 MFMAs (half the MFMA issues for the same pipe time; the numbers
+        // are meaningless) -- prices what a 32x32 fragment layout could buy before anyone writes it
+        constexpr bool P32 = (TM % 2 == 0) && (TN % 2 == 0) && !F16;
+        f32x16 acc32[P32 ? TM / 2 : 1][P32 ? TN / 2 : 1] = {};
+#endif
         auto mma_tile = [&]() {
+#if SEER_GEMM_PROBE & 8
+            if constexpr (P32) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int i = 0; i < TM / 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN / 2; ++j)
+                                acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][2 * j + h], af[ks][2 * i + h], acc32[i][j], 0, 0, 0);
+                return;
+            }
+#endif
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -684,6 +704,16 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
             stage = (stage + 1 == NS) ? 0 : stage + 1;
         }
         PSTAMP();
+#if SEER_GEMM_PROBE & 8
+        if constexpr (P32) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][e] = acc32[i / 2][j / 2][((i & 1) * 2 + (j & 1)) * 4 + e];
+        }
+#endif
         }
 #else
 #pragma unroll
@@ -997,7 +1027,7 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
         constexpr bool COLSUM_OK = !GEGLU && !SPLIT && tile_colsum_ok<BM, BN, NS, WM, WN>();
         float* cs_scratch = reinterpret_cast<float*>(smem + BM * CPITCH);
         if constexpr (COLSUM_OK) {
-            if (p.colsum) {
+            if (p.colsum || p.colsum_fx) {
                 const int cp = tid % CS_CP, rs = tid / CS_CP;
                 if (rs < CS_RS) {
                     const int rows = min(BM, p.M - m0);
@@ -1030,7 +1060,7 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
             }
         }
         if constexpr (COLSUM_OK) {
-            if (p.colsum) {
+            if (p.colsum || p.colsum_fx) {
                 __syncthreads();                        // the row-segment partials are parked
                 if (tid < BNO && n0o + tid < n_out) {
                     float sm = 0.f, sq = 0.f;
@@ -1040,9 +1070,15 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
                         sm += e[0];
                         sq += e[1];
                     }
-                    const int tiles_m = (p.M + BM - 1) / BM;
-                    float* o = p.colsum + (((int64_t)blockIdx.z * tiles_m + m0 / BM) * p.N + n0o + tid) * 2;
-                    *reinterpret_cast<f32x2*>(o) = f32x2{sm, sq};
+                    if (p.colsum_fx) {                   // accumulate per batch element (every phase of an upsampling conv adds here)
+                        int64_t* o = fx_slot(p, m0 / BM, m0) + n0o + tid;
+                        fx_add(o, sm);
+                        fx_add(o + p.N, sq);
+                    } else {
+                        const int tiles_m = (p.M + BM - 1) / BM;
+                        float* o = p.colsum + (((int64_t)blockIdx.z * tiles_m + m0 / BM) * p.N + n0o + tid) * 2;
+                        *reinterpret_cast<f32x2*>(o) = f32x2{sm, sq};
+                    }
                 }
             }
         }
@@ -1145,6 +1181,48 @@ __global__ void __launch_bounds__(256) seer_splitk_reduce_colsum_kernel(const se
     }
 }
 
+// the same pass for ACCUMULATED column sums (seer_gemm_desc::colsum_fx).  The atomics are the cost here (one per address every
+// ~12 ns, ~1.3 TB/s of them chip-wide): a block owns RB = RL * RPL rows x CB columns and adds ONE pair per column -- 16 x fewer
+// than one per 4-row strip (measured with 4 / 16-row strips: +10..15 us per conv, profiles/r04_gn_fx.log).  Thread -> (column
+// quad, row lane); the row lanes of a column are added in order by the column's thread.
+template <int CB, int RL, int RPL>
+__global__ void __launch_bounds__(256) seer_splitk_reduce_fx_kernel(const seer_gemm_desc p) {
+    constexpr int NQ = CB / 4, RB = RL * RPL;
+    static_assert(NQ * RL == 256, "one thread per (column quad, row lane)");
+    __shared__ float part[RL][NQ][8];
+    const int cq = threadIdx.x % NQ, rl = threadIdx.x / NQ;
+    const int n = blockIdx.x * CB + cq * 4;
+    const int mb = blockIdx.y * RB;
+    float sm[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+    if (n < p.N) {
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            const int m = mb + rl + i * RL;
+            if (m < p.M) {
+                const f32x4 v = splitk_reduce_quad(p, m, n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { sm[r] += v[r]; sq[r] += v[r] * v[r]; }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { part[rl][cq][r * 2] = sm[r]; part[rl][cq][r * 2 + 1] = sq[r]; }
+    __syncthreads();
+    const int col = blockIdx.x * CB + threadIdx.x;
+    if (threadIdx.x < CB && col < p.N) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int k = 0; k < RL; ++k) {
+            a += part[k][threadIdx.x >> 2][(threadIdx.x & 3) * 2];
+            b += part[k][threadIdx.x >> 2][(threadIdx.x & 3) * 2 + 1];
+        }
+        int64_t* o = fx_slot(p, blockIdx.y, mb) + col;
+        fx_add(o, a);
+        fx_add(o + p.N, b);
+    }
+}
+__host__ inline int splitk_fx_rows(int M) { return M >= 1024 ? 64 : 32; }
+
 // the kernel's `staged` condition, host side: column sums are taken from the staged bf16 tile
 bool colsum_store_ok(const seer_gemm_desc& d) {
     return !(d.epilogue & (SEER_EPI_OUT_F32 | SEER_EPI_TRANS_OUT | SEER_EPI_GEGLU)) && d.ldc % 8 == 0 && d.N % 8 == 0 &&
@@ -1178,7 +1256,7 @@ int launch_tile(const seer_gemm_desc& d, hipStream_t st) {
     const bool conv = d.mode == SEER_GEMM_CONV3X3;
     const bool geglu = (d.epilogue & SEER_EPI_GEGLU) != 0;
     if (conv && geglu) return SEER_EINVAL;
-    if (d.colsum && (geglu || !tile_colsum_ok<BM, BN, NS, WM, WN>() || !colsum_store_ok(d))) return SEER_EINVAL;
+    if ((d.colsum || d.colsum_fx) && (geglu || !tile_colsum_ok<BM, BN, NS, WM, WN>() || !colsum_store_ok(d))) return SEER_EINVAL;
     if (conv) {
         hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, true, false, false, NS, WM, WN>), grid, dim3(64 * WM * WN), lds, st, d);
     } else if (geglu) {
@@ -1228,7 +1306,15 @@ int launch_split_tile(const seer_gemm_desc& d, hipStream_t st) {
     else
         hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, false, true, NS>), grid, dim3(256), lds, st, d);
     SEER_LAUNCH_CHECK();
-    if (d.colsum) {
+    if (d.colsum_fx) {
+        if (d.epilogue & (SEER_EPI_OUT_F32 | SEER_EPI_TRANS_OUT | SEER_EPI_GEGLU)) return SEER_EINVAL;
+        if (splitk_fx_rows(d.M) == 64)
+            hipLaunchKernelGGL((seer_splitk_reduce_fx_kernel<64, 16, 4>), dim3((unsigned)((d.N + 63) / 64), (unsigned)((d.M + 63) / 64)),
+                               dim3(256), 0, st, d);
+        else
+            hipLaunchKernelGGL((seer_splitk_reduce_fx_kernel<32, 32, 1>), dim3((unsigned)((d.N + 31) / 32), (unsigned)((d.M + 31) / 32)),
+                               dim3(256), 0, st, d);
+    } else if (d.colsum) {
         if (d.epilogue & (SEER_EPI_OUT_F32 | SEER_EPI_TRANS_OUT | SEER_EPI_GEGLU)) return SEER_EINVAL;
         const int cs_rows = splitk_cs_rows(d.M);
         hipLaunchKernelGGL(seer_splitk_reduce_colsum_kernel, dim3((unsigned)((d.N + 255) / 256),
@@ -1528,10 +1614,33 @@ extern "C" int32_t seer_gemm_colsum_rows(const seer_gemm_desc* desc) {
     return rows > 0 ? rows : 0;           // an unknown tile code comes back as a negative status
 }
 
+extern "C" int32_t seer_gemm_colsum_fx_layout(const seer_gemm_desc* desc, int32_t rows_per_batch, int32_t* reps) {
+    if (reps) *reps = 1;
+    if (!desc || rows_per_batch <= 0 || desc->M % rows_per_batch) return 0;
+    int rows = seer_gemm_colsum_rows(desc);       // tile rows; 64 / 16 on the 256 x 320 tile; the strip of the split-K reduce pass
+    if (rows <= 0) return 0;
+    seer_gemm_desc d = *desc;
+    if (!t320_plan(d)) {
+        if (d.tile == SEER_TILE_T256x320 || d.tile == SEER_TILE_WS || d.tile == SEER_TILE_AUTO_TILED) d.tile = SEER_TILE_AUTO;
+        int s = 1;
+        if (prepare(d, &s) == SEER_OK && s > 1 && d.workspace && d.workspace_bytes >= (int64_t)s * d.M * d.N * (int64_t)sizeof(float))
+            rows = splitk_fx_rows(d.M);           // the accumulating reduce pass owns bigger row blocks
+    }
+    if (rows_per_batch % rows) return 0;
+    const int adds = rows_per_batch / rows;       // adds per address and launch without replicas
+    if (reps) *reps = adds <= 24 ? 1 : adds <= 48 ? 2 : adds <= 96 ? 4 : 8;
+    return rows;
+}
+
 extern "C" int seer_gemm_bf16(const seer_gemm_desc* desc, void* stream) {
     if (!desc) return SEER_EINVAL;
     seer_gemm_desc d = *desc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d.colsum_fx) {                  // accumulated column sums: no partial of this launch may straddle two batch elements
+        if (d.colsum) return SEER_EINVAL;
+        int reps = 1;
+        if (seer_gemm_colsum_fx_layout(desc, d.colsum_fx_rows, &reps) <= 0 || d.colsum_fx_reps < 1) return SEER_EINVAL;
+    }
     if (const int s320 = t320_plan(d)) {
         int sp = 1;
         seer_gemm_desc chk = d;
@@ -1539,7 +1648,7 @@ extern "C" int seer_gemm_bf16(const seer_gemm_desc* desc, void* stream) {
         const int rc320 = prepare(chk, &sp);         // the same argument checks as every other launch
         if (rc320 != SEER_OK) return rc320;
         d.K1 = chk.K1; d.lda2 = chk.lda2; d.batch = chk.batch; d.strideA = chk.strideA; d.strideW = chk.strideW; d.strideC = chk.strideC;
-        if (d.colsum && ((d.epilogue & SEER_EPI_GEGLU) || !colsum_store_ok(d) || d.M % 256)) return SEER_EINVAL;
+        if ((d.colsum || d.colsum_fx) && ((d.epilogue & SEER_EPI_GEGLU) || !colsum_store_ok(d) || d.M % 256)) return SEER_EINVAL;
         return seer_gemm_t320_launch(d, s320, st);
     }
     if (d.tile == SEER_TILE_T256x320) d.tile = SEER_TILE_AUTO;      // not eligible: the tile kernels take it
@@ -1554,7 +1663,7 @@ extern "C" int seer_gemm_bf16(const seer_gemm_desc* desc, void* stream) {
     }
     d.splits = 1;
     d.tile = desc->tile == SEER_TILE_T256x320 ? SEER_TILE_AUTO : desc->tile;            // prepare() may have picked a split tile; unsplit launches choose their own below
-    if (!d.colsum && !(d.epilogue & SEER_EPI_F16) && seer_gemm_ws_eligible(d) &&
+    if (!d.colsum && !d.colsum_fx && !(d.epilogue & SEER_EPI_F16) && seer_gemm_ws_eligible(d) &&
         (requested == SEER_TILE_WS || (requested == SEER_TILE_AUTO && seer_gemm_ws_profitable(d)))) {
         const int rc_ws = seer_gemm_ws_launch(d, st);
         if (rc_ws != SEER_ENOSYS) return rc_ws;
@@ -1563,7 +1672,7 @@ extern "C" int seer_gemm_bf16(const seer_gemm_desc* desc, void* stream) {
 
     const int tile = resolve_tile(d);
     if (d.epilogue & SEER_EPI_F16) {
-        if (d.colsum || (d.epilogue & (SEER_EPI_GEGLU | SEER_EPI_ROTARY))) return SEER_EINVAL;
+        if (d.colsum || d.colsum_fx || (d.epilogue & (SEER_EPI_GEGLU | SEER_EPI_ROTARY))) return SEER_EINVAL;
         switch (tile) {
             case SEER_TILE_G128x128_2: return launch_tile_f16<128, 128, 2>(d, st);
             case SEER_TILE_G128x64_3: return launch_tile_f16<128, 64, 3>(d, st);

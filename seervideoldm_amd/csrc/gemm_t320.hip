@@ -615,7 +615,7 @@ __global__ void __launch_bounds__(NT) seer_gemm_t320_kernel(const seer_gemm_desc
             // rows: colsum[z][4 tile_m + wave row][N][2]); split, one per 16-row fragment of a wave row (a slice finishes whole
             // quads: colsum[16 tile_m + 4 wave row + fragment][N][2], every entry written by exactly one slice).  A thread owns a
             // column pair of one block and adds its rows in order: deterministic, no atomics.
-            if (p.colsum) {
+            if (p.colsum || p.colsum_fx) {
                 constexpr int NB = SPLIT ? 8 : 2;             // row blocks in a pass
                 constexpr int RB = SPLIT ? 16 : 64;           // rows per block
                 for (int e = tid; e < 160 * NB; e += NT) {
@@ -635,8 +635,13 @@ __global__ void __launch_bounds__(NT) seer_gemm_t320_kernel(const seer_gemm_desc
                             s1 += f1; t1 += f1 * f1;
                         }
                     }
-                    const int64_t part = ((int64_t)(SPLIT ? 0 : blockIdx.z) * tiles_m + tm) * (2 * NB) + ps * NB + blk;
-                    *reinterpret_cast<f32x4*>(p.colsum + (part * p.N + n0 + cp * 2) * 2) = f32x4{s0, t0, s1, t1};
+                    if (p.colsum_fx) {               // accumulated per batch element in fixed point (seer_gemm_desc::colsum_fx)
+                        int64_t* o = fx_slot(p, mrow / RB, mrow) + n0 + cp * 2;
+                        fx_add(o, s0); fx_add(o + 1, s1); fx_add(o + p.N, t0); fx_add(o + p.N + 1, t1);
+                    } else {
+                        const int64_t part = ((int64_t)(SPLIT ? 0 : blockIdx.z) * tiles_m + tm) * (2 * NB) + ps * NB + blk;
+                        *reinterpret_cast<f32x4*>(p.colsum + (part * p.N + n0 + cp * 2) * 2) = f32x4{s0, t0, s1, t1};
+                    }
                 }
             }
         }

@@ -237,6 +237,7 @@ struct GnCsGeom {
     int nslice, nrowblk;
     int rpb;            // rows per row block
 };
+template <bool FX>
 __global__ void __launch_bounds__(256) gn_apply_cs_kernel(const bf16* __restrict__ x1, const bf16* __restrict__ x2, GnColsumSrc s1,
                                                           GnColsumSrc s2, GnCsGeom g, int batch, int64_t rows_per_batch,
                                                           float inv_count, float eps, const float* __restrict__ gamma,
@@ -252,6 +253,48 @@ __global__ void __launch_bounds__(256) gn_apply_cs_kernel(const bf16* __restrict
     // the eleven a channel-per-thread form needs
     const int nq = g.sc / 4;                            // channel quads in the slice (20 or 30)
     const int ntl = 256 / nq;                           // tile lanes (12 or 8)
+    if constexpr (FX) {
+        // the producers ACCUMULATED the sums per (batch element, channel) in 64-bit fixed point (seer_gemm_desc::colsum_fx): one
+        // 16-byte load per channel, the group's channels added as integers (exact, order-free), one conversion per group
+        long long* fxs = reinterpret_cast<long long*>(&part[0][0][0]);      // [channel of the slice][sum, sumsq]
+        if (tid < g.sc) {
+            const int c = c_lo + tid;
+            const GnColsumSrc& s = c < s1.C ? s1 : s2;
+            const int cl = c < s1.C ? c : c - s1.C;
+            // [rep][b][2][C]: s.phases = replicas (added here: integers, any order), s.tiles = batch elements
+            long long sm = 0, sq = 0;
+            for (int r = 0; r < s.phases; ++r) {
+                const long long* q = reinterpret_cast<const long long*>(s.cs) + (int64_t)((r * s.tiles + b) * 2) * s.C + cl;
+                sm += q[0];
+                sq += q[s.C];
+            }
+            fxs[tid * 2] = sm;
+            fxs[tid * 2 + 1] = sq;
+        }
+        __syncthreads();
+        const int gs = g.sc / g.cpg;
+        const int lane = tid & 63, wv = tid >> 6;
+        for (int gi = wv; gi < gs; gi += 4) {
+            long long sm = 0, sq = 0;
+            for (int ch = lane; ch < g.cpg; ch += 64) {
+                sm += fxs[(gi * g.cpg + ch) * 2];
+                sq += fxs[(gi * g.cpg + ch) * 2 + 1];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                sm += __shfl_xor(sm, o);
+                sq += __shfl_xor(sq, o);
+            }
+            if (lane == 0) {
+                const double k = (double)inv_count / (double)(1 << SEER_GN_FX_SHIFT);
+                const double mean = (double)sm * k;
+                double var = (double)sq * k - mean * mean;
+                var = var > 0.0 ? var : 0.0;
+                mean_s[gi] = (float)mean;
+                rstd_s[gi] = rsqrtf((float)var + eps);
+            }
+        }
+    } else {
     {
         const int tl = tid / nq, cq = tid - tl * nq;
         if (tl < ntl) {
@@ -321,6 +364,7 @@ __global__ void __launch_bounds__(256) gn_apply_cs_kernel(const bf16* __restrict
             }
         }
     }
+    }
     __syncthreads();
     // ---- apply: thread -> (row lane, 16-byte chunk of the slice)
     const int cps = g.sc / 8;
@@ -359,7 +403,10 @@ __global__ void __launch_bounds__(256) gn_apply_cs_kernel(const bf16* __restrict
 }
 
 // slice geometry for gn_apply_cs_kernel; false: this GroupNorm keeps the two-launch form
-bool gn_cs_geom(int C1, int C2, int groups, int batch, int64_t rows_per_batch, GnCsGeom* g) {
+#ifndef SEER_GN_FX_BLOCKS
+#define SEER_GN_FX_BLOCKS 1024
+#endif
+bool gn_cs_geom(int C1, int C2, int groups, int batch, int64_t rows_per_batch, GnCsGeom* g, int target_blocks = 512) {
     const int C = C1 + C2;
     if (C1 <= 0 || C2 < 0 || groups <= 0 || groups > 64 || C % groups || C1 % 8 || C2 % 8) return false;
     g->C1 = C1; g->C2 = C2; g->groups = groups; g->cpg = C / groups;
@@ -369,7 +416,7 @@ bool gn_cs_geom(int C1, int C2, int groups, int batch, int64_t rows_per_batch, G
     if (!sc || sc / g->cpg > 16) return false;
     g->sc = sc;
     g->nslice = C / sc;
-    int nrb = 512 / (batch * g->nslice);
+    int nrb = target_blocks / (batch * g->nslice);
     if (nrb < 1) nrb = 1;
     const int rows_par = 256 / (sc / 8);
     int64_t rpb = (rows_per_batch + nrb - 1) / nrb;
@@ -617,7 +664,25 @@ extern "C" int seer_groupnorm_apply_from_colsums(const void* x1, int32_t C1, con
     }
     const GnColsumSrc s1{cs1, C1, phases1, tiles1}, s2{cs2, C2, C2 ? phases2 : 0, C2 ? tiles2 : 0};
     dim3 grid((unsigned)(g.nslice * g.nrowblk), batch);
-    hipLaunchKernelGGL(gn_apply_cs_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(gn_apply_cs_kernel<false>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const bf16*>(x1), reinterpret_cast<const bf16*>(x2), s1, s2, g, batch, rows_per_batch,
+                       (float)(1.0 / count), eps, gamma, beta, silu, reinterpret_cast<bf16*>(y));
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
+extern "C" int seer_groupnorm_apply_fx(const void* x1, int32_t C1, const void* x2, int32_t C2, const int64_t* fx1, int32_t reps1,
+                                       const int64_t* fx2, int32_t reps2, int32_t batch, int64_t rows_per_batch, int32_t groups,
+                                       double count, float eps, const float* gamma, const float* beta, int32_t silu, void* y,
+                                       void* stream) {
+    if (!x1 || !fx1 || reps1 < 1 || !gamma || !beta || !y || batch <= 0 || rows_per_batch <= 0 || count <= 0) return SEER_EINVAL;
+    if (!x2) C2 = 0;
+    if (C2 > 0 && (!fx2 || reps2 < 1)) return SEER_EINVAL;
+    GnCsGeom g;
+    if (!gn_cs_geom(C1, C2, groups, batch, rows_per_batch, &g, SEER_GN_FX_BLOCKS)) return SEER_ENOSYS;
+    const GnColsumSrc s1{reinterpret_cast<const float*>(fx1), C1, reps1, batch}, s2{reinterpret_cast<const float*>(fx2), C2, C2 ? reps2 : 0, batch};
+    dim3 grid((unsigned)(g.nslice * g.nrowblk), batch);
+    hipLaunchKernelGGL(gn_apply_cs_kernel<true>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        reinterpret_cast<const bf16*>(x1), reinterpret_cast<const bf16*>(x2), s1, s2, g, batch, rows_per_batch,
                        (float)(1.0 / count), eps, gamma, beta, silu, reinterpret_cast<bf16*>(y));
     SEER_LAUNCH_CHECK();

@@ -158,6 +158,17 @@ __device__ __forceinline__ f32x2 gelu_erf_f2(f32x2 x) {
     return __builtin_elementwise_fma(-a, h, r);
 }
 
+// fixed-point accumulation of a column-sum partial (seer_gemm_desc::colsum_fx): integer adds commute, so the total does not
+// depend on arrival order.  No-return agent-scope atomic (executed at the memory side).
+__device__ __forceinline__ void fx_add(int64_t* p, float v) {
+    const long long q = __float2ll_rn(v * (float)(1 << SEER_GN_FX_SHIFT));
+    __hip_atomic_fetch_add(reinterpret_cast<long long*>(p), q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// planes (sum, sum of squares) of the replica / batch element a partial adds to: colsum_fx[rep][b][2][N]
+__device__ __forceinline__ int64_t* fx_slot(const seer_gemm_desc& p, int partial_index, int first_row) {
+    const int nb = p.M / p.colsum_fx_rows;
+    return p.colsum_fx + (int64_t)(((partial_index % p.colsum_fx_reps) * nb + first_row / p.colsum_fx_rows) * 2) * p.N;
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

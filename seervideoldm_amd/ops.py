@@ -60,6 +60,50 @@ class ColSums:
         self.buf, self.C, self.phases, self.tiles = buf, C_, phases, tiles
 
 
+class ColSumsFx:
+    """Column sums ACCUMULATED per batch element in 64-bit fixed point (seer_gemm_desc::colsum_fx): buf [reps, batch, 2, C] int64
+    out of an FxArena (planes: sum, sum of squares at scale 2^20; the replicas are added by the reader).  groupnorm_apply_fx
+    normalises with them in one launch."""
+    __slots__ = ("buf", "C")
+
+    def __init__(self, buf: torch.Tensor, C_: int):
+        self.buf, self.C = buf, C_
+
+    @property
+    def reps(self) -> int:
+        return self.buf.shape[0]
+
+    def totals(self) -> torch.Tensor:
+        """[batch, C, 2] fp64 (sum, sum of squares)"""
+        return self.buf.sum(dim=0).permute(0, 2, 1).to(torch.float64) / float(1 << 20)
+
+
+class FxArena:
+    """Bump allocator over one int64 buffer for the ColSumsFx of a UNet evaluation: reset() once per evaluation zeroes what the
+    previous evaluation of the same schedule used (one fill launch), take() hands out [batch, C, 2] slices.  Pass
+    colsum_batch=(B, arena) to gemm / conv3x3 / conv_up2x."""
+
+    def __init__(self, device, int64_elems: int):
+        self.buf = torch.zeros((int64_elems,), device=device, dtype=torch.int64)
+        self.used = 0
+        self.high = int64_elems        # everything is zero now; reset() zeroes the prefix that has been handed out since
+
+    def reset(self):
+        if self.high:
+            self.buf[:self.high].zero_()
+        self.used = 0
+        self.high = 0
+
+    def take(self, reps: int, batch: int, C_: int) -> Optional[torch.Tensor]:
+        n = reps * batch * C_ * 2
+        if self.used + n > self.buf.numel():
+            return None
+        t = self.buf[self.used:self.used + n].view(reps, batch, 2, C_)
+        self.used += n
+        self.high = max(self.high, self.used)
+        return t
+
+
 # ------------------------------------------------------------------------------------------------------------
 def gemm(a: torch.Tensor, w: torch.Tensor, *, bias=None, residual=None, rowvec=None, rows_per_batch=0,
          a2: Optional[torch.Tensor] = None, geglu=False, silu=False, out_f32=False, out: Optional[torch.Tensor] = None,
@@ -155,8 +199,19 @@ def _launch_gemm(d: GemmDesc, device, what: str, colsum_batch: int = 0) -> Optio
     if 0 < nsync <= _SYNC_BYTES:
         d.sync, d.sync_bytes = _sync_buffer(device).data_ptr(), _SYNC_BYTES
     cs = None
+    arena = None
+    if isinstance(colsum_batch, tuple):
+        colsum_batch, arena = colsum_batch
     if colsum_batch > 0 and d.M % colsum_batch == 0:
-        rows = lib.seer_gemm_colsum_rows(C.byref(d))
+        fx = None
+        if arena is not None:
+            reps = C.c_int32(1)
+            if lib.seer_gemm_colsum_fx_layout(C.byref(d), d.M // colsum_batch, C.byref(reps)) > 0:
+                fx = arena.take(reps.value, colsum_batch, int(d.N))
+        if fx is not None:
+            d.colsum_fx, d.colsum_fx_rows, d.colsum_fx_reps = fx.data_ptr(), d.M // colsum_batch, fx.shape[0]
+            cs = ColSumsFx(fx, int(d.N))
+        rows = 0 if fx is not None else lib.seer_gemm_colsum_rows(C.byref(d))
         if rows > 0 and (d.M // colsum_batch) % rows == 0:
             phases, tiles = max(int(d.batch), 1), d.M // rows
             buf = torch.empty((phases, tiles, d.N, 2), device=device, dtype=torch.float32)
@@ -421,6 +476,34 @@ def groupnorm_apply_from_colsums(x1: torch.Tensor, x2: Optional[torch.Tensor], c
         return None
     check(rc, "seer_groupnorm_apply_from_colsums")
     return out
+
+
+def groupnorm_apply_fx(x1: torch.Tensor, x2: Optional[torch.Tensor], fx1: ColSumsFx, fx2: Optional[ColSumsFx], batch: int,
+                       groups: int, count: float, eps: float, gamma: torch.Tensor, beta: torch.Tensor, silu: bool,
+                       out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """GroupNorm (+ SiLU) from the producers' accumulated fixed-point column sums: ONE launch, no statistics pass.  Returns None
+    when the channel layout does not slice into whole groups (SEER_ENOSYS)."""
+    _req(x1, bf16, "x1")
+    rows = x1.shape[0] // batch
+    C2 = 0 if x2 is None else x2.shape[1]
+    assert fx1.C == x1.shape[1] and fx1.buf.shape[1] == batch and (x2 is None or (fx2.C == C2 and fx2.buf.shape[1] == batch))
+    if out is None:
+        out = torch.empty((x1.shape[0], x1.shape[1] + C2), device=x1.device, dtype=bf16)
+    _req(gamma, torch.float32, "gamma"); _req(beta, torch.float32, "beta")
+    rc = _lib.load().seer_groupnorm_apply_fx(_p(x1), x1.shape[1], _p(x2), C2, _p(fx1.buf), fx1.reps,
+                                             _p(fx2.buf) if x2 is not None else None, fx2.reps if x2 is not None else 0, batch, rows, groups, float(count), float(eps), _p(gamma), _p(beta), int(silu),
+                                             _p(out), _stream())
+    if rc == _lib.SEER_ENOSYS:
+        return None
+    check(rc, "seer_groupnorm_apply_fx")
+    return out
+
+
+def groupnorm_stats_from_fx(fx1: ColSumsFx, fx2: Optional[ColSumsFx], batch: int, groups: int, stats: torch.Tensor) -> torch.Tensor:
+    """stats[b][g] = (sum, sumsq) from accumulated column sums (torch ops; the fall-back of a layout groupnorm_apply_fx refuses)."""
+    v = fx1.totals() if fx2 is None else torch.cat([fx1.totals(), fx2.totals()], dim=1)
+    stats.copy_(v.view(batch, groups, -1, 2).sum(dim=2).to(torch.float32))
+    return stats
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,

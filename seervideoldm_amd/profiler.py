@@ -80,7 +80,7 @@ class TimedOps:
                 nb = 4 * (cs1.buf.numel() + (0 if cs2 is None else cs2.buf.numel()))
                 return self._timed("groupnorm_stats", 0.0, nb, base, cs1, cs2, *a, **k)
             return f
-        if name == "groupnorm_apply_from_colsums":
+        if name in ("groupnorm_apply_from_colsums", "groupnorm_apply_fx"):
             # statistics + apply in one launch: timed as the apply it replaces (bytes: one read + one write of the activations)
             def f(x1, x2, *a, **k):
                 nb = 4 * (x1.numel() + (0 if x2 is None else x2.numel()))

@@ -210,6 +210,11 @@ class _Engine:
         self.gn_colsums = bool(getattr(model, "gn_colsums", True))
         # statistics from column sums INSIDE the apply launch (model.gn_fused = False / SEER_GN_FUSED=0: the two-launch form, A/B runs)
         self.gn_fused = bool(getattr(model, "gn_fused", os.environ.get("SEER_GN_FUSED", "1") != "0"))
+        # ... and, single-process engines: the producers ACCUMULATE the sums per batch element in fixed point (ops.ColSumsFx) and the
+        # apply launch reads them directly -- no finalize launch either (model.gn_fx = False / SEER_GN_FX=0: the forms above)
+        self.gn_fx = bool(getattr(model, "gn_fx", os.environ.get("SEER_GN_FX", "1") != "0"))
+        self._fx_arena = None
+        self._fx = None
         self.gn_from_colsums = 0
         self.w: Dict[str, torch.Tensor] = {}
         self._pack(sd)
@@ -307,7 +312,18 @@ class _Engine:
         cs1 = getattr(x1, "colsums", None)
         cs2 = getattr(x2, "colsums", None) if x2 is not None else None
         C = x1.shape[1] + (0 if x2 is None else x2.shape[1])
-        if self.gn_colsums and cs1 is not None and (x2 is None or cs2 is not None):
+        FX = getattr(ops, "ColSumsFx", ())
+        if isinstance(cs1, FX) or isinstance(cs2, FX):
+            if isinstance(cs1, FX) and (x2 is None or isinstance(cs2, FX)):
+                y = ops.groupnorm_apply_fx(x1, x2, cs1, cs2, B, self.G, rows_pb * (C // self.G), eps,
+                                           self.w[name + ".weight"], self.w[name + ".bias"], silu)
+                self.gn_from_colsums += 1
+                if y is not None:
+                    return y
+                ops.groupnorm_stats_from_fx(cs1, cs2, B, self.G, stats)
+            else:
+                ops.groupnorm_stats(x1, x2, B, self.G, stats)
+        elif self.gn_colsums and cs1 is not None and (x2 is None or cs2 is not None):
             if self.shard is None and self.gn_fused:
                 # one launch: every apply block re-derives the statistics of its own groups from the column sums (no frame
                 # shards: a sharded run all-reduces the statistics between the two steps)
@@ -326,6 +342,12 @@ class _Engine:
         return ops.groupnorm_apply(x1, x2, B, self.G, stats, count, eps, self.w[name + ".weight"],
                                    self.w[name + ".bias"], silu)
 
+    def _cb(self, B):
+        """`colsum_batch` of a launch whose output feeds a GroupNorm: (B, arena) = accumulate in fixed point, B = per-tile sums."""
+        if not self.gn_colsums:
+            return 0
+        return (B, self._fx) if self._fx is not None else B
+
     def _resnet(self, p, x, skip, geo):
         """ResnetBlock3D (resnet.py:174-208); `skip` is the channel-concat partner of unet_3d_blocks.py:596,712."""
         ops, w = self.ops, self.w
@@ -333,7 +355,7 @@ class _Engine:
         rows_pb = Fr * H * W
         off, n = self.temb_slices[p]
         temb = self._temb[:, off:off + n]
-        cb = B if self.gn_colsums else 0   # outputs that feed a GroupNorm leave their column sums behind
+        cb = self._cb(B)                   # outputs that feed a GroupNorm leave their column sums behind
         h = self._gn(x, skip, B, rows_pb, p + ".norm1", self.eps, True)
         h = ops.conv3x3(h, w[p + ".conv1.weight"], B * Fr, H, W, bias=w[p + ".conv1.bias"], rowvec=temb,
                         rows_per_batch=rows_pb, colsum_batch=cb)
@@ -385,7 +407,7 @@ class _Engine:
         ops.gemm(a, w[tb + ".attn2.to_out.0.weight"], bias=w[tb + ".attn2.to_out.0.bias"], residual=h, out=h)
         self._ff(tb, h)
         return ops.gemm(h, w[p + ".proj_out.weight"], bias=w[p + ".proj_out.bias"], residual=x,
-                        colsum_batch=B if self.gn_colsums else 0)
+                        colsum_batch=self._cb(B))
 
     def _cross_scores(self, q, k, B, Fr, H, W, heads, d, L):
         """`attention_scores` of the text cross attention (attention.py:556-584: scale * Q K^T before the softmax) as
@@ -452,7 +474,7 @@ class _Engine:
             for b in range(B):
                 self._ff(tb, h[b * Fr * HW + skip_f * HW:(b + 1) * Fr * HW])
         return ops.gemm(h, w[p + ".proj_out.weight"], bias=w[p + ".proj_out.bias"], residual=x,
-                        colsum_batch=B if self.gn_colsums else 0)
+                        colsum_batch=self._cb(B))
 
     # ---- the schedule ---------------------------------------------------------------------------------------------
     def n_groupnorms(self):
@@ -472,6 +494,15 @@ class _Engine:
         self._stats_arena = torch.empty((self.n_groupnorms(), B, self.G, 2), device=sample.device, dtype=torch.float32)
         self._stats_i = 0
         self.gn_from_colsums = 0        # GroupNorms of this forward that took their statistics from column sums
+        self._fx = None
+        if self.gn_fx and self.gn_colsums and self.shard is None and hasattr(ops, "FxArena"):
+            # every colsum producer of the evaluation takes a [B, C, 2] slot; reset() = one fill over what the last evaluation used
+            need = (self.n_groupnorms() + 16) * B * 4 * max(boc) * 2       # capacity; only what an evaluation takes is ever zeroed
+            if self._fx_arena is None or self._fx_arena.buf.numel() < need:
+                assert not torch.cuda.is_current_stream_capturing(), "the column-sum arena must exist before a graph capture"
+                self._fx_arena = ops.FxArena(sample.device, need)
+            self._fx_arena.reset()
+            self._fx = self._fx_arena
         emb = ops.timestep_embedding(t, boc[0], self.cfg.flip_sin_to_cos, self.cfg.freq_shift)
         emb = ops.linear_smallm(emb, w["time_embedding.linear_1.weight"], w["time_embedding.linear_1.bias"], silu_out=True)
         emb = ops.linear_smallm(emb, w["time_embedding.linear_2.weight"], w["time_embedding.linear_2.bias"])
@@ -490,7 +521,7 @@ class _Engine:
                 skips.append(x)
             if i < n - 1:
                 x = ops.conv3x3(x, w[f"{p}.downsamplers.0.conv.weight"], B * Fr, geo[2], geo[3], stride=2,
-                                bias=w[f"{p}.downsamplers.0.conv.bias"], colsum_batch=B if self.gn_colsums else 0)
+                                bias=w[f"{p}.downsamplers.0.conv.bias"], colsum_batch=self._cb(B))
                 geo = (B, Fr, (geo[2] - 1) // 2 + 1, (geo[3] - 1) // 2 + 1)
                 skips.append(x)
         x = self._resnet("mid_block.resnets.0", x, None, geo)
@@ -506,7 +537,7 @@ class _Engine:
                     x = self._temporal_transformer(f"{p}.temporal_attentions.{j}", x, geo, cond_frame)
             if i < n - 1:
                 x = ops.conv_up2x(x, w[f"{p}.upsamplers.0.conv.weight_up4"], B * Fr, geo[2], geo[3],
-                                  bias=w[f"{p}.upsamplers.0.conv.bias"], colsum_batch=B if self.gn_colsums else 0)
+                                  bias=w[f"{p}.upsamplers.0.conv.bias"], colsum_batch=self._cb(B))
                 geo = (B, Fr, geo[2] * 2, geo[3] * 2)
         x = self._gn(x, None, B, Fr * geo[2] * geo[3], "conv_norm_out", self.eps, True)
         out = ops.conv_out(x, w["conv_out.weight"], w["conv_out.bias"], B, Fr, geo[2], geo[3])

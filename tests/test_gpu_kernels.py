@@ -942,3 +942,93 @@ def test_groupnorm_apply_from_colsums(device, C1, C2, rows, tile):
     assert (got.float() - two.float()).abs().max().item() <= 2 ** -6 * ref.abs().max().item()      # at most a bf16 ulp apart
     again = ops.groupnorm_apply_from_colsums(x1, x2, x1.colsums, x2.colsums if C2 else None, B, G, count, 1e-5, gamma, beta, True)
     assert torch.equal(got, again), "fixed order of additions: bit-identical from launch to launch"
+
+
+@pytest.mark.parametrize("kind,shape,tile,splits", [
+    ("gemm", (1536, 640, 640), 0, 0), ("gemm", (3072, 320, 320), 16, 1), ("gemm", (768, 1280, 2560), 0, 0),
+    ("gemm", (2048, 320, 2560), 22, 1), ("gemm", (1024, 1280, 5120), 22, 4),
+    ("conv", (8, 16, 16, 640, 640), 0, 0), ("conv", (24, 4, 4, 1280, 1280), 0, 0), ("conv", (8, 16, 16, 640, 640), 8, 1),
+    ("conv", (8, 8, 8, 1280, 1280), 5, 4), ("conv", (8, 16, 16, 640, 640), 22, 1), ("up", (4, 8, 8, 640, 640), 0, 0),
+    ("up", (4, 8, 8, 640, 640), 22, 1), ("down", (8, 16, 16, 320, 320), 0, 0),
+])
+def test_column_sums_accumulated_in_fixed_point(device, kind, shape, tile, splits):
+    """seer_gemm_desc::colsum_fx: the launch ADDS (sum, sum of squares) of its stored output per (batch element, column) to an
+    int64 buffer at scale 2^20 -- tile epilogue, split-K reduce pass, the four phases of an upsampling conv, the 256 x 320 tile.
+    Against torch sums in fp64 of the stored bf16 output (resnet.py:179,197 / attention.py:133 take the statistics of exactly
+    these tensors); integer adds commute: a second launch into a fresh buffer gives the same bits."""
+    from seervideoldm_amd import ops
+    B = 2
+
+    def run(arena):
+        cb = (B, arena)
+        if kind == "gemm":
+            M, N, K = shape
+            a = _rand((M, K), device, 1).to(bf16)
+            w = (_rand((N, K), device, 2) / math.sqrt(K)).to(bf16)
+            return ops.gemm(a, w, bias=_rand((N,), device, 5), residual=_rand((M, N), device, 3).to(bf16), tile=tile, splits=splits,
+                            colsum_batch=cb)
+        n_img, H, W, Ci, Co = shape
+        x = _rand((n_img * H * W, Ci), device, 1).to(bf16)
+        if kind == "up":
+            from seervideoldm_amd.weights import pack_conv3x3_up_phases
+            w = _rand((Co, Ci, 3, 3), device, 2) / math.sqrt(9 * Ci)
+            return ops.conv_up2x(x, pack_conv3x3_up_phases(w).to(bf16), n_img, H, W, bias=_rand((Co,), device, 5), tile=tile, colsum_batch=cb)
+        w = (_rand((Co, 9 * Ci), device, 2) / math.sqrt(9 * Ci)).to(bf16)
+        if kind == "down":
+            return ops.conv3x3(x, w, n_img, H, W, stride=2, bias=_rand((Co,), device, 5), tile=tile, splits=splits, colsum_batch=cb)
+        return ops.conv3x3(x, w, n_img, H, W, bias=_rand((Co,), device, 5), rowvec=_rand((B, Co), device, 4),
+                           rows_per_batch=n_img // B * H * W, tile=tile, splits=splits, colsum_batch=cb)
+    arena = ops.FxArena(device, 1 << 18)
+    arena.reset()
+    y = run(arena)
+    fx = y.colsums
+    assert isinstance(fx, ops.ColSumsFx), "this launch was expected to accumulate its column sums"
+    v = y.double().reshape(B, -1, y.shape[1])
+    ref = torch.stack([v.sum(dim=1), (v * v).sum(dim=1)], -1)
+    got = fx.totals()
+    # one rounding to 2^-21 per partial, at most rows / 4 partials per column; the partial itself is an fp32 sum of <= 256 terms
+    tol = 2.0 ** -21 * v.shape[1] / 4 + 1e-6 * (v.abs().sum(dim=1).max().item() + (v * v).sum(dim=1).max().item())
+    assert (got - ref).abs().max().item() <= tol, ((got - ref).abs().max().item(), tol)
+    arena2 = ops.FxArena(device, 1 << 18)
+    arena2.reset()
+    y2 = run(arena2)
+    assert torch.equal(y2, y) and torch.equal(y2.colsums.buf, fx.buf), "integer accumulation: the same bits from launch to launch"
+    arena.reset()
+    assert int(arena.buf.abs().max().item()) == 0 and arena.used == 0
+
+
+@pytest.mark.parametrize("C1,C2,rows", [(320, 0, 1536), (640, 0, 768), (1280, 0, 512), (640, 320, 768), (1280, 1280, 256),
+                                        (320, 320, 12288), (1280, 640, 512), (640, 640, 3072), (2560, 0, 192)])
+def test_groupnorm_apply_fx(device, C1, C2, rows):
+    """GroupNorm (+ SiLU) whose statistics are the producers' accumulated fixed-point column sums: ONE launch per norm, against
+    F.group_norm in fp32 on the stored bf16 activations (resnet.py:179,197, attention.py:133) and against the two-launch form;
+    both skip-concat layouts (group width 30 and 60)."""
+    from seervideoldm_amd import ops
+    B, G = 2, 32
+    M = B * rows
+    arena = ops.FxArena(device, 1 << 18)
+    arena.reset()
+
+    def produce(C, seed):
+        a = _rand((M, 320), device, seed).to(bf16)
+        w = _rand((C, 320), device, seed + 1, 320 ** -0.5).to(bf16)
+        y = ops.gemm(a, w, bias=_rand((C,), device, seed + 2) * 3, colsum_batch=(B, arena))
+        assert isinstance(y.colsums, ops.ColSumsFx)
+        return y
+    x1 = produce(C1, 1)
+    x2 = produce(C2, 11) if C2 else None
+    C = C1 + C2
+    gamma, beta = _rand((C,), device, 21) + 1.0, _rand((C,), device, 22)
+    count = rows * (C // G)
+    got = ops.groupnorm_apply_fx(x1, x2, x1.colsums, x2.colsums if C2 else None, B, G, count, 1e-5, gamma, beta, True)
+    assert got is not None
+    xc = x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], 1)
+    ref = Fn.silu(Fn.group_norm(xc.reshape(B, rows, C).permute(0, 2, 1), G, gamma, beta, 1e-5)).permute(0, 2, 1).reshape(M, C)
+    _close(got, ref, rtol=1e-2, atol=1e-2, what=f"groupnorm_apply_fx C {C1}+{C2}")
+    stats = torch.zeros((B, G, 2), device=device, dtype=torch.float32)
+    ops.groupnorm_stats(x1, x2, B, G, stats)
+    two = ops.groupnorm_apply(x1, x2, B, G, stats, count, 1e-5, gamma, beta, True)
+    assert (got.float() - two.float()).abs().max().item() <= 2 ** -6 * ref.abs().max().item()      # at most a bf16 ulp apart
+    s2 = torch.zeros_like(stats)
+    ops.groupnorm_stats_from_fx(x1.colsums, x2.colsums if C2 else None, B, G, s2)
+    assert (s2 - stats).abs().max().item() <= 1e-4 * stats.abs().max().item()

@@ -106,10 +106,11 @@ def test_segmented_graph_replay(device):
     #  all-reduced between the launches; the reference engine is built the same way so that the comparison stays bit for bit)
     m._engine = None
     m.gn_fused = False
+    m.gn_fx = False
     try:
         ref = m(x, t, ctx).clone()
     finally:
-        del m.gn_fused
+        del m.gn_fused, m.gn_fx
         m._engine = None
     shard = parallel.attach(m, 1, 0)
     shard.debug_boundaries = True
