@@ -138,8 +138,26 @@ typedef struct seer_gemm_desc {
      * < 2^43 per (batch element, column). */
     int64_t* colsum_fx;
     int32_t colsum_fx_rows, colsum_fx_reps;
+    /* ---- LayerNorm folded into the GEMM that consumes it (BasicTransformerBlock: norm1 -> to_q|k|v, norm2 -> attn2.to_q,
+     * norm3 -> ff.net.0, attention.py:198-200, 231-246, 275-277, 308-327).  With W' = gamma (.) W (scaled along K) and
+     * x = the UN-normalised rows,  LN(x) W^T = rstd * (x W'^T - mean * wsum) + (beta W^T + b),  wsum[n] = sum_k W'[n][k]:
+     * the LayerNorm launch, its read and its write of the activations disappear.
+     * Producer side (the GEMM that writes x): rowstat[m][2] += round((sum, sum of squares) of the wave's columns of row m
+     * * 2^SEER_LN_FX_SHIFT), 64-bit integer atomic adds like colsum_fx (one pair per row and wave column; integer adds commute:
+     * bit-identical from run to run).  ZERO the buffer before the launch.  The sums are taken from the fp32 values the
+     * epilogue is about to round to bf16.  Valid when seer_gemm_rowstat_ok(desc). */
+    int64_t* rowstat;
+    /* Consumer side: A = x [M][K] (K = the normalised width, A2 NULL), W = W', bias = beta W^T + b; ln_rowstat = the producer's
+     * rowstat, ln_wsum fp32 [N] (sums of the bf16-ROUNDED W' rows, so that the mean cancels exactly), ln_eps the LayerNorm's
+     * epsilon.  The term is applied to the accumulators before bias / GEGLU / rotary / column scale / residual.  Valid when
+     * seer_gemm_lnfold_ok(desc) (unsplit tile-kernel launches with a staged bf16 output; a launch AUTO would give to the
+     * weight-stationary kernel says no: LayerNorm + that kernel is the faster pair there). */
+    const int64_t* ln_rowstat;
+    const float* ln_wsum;
+    float ln_eps;
 } seer_gemm_desc;
 #define SEER_GN_FX_SHIFT 20
+#define SEER_LN_FX_SHIFT 24
 
 #define SEER_TILE_AUTO 0
 #define SEER_TILE_128x128 1
@@ -180,6 +198,11 @@ int32_t seer_gemm_colsum_rows(const seer_gemm_desc* desc /* host */);
  * (rows_per_batch must be a multiple; 0: the launch cannot accumulate column sums) and sets *reps = the replica count to
  * allocate and pass as colsum_fx_reps */
 int32_t seer_gemm_colsum_fx_layout(const seer_gemm_desc* desc /* host */, int32_t rows_per_batch, int32_t* reps);
+/* 1 when this exact launch can accumulate the row statistics of its output (desc->rowstat), else 0 */
+int32_t seer_gemm_rowstat_ok(const seer_gemm_desc* desc /* host */);
+/* 1 when this exact launch (ln_rowstat / ln_wsum set) applies the folded LayerNorm, 0 when the caller has to run
+ * seer_layernorm and the unfolded weights instead */
+int32_t seer_gemm_lnfold_ok(const seer_gemm_desc* desc /* host */);
 /* bytes of zeroed counter memory (desc->sync) the call would use to reduce its K slices inside the launch (0: none) */
 int64_t seer_gemm_sync_bytes(const seer_gemm_desc* desc /* host */);
 

@@ -142,6 +142,14 @@ int main(int argc, char** argv) {
             int32_t reps = 1;
             if (seer_gemm_colsum_fx_layout(&d, d.M / 2, &reps) > 0) { d.colsum_fx = (int64_t*)dCs; d.colsum_fx_rows = d.M / 2; d.colsum_fx_reps = reps; }
         }
+        if (getenv("LAB_ROWSTAT") && !s.geglu && !s.conv) {      // the launch also accumulates the row statistics of its output
+            d.rowstat = (int64_t*)dCs;
+            if (!seer_gemm_rowstat_ok(&d)) d.rowstat = nullptr;
+        }
+        if (getenv("LAB_LN") && !s.conv) {                      // folded LayerNorm in front (statistics of a zeroed buffer: timing only)
+            d.ln_rowstat = (const int64_t*)dCs; d.ln_wsum = dB; d.ln_eps = 1e-5f;
+            if (!seer_gemm_lnfold_ok(&d)) { d.ln_rowstat = nullptr; d.ln_wsum = nullptr; }
+        }
         const bool stamps = getenv("LAB_STAMPS") != nullptr;
         if (stamps) { d.workspace = dWs; d.workspace_bytes = 777; CK(hipMemset(dWs, 0, 1 << 22)); }
         int rc = 0;

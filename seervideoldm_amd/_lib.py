@@ -13,7 +13,7 @@ _PKG = Path(__file__).resolve().parent
 _LIB_PATH = _PKG / "lib" / "libseer_hip.so"
 _lib = None
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 SEER_GEMM_PLAIN = 0
 SEER_GEMM_CONV3X3 = 1
@@ -53,6 +53,7 @@ class GemmDesc(C.Structure):
         ("col_scale_cols", C.c_int32), ("col_scale", C.c_float),
         ("colsum", C.c_void_p), ("sync", C.c_void_p), ("sync_bytes", C.c_int64),
         ("colsum_fx", C.c_void_p), ("colsum_fx_rows", C.c_int32), ("colsum_fx_reps", C.c_int32),
+        ("rowstat", C.c_void_p), ("ln_rowstat", C.c_void_p), ("ln_wsum", C.c_void_p), ("ln_eps", C.c_float),
     ]
 
 
@@ -92,6 +93,8 @@ SIGNATURES = {
     "seer_gemm_workspace_bytes": ([C.POINTER(GemmDesc)], C.c_int64),
     "seer_gemm_colsum_rows": ([C.POINTER(GemmDesc)], C.c_int32),
     "seer_gemm_sync_bytes": ([C.POINTER(GemmDesc)], C.c_int64),
+    "seer_gemm_rowstat_ok": ([C.POINTER(GemmDesc)], C.c_int32),
+    "seer_gemm_lnfold_ok": ([C.POINTER(GemmDesc)], C.c_int32),
     "seer_attn_fwd": ([C.POINTER(AttnDesc), _vp], C.c_int),
     "seer_rotary_table": ([_vp, _i32, _i32, _vp, _vp], C.c_int),
     "seer_rotary_inplace": ([_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp], C.c_int),

@@ -90,6 +90,17 @@ constexpr bool tile_colsum_ok() {
     return !PP8 && BN <= NT && BM * CPITCH + (NT / (BN / 2)) * BN * 8 <= (NS == 0 ? 2 : NS) * STAGE * (int)sizeof(bf16);
 }
 
+// whether a tile instantiation can take part in a folded LayerNorm (seer_gemm_desc::rowstat / ln_rowstat): the consumer parks
+// (mean * rstd, rstd) of its BM rows behind the staged C tile and the column-sum scratch
+template <int BM, int BN, int NS, int WM, int WN>
+constexpr bool tile_ln_ok() {
+    constexpr int NT = 64 * WM * WN, STAGE = (BM + BN) * BK;
+    constexpr bool PP8 = WM == 2 && WN == 4 && BM == 256 && BN == 256;
+    constexpr bool CSWZ = BM * (BN * 2 + 16) > 2 * STAGE * (int)sizeof(bf16);
+    constexpr int CPITCH = BN * 2 + (CSWZ ? 0 : 16);
+    return !PP8 && BM <= NT && BM * CPITCH + 4096 + BM * 8 <= (NS == 0 ? 2 : NS) * STAGE * (int)sizeof(bf16);
+}
+
 // F16: A, A2, W, residual and C hold IEEE half instead of bf16 (SEER_EPI_F16: the VAE, which the reference runs in fp32 --
 // 11 significand bits instead of 8 at the same MFMA rate).  Same 16-bit loads and LDS image; only the MFMA opcode and the
 // pack / unpack of the epilogue differ.
@@ -319,6 +330,37 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
                     rpre[i][j] = (m < p.M && n < p.N) ? *reinterpret_cast<const u32x2*>(R + (int64_t)m * p.ldr + n)
                                                         : u32x2{0u, 0u};
                 }
+            }
+        }
+    }
+
+    // folded LayerNorm (seer_gemm_desc::ln_rowstat): thread t < BM reads the accumulated (sum, sum of squares) of tile row t and
+    // keeps (mean * rstd, rstd) through the K loop; the epilogue hands them to the lanes that own the row through LDS
+    constexpr bool LN_OK = !SPLIT && !F16 && tile_ln_ok<BM, BN, NS, WM, WN>();
+    float ln_mr = 0.f, ln_r = 1.f;
+    if constexpr (LN_OK) {
+        if (p.ln_rowstat && tid < BM) {
+            const int m = min(m0 + tid, p.M - 1);
+            const long long* q = reinterpret_cast<const long long*>(p.ln_rowstat) + (int64_t)m * 2;
+            const float sm = (float)((double)q[0] * (1.0 / (double)(1 << SEER_LN_FX_SHIFT)));
+            const float sq = (float)((double)q[1] * (1.0 / (double)(1 << SEER_LN_FX_SHIFT)));
+            const float inv = 1.0f / (float)p.K;
+            const float mean = sm * inv;
+            float var = sq * inv - mean * mean;
+            var = var > 0.f ? var : 0.f;
+            ln_r = rsqrtf(var + p.ln_eps);
+            ln_mr = mean * ln_r;
+        }
+    }
+    // ... and the lane's wsum quads, requested before the K loop like the bias (a dependent L2 round trip at the head of the
+    // epilogue otherwise)
+    f32x4 spre[LN_OK ? TN : 1];
+    if constexpr (LN_OK) {
+        if (p.ln_rowstat) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WTN + j * 16 + (lane >> 4) * 4;
+                spre[j] = n < p.N ? *reinterpret_cast<const f32x4*>(p.ln_wsum + n) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
     }
@@ -798,6 +840,25 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
     const bool staged = !out_f32 && !trans && (p.ldc % 8 == 0) && (p.N % (GEGLU ? 16 : 8) == 0) &&
                         ((reinterpret_cast<uintptr_t>(Cb) & 15) == 0);
     if (staged) __syncthreads();                        // every wave is done with the K-loop stages
+    // folded LayerNorm: acc <- rstd * acc - (mean * rstd) * wsum[n], first term of the epilogue (the host admits it only for
+    // staged launches: the row statistics travel through the idle K-loop LDS)
+    constexpr int LNROW_OFF = BM * CPITCH + 4096;
+    bool do_ln = false;
+    float lmr[TM], lr[TM];
+    if constexpr (LN_OK) {
+        do_ln = p.ln_rowstat != nullptr && staged;
+        if (do_ln) {
+            float* lnrow = reinterpret_cast<float*>(smem + LNROW_OFF);
+            if (tid < BM) *reinterpret_cast<f32x2*>(lnrow + tid * 2) = f32x2{ln_mr, ln_r};
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const f32x2 v = *reinterpret_cast<const f32x2*>(lnrow + (wm * WTM + i * 16 + frow) * 2);
+                lmr[i] = v[0];
+                lr[i] = v[1];
+            }
+        }
+    }
 
     // ---- fast epilogue: a full tile whose epilogue is bias / GEGLU / preloaded row vector / rotary / column scale / preloaded
     // residual into the staged C tile (every FF, projection, q|k|v and conv GEMM of the U-Net).  The general body below tests each descriptor flag for each of the
@@ -805,10 +866,32 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
     // issue per 256x256 tile and 1.6 us per 128x128 tile (profiles/r02_pp8_stamps.log).  Here every term is its own pass over
     // the accumulators behind ONE wave-uniform branch, in the general body's order of additions (bit-identical results), and
     // the staging address is one XOR per fragment column plus an immediate offset per fragment row.
+    // row statistics of the output (seer_gemm_desc::rowstat): each lane adds the fp32 values of its quads per fragment row, the
+    // four lanes of a row meet by two lane exchanges, one atomic pair per (row, wave column)
+    constexpr bool RS_OK = !GEGLU && !SPLIT && !F16 && tile_ln_ok<BM, BN, NS, WM, WN>();
+    bool do_rs = false;
+    float rsum[TM], rsq[TM];
+    if constexpr (RS_OK) {
+        do_rs = p.rowstat != nullptr;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { rsum[i] = 0.f; rsq[i] = 0.f; }
+    }
     const bool fast_epi = staged && m0 + BM <= p.M && n0 + BN <= p.N && !do_silu &&
                           (!GEGLU || !(do_rot || (p.epilogue & SEER_EPI_COLSCALE))) && (!p.rowvec || (RV_PRE && rv_pre_ok)) &&
                           (!R || RES_PRE);          // a residual that was not prefetched takes the general body
     if (fast_epi) {
+        if constexpr (LN_OK) {
+            if (do_ln) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const f32x4 sv = spre[j];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[i][j][r] = ln_term(acc[i][j][r], lr[i], sv[r], lmr[i]);
+                }
+            }
+        }
         if (p.bias) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -896,6 +979,20 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
                 }
             }
         }
+        if constexpr (RS_OK) {
+            if (do_rs) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    float sm = 0.f, sq = 0.f;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { sm += acc[i][j][r]; sq = fmaf(acc[i][j][r], acc[i][j][r], sq); }
+                    rsum[i] = sm;
+                    rsq[i] = sq;
+                }
+            }
+        }
         // byte column of the lane's quad inside the staged row: GEGLU halves the column pitch (value columns only)
         const int cb0 = GEGLU ? (wn * WTN + fq * 8) : (wn * WTN * 2 + fq * 8);
         const int rowb = (wm * WTM + frow) * CPITCH;
@@ -924,6 +1021,13 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+                if constexpr (LN_OK) {
+                    if (do_ln) {
+                        const f32x4 sv = spre[j];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = ln_term(v[r], lr[i], sv[r], lmr[i]);
+                    }
+                }
                 if (p.bias) {
                     f32x4 bv;
                     if constexpr (BIAS_PRE) bv = bpre[j];
@@ -936,6 +1040,13 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
                     float g[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) g[r] = acc[i][j + 1][r];
+                    if constexpr (LN_OK) {
+                        if (do_ln) {
+                            const f32x4 sv = spre[j + 1];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) g[r] = ln_term(g[r], lr[i], sv[r], lmr[i]);
+                        }
+                    }
                     if (p.bias) {
                         f32x4 bg;
                         if constexpr (BIAS_PRE) bg = bpre[j + 1];
@@ -984,6 +1095,12 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
                     v[2] += r23[0];
                     v[3] += r23[1];
                 }
+                if constexpr (RS_OK) {
+                    if (do_rs) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { rsum[i] += v[r]; rsq[i] = fmaf(v[r], v[r], rsq[i]); }
+                    }
+                }
                 if (trans) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -1009,6 +1126,20 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
             }
         }
     }   // general epilogue
+    if constexpr (RS_OK) {
+        if (do_rs) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float sm = rsum[i], sq = rsq[i];
+                sm += __shfl_xor(sm, 16); sq += __shfl_xor(sq, 16);
+                sm += __shfl_xor(sm, 32); sq += __shfl_xor(sq, 32);
+                // ONE instruction for both: lanes fq = 0 add the sums, lanes fq = 1 the squares of the same 16 rows -- 256 contiguous
+                // bytes = four fully used 64-byte atomic requests (the requests are the cost: ~12 ns each per CU)
+                const int m = m0 + wm * WTM + i * 16 + frow;
+                if (fq < 2 && m < p.M) fx_add_ln(p.rowstat + (int64_t)m * 2 + fq, fq ? sq : sm);
+            }
+        }
+    }
     PSTAMP();
     if (staged) {
         __syncthreads();
@@ -1257,6 +1388,7 @@ int launch_tile(const seer_gemm_desc& d, hipStream_t st) {
     const bool geglu = (d.epilogue & SEER_EPI_GEGLU) != 0;
     if (conv && geglu) return SEER_EINVAL;
     if ((d.colsum || d.colsum_fx) && (geglu || !tile_colsum_ok<BM, BN, NS, WM, WN>() || !colsum_store_ok(d))) return SEER_EINVAL;
+    if ((d.rowstat || d.ln_rowstat) && !tile_ln_ok<BM, BN, NS, WM, WN>()) return SEER_EINVAL;
     if (conv) {
         hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, true, false, false, NS, WM, WN>), grid, dim3(64 * WM * WN), lds, st, d);
     } else if (geglu) {
@@ -1506,6 +1638,7 @@ bool t320_buffers_ok(const seer_gemm_desc& d, int s) {
 }
 // assume_buffers: a size query -- plan as if workspace and sync will be provided; the launch plans with what it was given
 int t320_plan(const seer_gemm_desc& d, bool assume_buffers = false) {
+    if (d.rowstat || d.ln_rowstat) return 0;          // row statistics / folded LayerNorm live in the tile kernel
     if (d.tile != SEER_TILE_T256x320 && d.tile != SEER_TILE_AUTO) return 0;
     if (d.mode != SEER_GEMM_PLAIN && d.mode != SEER_GEMM_CONV3X3) return 0;
     if (!seer_gemm_t320_eligible(d)) return 0;
@@ -1614,6 +1747,47 @@ extern "C" int32_t seer_gemm_colsum_rows(const seer_gemm_desc* desc) {
     return rows > 0 ? rows : 0;           // an unknown tile code comes back as a negative status
 }
 
+// ---- folded LayerNorm (seer_gemm_desc::rowstat / ln_rowstat): such launches stay on the tile kernel, unsplit, with a staged
+// bf16 output.  Returns the tile code the launch takes, 0 when it cannot carry row statistics.
+int ln_resolve(const seer_gemm_desc& in) {
+    seer_gemm_desc d = in;
+    const bool geglu = (d.epilogue & SEER_EPI_GEGLU) != 0;
+    if (d.mode != SEER_GEMM_PLAIN || d.batch > 1 || (d.epilogue & (SEER_EPI_F16 | SEER_EPI_OUT_F32 | SEER_EPI_TRANS_OUT | SEER_EPI_SILU)))
+        return 0;
+    if (d.ldc % 8 || d.N % (geglu ? 16 : 8) || (reinterpret_cast<uintptr_t>(d.C) & 15)) return 0;      // the kernel's `staged`
+    if (d.rowstat && (geglu || d.colsum || d.colsum_fx)) return 0;
+    if (d.ln_rowstat && (d.A2 || !d.ln_wsum || (reinterpret_cast<uintptr_t>(d.ln_wsum) & 15))) return 0;
+    const bool special = d.tile == SEER_TILE_T256x320 || d.tile == SEER_TILE_WS || d.tile == SEER_TILE_AUTO_TILED;
+    if (special) d.tile = SEER_TILE_AUTO;
+    int sp = 1;
+    if (prepare(d, &sp) != SEER_OK) return 0;
+    d.splits = 1;
+    d.tile = special ? SEER_TILE_AUTO : in.tile;
+    const int tile = resolve_tile(d);
+    const int ok = dispatch_tile(tile, [&](auto t) {
+        using T = decltype(t);
+        return tile_ln_ok<T::BM, T::BN, T::NS, T::WM, T::WN>() ? 1 : 0;
+    });
+    return ok == 1 ? tile : 0;
+}
+
+extern "C" int32_t seer_gemm_rowstat_ok(const seer_gemm_desc* desc) {
+    if (!desc) return 0;
+    seer_gemm_desc d = *desc;
+    if (!d.rowstat) d.rowstat = reinterpret_cast<int64_t*>(16);      // the question is about the launch WITH row statistics
+    return ln_resolve(d) ? 1 : 0;
+}
+
+extern "C" int32_t seer_gemm_lnfold_ok(const seer_gemm_desc* desc) {
+    if (!desc || !desc->ln_rowstat) return 0;
+    // a launch AUTO gives to the weight-stationary kernel (the level-0 GEGLU projection) keeps LayerNorm + that kernel: faster
+    // than the tile kernel with the fold (58.7 vs 65.5 us, profiles/r02_tile_sweep_fastepi.log, against 7.6 us of LayerNorm)
+    seer_gemm_desc d = *desc;
+    d.ln_rowstat = nullptr;
+    if (d.tile == SEER_TILE_AUTO && !d.colsum && !d.colsum_fx && !d.rowstat && seer_gemm_ws_eligible(d) && seer_gemm_ws_profitable(d)) return 0;
+    return ln_resolve(*desc) ? 1 : 0;
+}
+
 extern "C" int32_t seer_gemm_colsum_fx_layout(const seer_gemm_desc* desc, int32_t rows_per_batch, int32_t* reps) {
     if (reps) *reps = 1;
     if (!desc || rows_per_batch <= 0 || desc->M % rows_per_batch) return 0;
@@ -1641,7 +1815,9 @@ extern "C" int seer_gemm_bf16(const seer_gemm_desc* desc, void* stream) {
         int reps = 1;
         if (seer_gemm_colsum_fx_layout(desc, d.colsum_fx_rows, &reps) <= 0 || d.colsum_fx_reps < 1) return SEER_EINVAL;
     }
-    if (const int s320 = t320_plan(d)) {
+    const bool rows_ln = d.rowstat || d.ln_rowstat;       // row statistics / folded LayerNorm: tile kernel, unsplit
+    if (rows_ln && !ln_resolve(d)) return SEER_EINVAL;
+    if (const int s320 = rows_ln ? 0 : t320_plan(d)) {
         int sp = 1;
         seer_gemm_desc chk = d;
         chk.tile = SEER_TILE_AUTO;
@@ -1657,13 +1833,13 @@ extern "C" int seer_gemm_bf16(const seer_gemm_desc* desc, void* stream) {
     int s = 1;
     const int rc = prepare(d, &s);
     if (rc != SEER_OK) return rc;
-    if (s > 1 && d.workspace && d.workspace_bytes >= (int64_t)s * d.M * d.N * (int64_t)sizeof(float)) {
+    if (s > 1 && !rows_ln && d.workspace && d.workspace_bytes >= (int64_t)s * d.M * d.N * (int64_t)sizeof(float)) {
         d.splits = s;
         return launch_split(d, st);
     }
     d.splits = 1;
     d.tile = desc->tile == SEER_TILE_T256x320 ? SEER_TILE_AUTO : desc->tile;            // prepare() may have picked a split tile; unsplit launches choose their own below
-    if (!d.colsum && !d.colsum_fx && !(d.epilogue & SEER_EPI_F16) && seer_gemm_ws_eligible(d) &&
+    if (!d.colsum && !d.colsum_fx && !rows_ln && !(d.epilogue & SEER_EPI_F16) && seer_gemm_ws_eligible(d) &&
         (requested == SEER_TILE_WS || (requested == SEER_TILE_AUTO && seer_gemm_ws_profitable(d)))) {
         const int rc_ws = seer_gemm_ws_launch(d, st);
         if (rc_ws != SEER_ENOSYS) return rc_ws;

@@ -120,6 +120,15 @@ __device__ __forceinline__ f32x2 rot_pair(f32x2 x, float c, float s) {
     return __builtin_elementwise_fma(x, f32x2{c, c}, f32x2{t0, t1});
 }
 
+// folded LayerNorm term of a GEMM epilogue: acc * rstd - wsum * (mean * rstd), as two scalar instructions (written in C++ the
+// row scalars sit in the halves of an LDS read pair and hipcc broadcasts the high half with op_sel[1] = 1: the form above)
+__device__ __forceinline__ float ln_term(float acc, float rstd, float wsum, float mean_rstd) {
+    float t, o;
+    asm("v_mul_f32_e32 %0, %1, %2" : "=v"(t) : "v"(wsum), "v"(mean_rstd));
+    asm("v_fma_f32 %0, %1, %2, -%3" : "=v"(o) : "v"(acc), "v"(rstd), "v"(t));
+    return o;
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // exact-erf GELU (F.gelu default, attention.py:785-793) without libm and with ONE transcendental:
 //     gelu(x) = relu(x) - |x| * Phi(-|x|),      Phi(-a) = 0.5 * erfc(a / sqrt 2) = 2^(a * R(a) - 1)
@@ -162,6 +171,10 @@ __device__ __forceinline__ f32x2 gelu_erf_f2(f32x2 x) {
 // depend on arrival order.  No-return agent-scope atomic (executed at the memory side).
 __device__ __forceinline__ void fx_add(int64_t* p, float v) {
     const long long q = __float2ll_rn(v * (float)(1 << SEER_GN_FX_SHIFT));
+    __hip_atomic_fetch_add(reinterpret_cast<long long*>(p), q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void fx_add_ln(int64_t* p, float v) {
+    const long long q = __float2ll_rn(v * (float)(1 << SEER_LN_FX_SHIFT));
     __hip_atomic_fetch_add(reinterpret_cast<long long*>(p), q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // planes (sum, sum of squares) of the replica / batch element a partial adds to: colsum_fx[rep][b][2][N]

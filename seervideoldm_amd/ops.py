@@ -78,6 +78,32 @@ class ColSumsFx:
         return self.buf.sum(dim=0).permute(0, 2, 1).to(torch.float64) / float(1 << 20)
 
 
+class RowStats:
+    """Per-row (sum, sum of squares) a GEMM accumulated next to its output (seer_gemm_desc::rowstat): buf [M, 2] int64 at scale
+    2^24, out of an FxArena (zeroed) or a fresh zeroed tensor.  gemm(..., ln=(rowstats, wsum, eps)) normalises the rows inside
+    the consuming GEMM (folded LayerNorm)."""
+    __slots__ = ("buf",)
+
+    def __init__(self, buf: torch.Tensor):
+        self.buf = buf
+
+    def totals(self) -> torch.Tensor:
+        return self.buf.to(torch.float64) / float(1 << 24)
+
+
+def fold_layernorm(w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, bias: Optional[torch.Tensor] = None):
+    """LayerNorm(gamma, beta) followed by Linear(w [N, K], bias) as ONE GEMM over the un-normalised rows:
+    LN(x) W^T + b = rstd * (x W'^T - mean * wsum) + b',  W' = bf16(gamma (.) W),  wsum = row sums of W' AS ROUNDED (the mean
+    cancels exactly),  b' = W beta + b (fp32).  Returns (W' bf16 [N, K], wsum fp32 [N], b' fp32 [N])."""
+    wf = w.float()
+    wp = (wf * gamma.float()[None, :]).to(bf16).contiguous()
+    wsum = wp.float().sum(dim=1).contiguous()
+    bp = wf @ beta.float()
+    if bias is not None:
+        bp = bp + bias.float()
+    return wp, wsum, bp.contiguous()
+
+
 class FxArena:
     """Bump allocator over one int64 buffer for the ColSumsFx of a UNet evaluation: reset() once per evaluation zeroes what the
     previous evaluation of the same schedule used (one fill launch), take() hands out [batch, C, 2] slices.  Pass
@@ -94,6 +120,15 @@ class FxArena:
         self.used = 0
         self.high = 0
 
+    def take_rows(self, rows: int) -> Optional[torch.Tensor]:
+        n = rows * 2
+        if self.used + n > self.buf.numel():
+            return None
+        t = self.buf[self.used:self.used + n].view(rows, 2)
+        self.used += n
+        self.high = max(self.high, self.used)
+        return t
+
     def take(self, reps: int, batch: int, C_: int) -> Optional[torch.Tensor]:
         n = reps * batch * C_ * 2
         if self.used + n > self.buf.numel():
@@ -107,8 +142,11 @@ class FxArena:
 # ------------------------------------------------------------------------------------------------------------
 def gemm(a: torch.Tensor, w: torch.Tensor, *, bias=None, residual=None, rowvec=None, rows_per_batch=0,
          a2: Optional[torch.Tensor] = None, geglu=False, silu=False, out_f32=False, out: Optional[torch.Tensor] = None,
-         tile=0, splits=0, rotary=None, col_scale=None, colsum_batch=0) -> torch.Tensor:
+         tile=0, splits=0, rotary=None, col_scale=None, colsum_batch=0, rowstat=False, ln=None) -> Optional[torch.Tensor]:
     """out[M,N] = epi(a[M,K1] | a2[M,K-K1]) @ w[N,K]^T ; a/a2 may be row-strided views (last dim contiguous).
+    rowstat = True or an FxArena: out.rowstats = RowStats of the output rows (None when this launch cannot accumulate them).
+    ln = (RowStats of a, wsum, eps): a holds UN-normalised rows and w / bias are fold_layernorm()'s W' / b' -- the LayerNorm is
+    applied inside the epilogue.  Returns None (nothing launched) when this launch cannot fold: run layernorm() + the plain weights.
     colsum_batch = B > 0: the output feeds a GroupNorm over B batch elements -- out.colsums is set to the ColSums the launch
     left (or None when this launch cannot produce them; the caller then runs groupnorm_stats on the output).
     rotary = (cos_sin table, tokens_per_batch, pos_offset, head_dim, rot_dim, cols): rotate columns < cols in the epilogue.
@@ -160,8 +198,24 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias=None, residual=None, rowvec=N
     d.batch = 1
     d.tile = tile
     d.splits = splits
+    lib = _lib.load()
+    if ln is not None:
+        rs, wsum, eps = ln
+        _req(wsum, torch.float32, "ln wsum")
+        assert rs.buf.shape[0] == M and wsum.shape[0] == N and a2 is None
+        d.ln_rowstat, d.ln_wsum, d.ln_eps = _p(rs.buf), _p(wsum), float(eps)
+        if not lib.seer_gemm_lnfold_ok(C.byref(d)):
+            return None
+    rstats = None
+    if rowstat and lib.seer_gemm_rowstat_ok(C.byref(d)):
+        buf = rowstat.take_rows(M) if isinstance(rowstat, FxArena) else None      # rowstat = True or the evaluation's arena
+        if buf is None:
+            buf = torch.zeros((M, 2), device=a.device, dtype=torch.int64)
+        rstats = RowStats(buf)
+        d.rowstat = _p(buf)
     cs = _launch_gemm(d, a.device, "seer_gemm_bf16", colsum_batch)
     out.colsums = cs            # always assigned: a reused `out=` tensor must not keep the column sums of an earlier launch
+    out.rowstats = rstats       # likewise
     return out
 
 

@@ -215,6 +215,11 @@ class _Engine:
         self.gn_fx = bool(getattr(model, "gn_fx", os.environ.get("SEER_GN_FX", "1") != "0"))
         self._fx_arena = None
         self._fx = None
+        # LayerNorm folded into the consuming GEMM: the producers of the residual stream leave per-row (sum, sum of squares) next
+        # to it (ops.RowStats), the q|k|v / to_q / ff.net.0 GEMMs normalise in their epilogue -- no LayerNorm launch
+        # (model.ln_fold = False / SEER_LN_FOLD=0: the layernorm kernel everywhere)
+        self.ln_fold = bool(getattr(model, "ln_fold", os.environ.get("SEER_LN_FOLD", "1") != "0")) and hasattr(self.ops, "fold_layernorm")
+        self.ln_folded = 0
         self.gn_from_colsums = 0
         self.w: Dict[str, torch.Tensor] = {}
         self._pack(sd)
@@ -300,6 +305,24 @@ class _Engine:
                 p = k[: -len(".to_q.weight")]
                 w[p + ".q"] = b16(sd[p + ".to_q.weight"])
                 w[p + ".kv"] = b16(torch.cat([sd[p + ".to_k.weight"], sd[p + ".to_v.weight"]], 0))
+        # LayerNorm folded into the GEMM that consumes it (ops.fold_layernorm): W' = gamma (.) W from the fp32 weights, its row
+        # sums and beta W^T + b, next to the plain weights (a launch that cannot fold runs layernorm + the plain ones)
+        self.wln: Dict[str, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = {}
+        if self.ln_fold:
+            fold = self.ops.fold_layernorm
+            for k in sd:
+                if not k.endswith(".norm1.weight") or ".transformer_blocks." not in k:
+                    continue
+                tb = k[: -len(".norm1.weight")]
+                g = lambda n: (f32(sd[f"{tb}.{n}.weight"]), f32(sd[f"{tb}.{n}.bias"]))
+                qkv = torch.cat([sd[tb + ".attn1.to_q.weight"], sd[tb + ".attn1.to_k.weight"], sd[tb + ".attn1.to_v.weight"]], 0)
+                self.wln[tb + ".attn1.qkv"] = fold(f32(qkv), *g("norm1"))
+                if (tb + ".attn2.to_q.weight") in sd and (tb + ".norm2.weight") in sd:
+                    self.wln[tb + ".attn2.q"] = fold(f32(sd[tb + ".attn2.to_q.weight"]), *g("norm2"))
+                if (tb + ".norm3.weight") in sd:
+                    v = sd[tb + ".ff.net.0.proj.weight"]
+                    order = geglu_row_order(v.shape[0] // 2)
+                    self.wln[tb + ".ff.net.0.proj.weight"] = fold(f32(v[order]), *g("norm3"), f32(sd[tb + ".ff.net.0.proj.bias"][order]))
 
     # ---- building blocks --------------------------------------------------------------------------------------
     def _gn(self, x1, x2, B, rows_pb, name, eps, silu):
@@ -367,10 +390,27 @@ class _Engine:
             sc = x
         return ops.conv3x3(h, w[p + ".conv2.weight"], B * Fr, H, W, bias=w[p + ".conv2.bias"], residual=sc, colsum_batch=cb)
 
+    def _ln_gemm(self, h, tb, norm, wkey, bias_key=None, **kw):
+        """LayerNorm `tb + norm` followed by the projection `wkey`: one GEMM when the producer of h left its row statistics and the
+        launch can fold (ops.gemm(..., ln=)), else the layernorm kernel and the plain weights."""
+        ops, w = self.ops, self.w
+        rs = getattr(h, "rowstats", None)
+        f = self.wln.get(wkey) if rs is not None else None
+        if f is not None:
+            y = ops.gemm(h, f[0], bias=f[2], ln=(rs, f[1], 1e-5), **kw)
+            if y is not None:
+                self.ln_folded += 1
+                return y
+        n = ops.layernorm(h, w[tb + norm + ".weight"], w[tb + norm + ".bias"])
+        return ops.gemm(n, w[wkey], bias=(w[bias_key] if bias_key else None), **kw)
+
+    def _rs(self):
+        """extra arguments of a GEMM whose output rows feed a LayerNorm"""
+        return {"rowstat": self._fx_arena if self._fx_arena is not None else True} if self.ln_fold else {}
+
     def _ff(self, tb, h_rows):
         ops, w = self.ops, self.w
-        n3 = ops.layernorm(h_rows, w[tb + ".norm3.weight"], w[tb + ".norm3.bias"])
-        g = ops.gemm(n3, w[tb + ".ff.net.0.proj.weight"], bias=w[tb + ".ff.net.0.proj.bias"], geglu=True)
+        g = self._ln_gemm(h_rows, tb, ".norm3", tb + ".ff.net.0.proj.weight", tb + ".ff.net.0.proj.bias", geglu=True)
         ops.gemm(g, w[tb + ".ff.net.2.weight"], bias=w[tb + ".ff.net.2.bias"], residual=h_rows, out=h_rows)
 
     def _text_transformer(self, p, x, geo):
@@ -382,20 +422,18 @@ class _Engine:
         HW = H * W
         tb = p + ".transformer_blocks.0"
         hn = self._gn(x, None, B, Fr * HW, p + ".norm", 1e-6, False)
-        h = ops.gemm(hn, w[p + ".proj_in.weight"], bias=w[p + ".proj_in.bias"])
+        h = ops.gemm(hn, w[p + ".proj_in.weight"], bias=w[p + ".proj_in.bias"], **self._rs())
         # self attention per frame
-        n1 = ops.layernorm(h, w[tb + ".norm1.weight"], w[tb + ".norm1.bias"])
         # the q columns leave the projection as q * scale * log2(e) (one bf16 rounding): the attention kernels exponentiate
         # the raw dot products
         qs = ops.qk_prescale(d)
-        qkv = ops.gemm(n1, w[tb + ".attn1.qkv"], col_scale=(qs, C))
+        qkv = self._ln_gemm(h, tb, ".norm1", tb + ".attn1.qkv", col_scale=(qs, C))
         a = torch.empty_like(h)
         ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], a, batch=B * Fr, heads=heads, head_dim=d,
                       Sq=HW, Sk=HW, q_prescaled=True)
-        ops.gemm(a, w[tb + ".attn1.to_out.0.weight"], bias=w[tb + ".attn1.to_out.0.bias"], residual=h, out=h)
+        ops.gemm(a, w[tb + ".attn1.to_out.0.weight"], bias=w[tb + ".attn1.to_out.0.bias"], residual=h, out=h, **self._rs())
         # text cross attention per frame (K/V depend on the context only: cached across DDIM steps)
-        n2 = ops.layernorm(h, w[tb + ".norm2.weight"], w[tb + ".norm2.bias"])
-        q = ops.gemm(n2, w[tb + ".attn2.q"], col_scale=(qs, C))
+        q = self._ln_gemm(h, tb, ".norm2", tb + ".attn2.q", col_scale=(qs, C))
         kv = self._kv_cache.get(tb)
         if kv is None:
             kv = ops.gemm(self._ctx, w[tb + ".attn2.kv"])
@@ -404,7 +442,7 @@ class _Engine:
         if self._attn_list is not None and p in self._attn_wanted:
             self._attn_list.append(self._cross_scores(q, kv[:, :C], B, Fr, H, W, heads, d, L))
         ops.attention(q, kv[:, :C], kv[:, C:], a, batch=B * Fr, heads=heads, head_dim=d, Sq=HW, Sk=L, q_prescaled=True)
-        ops.gemm(a, w[tb + ".attn2.to_out.0.weight"], bias=w[tb + ".attn2.to_out.0.bias"], residual=h, out=h)
+        ops.gemm(a, w[tb + ".attn2.to_out.0.weight"], bias=w[tb + ".attn2.to_out.0.bias"], residual=h, out=h, **self._rs())
         self._ff(tb, h)
         return ops.gemm(h, w[p + ".proj_out.weight"], bias=w[p + ".proj_out.bias"], residual=x,
                         colsum_batch=self._cb(B))
@@ -445,15 +483,14 @@ class _Engine:
         HW = H * W
         tb = p + ".transformer_blocks.0"
         hn = self._gn(x, None, B, Fr * HW, p + ".norm", 1e-6, False)
-        h = ops.gemm(hn, w[p + ".proj_in.weight"], bias=w[p + ".proj_in.bias"])
-        n1 = ops.layernorm(h, w[tb + ".norm1.weight"], w[tb + ".norm1.bias"])
+        h = ops.gemm(hn, w[p + ".proj_in.weight"], bias=w[p + ".proj_in.bias"], **self._rs())
         F_all = Fr if self.shard is None else self.shard.total_frames
         f_off = 0 if self.shard is None else self.shard.frame_offset
         rot_dim = min(32, d)
         cs = self._rotary_table(tb, F_all * HW)
         # q|k|v projection with the rotary embedding applied to the q and k columns in the GEMM epilogue
-        qkv = ops.gemm(n1, w[tb + ".attn1.qkv"], rotary=(cs, Fr * HW, f_off * HW, d, rot_dim, 2 * C),
-                       col_scale=(ops.qk_prescale(d), C))
+        qkv = self._ln_gemm(h, tb, ".norm1", tb + ".attn1.qkv", rotary=(cs, Fr * HW, f_off * HW, d, rot_dim, 2 * C),
+                            col_scale=(ops.qk_prescale(d), C))
         a = torch.empty_like(h)
         if self.shard is not None:
             self.shard.temporal_attention(ops, qkv, a, B, heads, d, H, W, sync=self.sync_point)
@@ -465,7 +502,7 @@ class _Engine:
             else:
                 ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], a, batch=B, heads=heads, head_dim=d,
                               Sq=Fr * HW, Sk=Fr * HW, causal=True, q_prescaled=True)
-        ops.gemm(a, w[tb + ".attn1.to_out.0.weight"], bias=w[tb + ".attn1.to_out.0.bias"], residual=h, out=h)
+        ops.gemm(a, w[tb + ".attn1.to_out.0.weight"], bias=w[tb + ".attn1.to_out.0.bias"], residual=h, out=h, **self._rs())
         # FF skips the conditioning frames (attention.py:241-246); frames are the slow index inside a batch element
         skip_f = cond_frame if self.shard is None else self.shard.local_cond_frames(cond_frame)
         if skip_f <= 0:
@@ -494,15 +531,18 @@ class _Engine:
         self._stats_arena = torch.empty((self.n_groupnorms(), B, self.G, 2), device=sample.device, dtype=torch.float32)
         self._stats_i = 0
         self.gn_from_colsums = 0        # GroupNorms of this forward that took their statistics from column sums
+        self.ln_folded = 0              # LayerNorms of this forward that ran inside the consuming GEMM
         self._fx = None
-        if self.gn_fx and self.gn_colsums and self.shard is None and hasattr(ops, "FxArena"):
-            # every colsum producer of the evaluation takes a [B, C, 2] slot; reset() = one fill over what the last evaluation used
-            need = (self.n_groupnorms() + 16) * B * 4 * max(boc) * 2       # capacity; only what an evaluation takes is ever zeroed
+        fx_gn = self.gn_fx and self.gn_colsums and self.shard is None
+        if (fx_gn or self.ln_fold) and hasattr(ops, "FxArena"):
+            # fixed-point accumulators of the evaluation: a [reps, B, 2, C] slot per colsum producer, a [rows, 2] slot per producer
+            # of LayerNorm rows; reset() = one fill over what the last evaluation took
+            need = (self.n_groupnorms() + 16) * B * 4 * max(boc) * 2 + 5 * 16 * B * Fr * H * W * 2
             if self._fx_arena is None or self._fx_arena.buf.numel() < need:
-                assert not torch.cuda.is_current_stream_capturing(), "the column-sum arena must exist before a graph capture"
+                assert not torch.cuda.is_current_stream_capturing(), "the accumulator arena must exist before a graph capture"
                 self._fx_arena = ops.FxArena(sample.device, need)
             self._fx_arena.reset()
-            self._fx = self._fx_arena
+            self._fx = self._fx_arena if fx_gn else None
         emb = ops.timestep_embedding(t, boc[0], self.cfg.flip_sin_to_cos, self.cfg.freq_shift)
         emb = ops.linear_smallm(emb, w["time_embedding.linear_1.weight"], w["time_embedding.linear_1.bias"], silu_out=True)
         emb = ops.linear_smallm(emb, w["time_embedding.linear_2.weight"], w["time_embedding.linear_2.bias"])

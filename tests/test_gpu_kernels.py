@@ -1032,3 +1032,99 @@ def test_groupnorm_apply_fx(device, C1, C2, rows):
     s2 = torch.zeros_like(stats)
     ops.groupnorm_stats_from_fx(x1.colsums, x2.colsums if C2 else None, B, G, s2)
     assert (s2 - stats).abs().max().item() <= 1e-4 * stats.abs().max().item()
+
+
+@pytest.mark.parametrize("M,N,K,tile,res", [(1536, 320, 320, 0, True), (3072, 640, 640, 16, True), (768, 1280, 1280, 7, False),
+                                            (384, 1280, 1280, 0, True), (1536, 320, 1280, 8, True), (2048, 640, 2560, 5, True),
+                                            (1000, 320, 320, 0, True), (1536, 328, 320, 8, False)])
+def test_gemm_row_statistics(device, M, N, K, tile, res):
+    """seer_gemm_desc::rowstat: (sum, sum of squares) of every stored output row per tile column -- what the LayerNorm folded into
+    the consuming GEMM normalises with (attention.py:198-200, 275-277 run nn.LayerNorm on exactly these rows); ragged M and N."""
+    from seervideoldm_amd import ops
+    a = _rand((M, K), device, 1).to(bf16)
+    w = _rand((N, K), device, 2, K ** -0.5).to(bf16)
+    y = ops.gemm(a, w, bias=_rand((N,), device, 3), residual=_rand((M, N), device, 4).to(bf16) if res else None, tile=tile, rowstat=True)
+    rs = y.rowstats
+    assert rs is not None and rs.buf.shape == (M, 2)
+    got = rs.totals()
+    v = y.double()
+    ref = torch.stack([v.sum(dim=1), (v * v).sum(dim=1)], -1)
+    # the sums are taken from the fp32 values the epilogue rounds to bf16: 2^-9 relative per element, adding up like a random walk
+    tol = 2.0 ** -9 * (v * v).sum(dim=1).sqrt().max().item() * 4 + 2.0 ** -8 * ref[:, 1].max().item() / math.sqrt(N) * 4
+    assert (got - ref).abs().max().item() <= tol, ((got - ref).abs().max().item(), tol)
+    plain = ops.gemm(a, w, bias=_rand((N,), device, 3), residual=_rand((M, N), device, 4).to(bf16) if res else None, tile=tile)
+    assert torch.equal(plain, y), "the statistics are a side output: same bits in C"
+
+
+@pytest.mark.parametrize("C,M,kind,ptile,ctile", [
+    (320, 1536, "qkv", 0, 0), (320, 3072, "geglu", 16, 5), (640, 1536, "qkv", 8, 16), (640, 768, "geglu", 0, 0),
+    (1280, 768, "q", 7, 7), (1280, 384, "geglu", 0, 0), (320, 2048, "rotary", 0, 0), (1280, 384, "rotary", 0, 8),
+    (640, 1000, "qkv", 0, 0), (320, 24576, "qkv", 0, 0),
+])
+def test_layernorm_folded_into_gemm(device, C, M, kind, ptile, ctile):
+    """LayerNorm + Linear as ONE GEMM over the un-normalised rows (seer_gemm_desc::ln_rowstat; norm1 -> to_q|k|v, norm2 ->
+    attn2.to_q, norm3 -> ff.net.0 of attention.py:231-246, 308-327): against nn.LayerNorm + nn.Linear in fp32 on the stored bf16
+    rows, and against the two-launch form (layernorm kernel + plain weights); rows with a large common offset (mean >> std)."""
+    from seervideoldm_amd import ops
+    Hh = 8
+    d = C // Hh
+    a = _rand((M, C), device, 1).to(bf16)
+    wp = _rand((C, C), device, 2, C ** -0.5).to(bf16)
+    x = ops.gemm(a, wp, bias=_rand((C,), device, 3) * 2 + 1.5, residual=(_rand((M, C), device, 4) * 2).to(bf16), tile=ptile, rowstat=True)
+    assert x.rowstats is not None
+    gamma, beta = _rand((C,), device, 5) * 0.3 + 1.0, _rand((C,), device, 6) * 0.2
+    N = {"qkv": 3 * C, "q": C, "geglu": 8 * C, "rotary": 3 * C}[kind]
+    w = _rand((N, C), device, 7, C ** -0.5).to(bf16)
+    bias = _rand((N,), device, 8) if kind == "geglu" else None
+    kw = {}
+    if kind in ("qkv", "q"):
+        kw["col_scale"] = (0.7, C)
+    if kind == "geglu":
+        kw["geglu"] = True
+    if kind == "rotary":
+        T = M // 2
+        freqs = (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))).to(device)
+        cs = ops.rotary_table(freqs, T)
+        kw["rotary"] = (cs, T, 0, d, min(32, d), 2 * C)
+        kw["col_scale"] = (0.7, C)
+    wf, wsum, bf = ops.fold_layernorm(w, gamma, beta, bias)
+    got = ops.gemm(x, wf, bias=bf, ln=(x.rowstats, wsum, 1e-5), tile=ctile, **kw)
+    assert got is not None, "this launch was expected to fold the LayerNorm"
+    n = ops.layernorm(x, gamma, beta)
+    two = ops.gemm(n, w, bias=bias, tile=ctile, **kw)
+    # fp32 reference of the same stages
+    ln = Fn.layer_norm(x.float(), (C,), gamma, beta, 1e-5)
+    acc = ln @ w.float().t()
+    if bias is not None:
+        acc = acc + bias
+    if kind == "geglu":
+        # value / gate column pairs interleave in blocks of 16 inside the packed weight (weights.pack_geglu): compare against the
+        # two-launch form only (it reads the same packing)
+        ref = two.float()
+    else:
+        if kind == "rotary":
+            pos = torch.arange(M, device=device) % (M // 2)
+            c, s = cs[pos, :, 0], cs[pos, :, 1]
+            rd = min(32, d)
+            t = acc[:, :2 * C].reshape(M, 2 * Hh, d)
+            x0, x1 = t[..., :rd:2], t[..., 1:rd:2]
+            rot = torch.stack([x0 * c[:, None] - x1 * s[:, None], x1 * c[:, None] + x0 * s[:, None]], -1).flatten(-2)
+            acc = torch.cat([torch.cat([rot, t[..., rd:]], -1).reshape(M, 2 * C), acc[:, 2 * C:]], 1)
+        acc = torch.cat([acc[:, :C] * 0.7, acc[:, C:]], 1)
+        ref = acc
+    if kind == "geglu":
+        # value * gelu(gate) against ANOTHER bf16 result (not fp32): a gate off by one bf16 step moves a product with a large
+        # value by more than an element-wise tolerance allows; bound the error against the tensor's scale instead
+        e = (got.float() - ref)
+        assert torch.isfinite(got.float()).all()
+        assert e.pow(2).mean().sqrt().item() <= 1e-2 * ref.pow(2).mean().sqrt().item()
+        assert e.abs().max().item() <= 1e-2 * ref.abs().max().item()
+    else:
+        _close(got, ref, rtol=2e-2, atol=2e-2, what=f"folded LayerNorm {kind} C{C}")
+    # ... and no further from the fp32 reference than the two-launch form is (it rounds LN(x) to bf16; this one rounds gamma (.) W)
+    if kind != "geglu":
+        e_fold = (got.float() - ref).pow(2).mean().sqrt().item()
+        e_two = (two.float() - ref).pow(2).mean().sqrt().item()
+        assert e_fold <= 1.5 * e_two + 1e-4, (e_fold, e_two)
+    again = ops.gemm(x, wf, bias=bf, ln=(x.rowstats, wsum, 1e-5), tile=ctile, **kw)
+    assert torch.equal(got, again)
