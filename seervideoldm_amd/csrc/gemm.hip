@@ -1314,7 +1314,7 @@ __global__ void __launch_bounds__(256) seer_splitk_reduce_colsum_kernel(const se
 
 // the same pass for ACCUMULATED column sums (seer_gemm_desc::colsum_fx).  The atomics are the cost here (one per address every
 // ~12 ns, ~1.3 TB/s of them chip-wide): a block owns RB = RL * RPL rows x CB columns and adds ONE pair per column -- 16 x fewer
-// than one per 4-row strip (measured with 4 / 16-row strips: +10..15 us per conv, profiles/r04_gn_fx.log).  Thread -> (column
+// than one per 4-row strip (measured with 4 / 16-row strips: +10..15 us per conv, profiles/r04_gn_fx_producers.md).  Thread -> (column
 // quad, row lane); the row lanes of a column are added in order by the column's thread.
 template <int CB, int RL, int RPL>
 __global__ void __launch_bounds__(256) seer_splitk_reduce_fx_kernel(const seer_gemm_desc p) {
