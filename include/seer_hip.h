@@ -315,10 +315,11 @@ int seer_groupnorm_apply_from_colsums(const void* x1, int32_t C1, const void* x2
                                       const float* beta, int32_t silu, void* y, void* stream);
 /* GroupNorm apply whose statistics are the fixed-point column sums the producers ACCUMULATED (seer_gemm_desc::colsum_fx):
  * fx1 [reps1][batch][2][C1], fx2 [reps2][batch][2][C2] int64 (NULL with C2 = 0).  One launch per GroupNorm; every block converts the sums of
- * the groups it normalises (double precision) and streams its rows.  SEER_ENOSYS as above. */
+ * the groups it normalises (double precision) and streams its rows.  stats_out (or NULL): receives (sum, sum of squares) per
+ * (batch element, group) as fp32 [batch][groups][2], what seer_groupnorm_bwd takes.  SEER_ENOSYS as above. */
 int seer_groupnorm_apply_fx(const void* x1, int32_t C1, const void* x2, int32_t C2, const int64_t* fx1, int32_t reps1,
                             const int64_t* fx2, int32_t reps2, int32_t batch, int64_t rows_per_batch, int32_t groups, double count, float eps, const float* gamma,
-                            const float* beta, int32_t silu, void* y, void* stream);
+                            const float* beta, int32_t silu, void* y, float* stats_out, void* stream);
 /* the same two with the storage type of x1 / x2 / y chosen by `dtype` (SEER_DT_*): the VAE's nn.GroupNorm(32, eps 1e-6)
  * (ldm/modules/diffusionmodules/model.py:38-40) on fp16 activations */
 int seer_groupnorm_stats_dt(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t batch,

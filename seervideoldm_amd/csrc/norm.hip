@@ -241,7 +241,8 @@ template <bool FX>
 __global__ void __launch_bounds__(256) gn_apply_cs_kernel(const bf16* __restrict__ x1, const bf16* __restrict__ x2, GnColsumSrc s1,
                                                           GnColsumSrc s2, GnCsGeom g, int batch, int64_t rows_per_batch,
                                                           float inv_count, float eps, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, int silu, bf16* __restrict__ y) {
+                                                          const float* __restrict__ beta, int silu, bf16* __restrict__ y,
+                                                          float* __restrict__ stats_out) {
     __shared__ float part[12][128][2];                  // [tile lane][channel of the slice][sum, sumsq]
     __shared__ float mean_s[16], rstd_s[16];
     const int tid = threadIdx.x;
@@ -292,6 +293,13 @@ __global__ void __launch_bounds__(256) gn_apply_cs_kernel(const bf16* __restrict
                 var = var > 0.0 ? var : 0.0;
                 mean_s[gi] = (float)mean;
                 rstd_s[gi] = rsqrtf((float)var + eps);
+                // (sum, sumsq) per (batch element, group) for a backward pass (seer_groupnorm_bwd): the first row block writes them
+                if (stats_out && rb == 0) {
+                    const double u = 1.0 / (double)(1 << SEER_GN_FX_SHIFT);
+                    float* o = stats_out + ((int64_t)b * g.groups + slice * gs + gi) * 2;
+                    o[0] = (float)((double)sm * u);
+                    o[1] = (float)((double)sq * u);
+                }
             }
         }
     } else {
@@ -666,7 +674,7 @@ extern "C" int seer_groupnorm_apply_from_colsums(const void* x1, int32_t C1, con
     dim3 grid((unsigned)(g.nslice * g.nrowblk), batch);
     hipLaunchKernelGGL(gn_apply_cs_kernel<false>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        reinterpret_cast<const bf16*>(x1), reinterpret_cast<const bf16*>(x2), s1, s2, g, batch, rows_per_batch,
-                       (float)(1.0 / count), eps, gamma, beta, silu, reinterpret_cast<bf16*>(y));
+                       (float)(1.0 / count), eps, gamma, beta, silu, reinterpret_cast<bf16*>(y), (float*)nullptr);
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }
@@ -674,7 +682,7 @@ extern "C" int seer_groupnorm_apply_from_colsums(const void* x1, int32_t C1, con
 extern "C" int seer_groupnorm_apply_fx(const void* x1, int32_t C1, const void* x2, int32_t C2, const int64_t* fx1, int32_t reps1,
                                        const int64_t* fx2, int32_t reps2, int32_t batch, int64_t rows_per_batch, int32_t groups,
                                        double count, float eps, const float* gamma, const float* beta, int32_t silu, void* y,
-                                       void* stream) {
+                                       float* stats_out, void* stream) {
     if (!x1 || !fx1 || reps1 < 1 || !gamma || !beta || !y || batch <= 0 || rows_per_batch <= 0 || count <= 0) return SEER_EINVAL;
     if (!x2) C2 = 0;
     if (C2 > 0 && (!fx2 || reps2 < 1)) return SEER_EINVAL;
@@ -684,7 +692,7 @@ extern "C" int seer_groupnorm_apply_fx(const void* x1, int32_t C1, const void* x
     dim3 grid((unsigned)(g.nslice * g.nrowblk), batch);
     hipLaunchKernelGGL(gn_apply_cs_kernel<true>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        reinterpret_cast<const bf16*>(x1), reinterpret_cast<const bf16*>(x2), s1, s2, g, batch, rows_per_batch,
-                       (float)(1.0 / count), eps, gamma, beta, silu, reinterpret_cast<bf16*>(y));
+                       (float)(1.0 / count), eps, gamma, beta, silu, reinterpret_cast<bf16*>(y), stats_out);
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }

@@ -534,9 +534,10 @@ def groupnorm_apply_from_colsums(x1: torch.Tensor, x2: Optional[torch.Tensor], c
 
 def groupnorm_apply_fx(x1: torch.Tensor, x2: Optional[torch.Tensor], fx1: ColSumsFx, fx2: Optional[ColSumsFx], batch: int,
                        groups: int, count: float, eps: float, gamma: torch.Tensor, beta: torch.Tensor, silu: bool,
-                       out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+                       out: Optional[torch.Tensor] = None, stats_out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """GroupNorm (+ SiLU) from the producers' accumulated fixed-point column sums: ONE launch, no statistics pass.  Returns None
-    when the channel layout does not slice into whole groups (SEER_ENOSYS)."""
+    when the channel layout does not slice into whole groups (SEER_ENOSYS).  stats_out [batch, groups, 2] fp32: also receives
+    (sum, sum of squares) per (batch element, group) for the backward pass."""
     _req(x1, bf16, "x1")
     rows = x1.shape[0] // batch
     C2 = 0 if x2 is None else x2.shape[1]
@@ -544,9 +545,13 @@ def groupnorm_apply_fx(x1: torch.Tensor, x2: Optional[torch.Tensor], fx1: ColSum
     if out is None:
         out = torch.empty((x1.shape[0], x1.shape[1] + C2), device=x1.device, dtype=bf16)
     _req(gamma, torch.float32, "gamma"); _req(beta, torch.float32, "beta")
+    if stats_out is not None:
+        _req(stats_out, torch.float32, "stats_out")
+        assert stats_out.shape == (batch, groups, 2) and stats_out.is_contiguous()
     rc = _lib.load().seer_groupnorm_apply_fx(_p(x1), x1.shape[1], _p(x2), C2, _p(fx1.buf), fx1.reps,
-                                             _p(fx2.buf) if x2 is not None else None, fx2.reps if x2 is not None else 0, batch, rows, groups, float(count), float(eps), _p(gamma), _p(beta), int(silu),
-                                             _p(out), _stream())
+                                             _p(fx2.buf) if x2 is not None else None, fx2.reps if x2 is not None else 0, batch, rows,
+                                             groups, float(count), float(eps), _p(gamma), _p(beta), int(silu), _p(out),
+                                             _p(stats_out), _stream())
     if rc == _lib.SEER_ENOSYS:
         return None
     check(rc, "seer_groupnorm_apply_fx")

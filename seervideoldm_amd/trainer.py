@@ -20,6 +20,7 @@ file's wiring on CPU against autograd of the oracle).
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -208,6 +209,10 @@ class SeerTrainer:
         WT = P.wT[wkey] if P is not None else self._frozenT(wkey)
         return ops.gemm(dy, WT, residual=dres, out=out)
 
+    def _cb(self, B):
+        """`colsum_batch` of a launch whose output feeds a GroupNorm: accumulate into the step's arena when there is one"""
+        return (B, self._fx) if getattr(self, "_fx", None) is not None else B
+
     def _gn_fwd(self, x1, x2, B, rows_pb, name, eps, silu):
         ops, w = self.ops, self.w
         stats = torch.empty((B, self.eng.G, 2), device=x1.device, dtype=f32)
@@ -215,12 +220,22 @@ class SeerTrainer:
         # every source has them -- no statistics pass over the activations
         cs1 = getattr(x1, "colsums", None)
         cs2 = getattr(x2, "colsums", None) if x2 is not None else None
-        if cs1 is not None and (x2 is None or cs2 is not None):
+        C = x1.shape[1] + (0 if x2 is None else x2.shape[1])
+        count = rows_pb * (C // self.eng.G)
+        FX = getattr(ops, "ColSumsFx", ())
+        if isinstance(cs1, FX) and (x2 is None or isinstance(cs2, FX)):
+            # accumulated fixed-point sums (unet._Engine._gn): one launch normalises and leaves the statistics for the backward
+            y = ops.groupnorm_apply_fx(x1, x2, cs1, cs2, B, self.eng.G, count, eps, w[name + ".weight"], w[name + ".bias"], silu,
+                                       stats_out=stats)
+            if y is not None:
+                return y, (x1, x2, B, stats, count, name, eps, silu)
+            ops.groupnorm_stats_from_fx(cs1, cs2, B, self.eng.G, stats)
+        elif isinstance(cs1, FX) or isinstance(cs2, FX):
+            ops.groupnorm_stats(x1, x2, B, self.eng.G, stats)
+        elif cs1 is not None and (x2 is None or cs2 is not None):
             ops.groupnorm_stats_from_colsums(cs1, cs2, B, self.eng.G, stats)
         else:
             ops.groupnorm_stats(x1, x2, B, self.eng.G, stats)
-        C = x1.shape[1] + (0 if x2 is None else x2.shape[1])
-        count = rows_pb * (C // self.eng.G)
         y = ops.groupnorm_apply(x1, x2, B, self.eng.G, stats, count, eps, w[name + ".weight"], w[name + ".bias"], silu)
         return y, (x1, x2, B, stats, count, name, eps, silu)
 
@@ -241,11 +256,11 @@ class SeerTrainer:
         temb = self._temb[:, off:off + n]
         h1, s1 = self._gn_fwd(x, skip, B, rows_pb, p + ".norm1", self.eng.eps, True)
         h2 = ops.conv3x3(h1, w[p + ".conv1.weight"], B * Fr, H, W, bias=w[p + ".conv1.bias"], rowvec=temb, rows_per_batch=rows_pb,
-                         colsum_batch=B)
+                         colsum_batch=self._cb(B))
         h3, s2 = self._gn_fwd(h2, None, B, rows_pb, p + ".norm2", self.eng.eps, True)
         has_sc = (p + ".conv_shortcut.weight") in w
         sc = ops.gemm(x, w[p + ".conv_shortcut.weight"], a2=skip, bias=w[p + ".conv_shortcut.bias"]) if has_sc else x
-        out = ops.conv3x3(h3, w[p + ".conv2.weight"], B * Fr, H, W, bias=w[p + ".conv2.bias"], residual=sc, colsum_batch=B)
+        out = ops.conv3x3(h3, w[p + ".conv2.weight"], B * Fr, H, W, bias=w[p + ".conv2.bias"], residual=sc, colsum_batch=self._cb(B))
         return out, (p, geo, s1, s2, has_sc, x.shape[1])
 
     def _resnet_bwd(self, saved, dout):
@@ -317,7 +332,7 @@ class SeerTrainer:
         ops.attention(q2, kv[:, :C], kv[:, C:], a2, lse=lse2, **kw2)
         h2 = ops.gemm(a2, w[tb + ".attn2.to_out.0.weight"], bias=w[tb + ".attn2.to_out.0.bias"], residual=h1)
         h3, sff = self._ff_fwd(None, w, self._unet_ff_names(tb), h2)
-        out = ops.gemm(h3, w[p + ".proj_out.weight"], bias=w[p + ".proj_out.bias"], residual=x, colsum_batch=B)
+        out = ops.gemm(h3, w[p + ".proj_out.weight"], bias=w[p + ".proj_out.bias"], residual=x, colsum_batch=self._cb(B))
         return out, (p, C, sg, h0, qkv, a1, lse1, kw1, h1, q2, kv, a2, lse2, kw2, sff)
 
     def _text_bwd(self, saved, dout, stop_after_kv=False):
@@ -397,7 +412,7 @@ class SeerTrainer:
                 self._scatter(h2, hf2, sl)
             else:
                 h2 = hf2
-        out = ops.gemm(h2, w[p + ".proj_out.weight"], bias=w[p + ".proj_out.bias"], residual=x, colsum_batch=B)
+        out = ops.gemm(h2, w[p + ".proj_out.weight"], bias=w[p + ".proj_out.bias"], residual=x, colsum_batch=self._cb(B))
         return out, (p, C, d, rot_dim, cs, Fr * HW, sg, hn, h0, n1, qkv, a1, lse, kw, sl, cond_frame, sff, h2)
 
     def _temporal_bwd(self, saved, dout):
@@ -458,6 +473,14 @@ class SeerTrainer:
         emb = ops.linear_smallm(emb, w["time_embedding.linear_2.weight"], w["time_embedding.linear_2.bias"])
         self._temb = ops.linear_smallm(emb, w["temb_all.w"], w["temb_all.b"], silu_in=True)
         tape: List[Tuple] = []
+        self._fx = None
+        if getattr(self, "gn_fx", os.environ.get("SEER_GN_FX", "1") != "0") and hasattr(ops, "FxArena"):
+            need = (eng.n_groupnorms() + 16) * B * 4 * max(boc) * 2
+            if getattr(self, "_fx_arena", None) is None or self._fx_arena.buf.numel() < need:
+                assert not torch.cuda.is_current_stream_capturing(), "the accumulator arena must exist before a graph capture"
+                self._fx_arena = ops.FxArena(sample.device, need)
+            self._fx_arena.reset()
+            self._fx = self._fx_arena
         x = ops.conv_in(sample, w["conv_in.weight"], w["conv_in.bias"])
         skips = [x]
         geo = (B, Fr, H, W)
@@ -471,7 +494,7 @@ class SeerTrainer:
                 skips.append(x); tape.append(("push", None))
             if i < n - 1:
                 x = ops.conv3x3(x, w[f"{p}.downsamplers.0.conv.weight"], B * Fr, geo[2], geo[3], stride=2,
-                                bias=w[f"{p}.downsamplers.0.conv.bias"], colsum_batch=B)
+                                bias=w[f"{p}.downsamplers.0.conv.bias"], colsum_batch=self._cb(B))
                 tape.append(("down", (f"{p}.downsamplers.0.conv.weight", geo)))
                 geo = (B, Fr, (geo[2] - 1) // 2 + 1, (geo[3] - 1) // 2 + 1)
                 skips.append(x); tape.append(("push", None))
@@ -488,7 +511,7 @@ class SeerTrainer:
                     x, s = self._temporal_fwd(f"{p}.temporal_attentions.{j}", x, geo, cond_frame); tape.append(("temporal", s))
             if i < n - 1:
                 x = ops.conv3x3(x, w[f"{p}.upsamplers.0.conv.weight"], B * Fr, geo[2], geo[3], upsample=True,
-                                bias=w[f"{p}.upsamplers.0.conv.bias"], colsum_batch=B)
+                                bias=w[f"{p}.upsamplers.0.conv.bias"], colsum_batch=self._cb(B))
                 tape.append(("up", (f"{p}.upsamplers.0.conv.weight", geo)))
                 geo = (B, Fr, geo[2] * 2, geo[3] * 2)
         x, s = self._gn_fwd(x, None, B, Fr * geo[2] * geo[3], "conv_norm_out", eng.eps, True); tape.append(("gn_out", s))

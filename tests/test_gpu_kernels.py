@@ -1020,7 +1020,8 @@ def test_groupnorm_apply_fx(device, C1, C2, rows):
     C = C1 + C2
     gamma, beta = _rand((C,), device, 21) + 1.0, _rand((C,), device, 22)
     count = rows * (C // G)
-    got = ops.groupnorm_apply_fx(x1, x2, x1.colsums, x2.colsums if C2 else None, B, G, count, 1e-5, gamma, beta, True)
+    st_out = torch.zeros((B, G, 2), device=device, dtype=torch.float32)
+    got = ops.groupnorm_apply_fx(x1, x2, x1.colsums, x2.colsums if C2 else None, B, G, count, 1e-5, gamma, beta, True, stats_out=st_out)
     assert got is not None
     xc = x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], 1)
     ref = Fn.silu(Fn.group_norm(xc.reshape(B, rows, C).permute(0, 2, 1), G, gamma, beta, 1e-5)).permute(0, 2, 1).reshape(M, C)
@@ -1032,6 +1033,7 @@ def test_groupnorm_apply_fx(device, C1, C2, rows):
     s2 = torch.zeros_like(stats)
     ops.groupnorm_stats_from_fx(x1.colsums, x2.colsums if C2 else None, B, G, s2)
     assert (s2 - stats).abs().max().item() <= 1e-4 * stats.abs().max().item()
+    assert (st_out - stats).abs().max().item() <= 1e-4 * stats.abs().max().item(), "the statistics the backward pass takes"
 
 
 @pytest.mark.parametrize("M,N,K,tile,res", [(1536, 320, 320, 0, True), (3072, 640, 640, 16, True), (768, 1280, 1280, 7, False),
