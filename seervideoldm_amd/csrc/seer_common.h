@@ -175,7 +175,11 @@ __device__ __forceinline__ void fx_add(int64_t* p, float v) {
 }
 __device__ __forceinline__ void fx_add_ln(int64_t* p, float v) {
     const long long q = __float2ll_rn(v * (float)(1 << SEER_LN_FX_SHIFT));
+#ifdef SEER_RS_PROBE_STORE      // measurement build: a plain store in place of the atomic (wrong sums) -- what the atomic itself costs
+    *reinterpret_cast<long long*>(p) = q;
+#else
     __hip_atomic_fetch_add(reinterpret_cast<long long*>(p), q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 }
 // planes (sum, sum of squares) of the replica / batch element a partial adds to: colsum_fx[rep][b][2][N]
 __device__ __forceinline__ int64_t* fx_slot(const seer_gemm_desc& p, int partial_index, int first_row) {

@@ -189,6 +189,9 @@ class SeerUNet(nn.Module):
 
 
 # =====================================================================================================================
+FX_MAX_ROWS = 100_000        # rows at the finest level up to which the accumulated-statistics forms are used (see _Engine._forward)
+
+
 class _Engine:
     """packed weights + the kernel schedule of one SeerUNet forward."""
 
@@ -220,6 +223,7 @@ class _Engine:
         # (model.ln_fold = False / SEER_LN_FOLD=0: the layernorm kernel everywhere)
         self.ln_fold = bool(getattr(model, "ln_fold", os.environ.get("SEER_LN_FOLD", "1") != "0")) and hasattr(self.ops, "fold_layernorm")
         self.ln_folded = 0
+        self._ln_on = False
         self.gn_from_colsums = 0
         self.w: Dict[str, torch.Tensor] = {}
         self._pack(sd)
@@ -406,7 +410,7 @@ class _Engine:
 
     def _rs(self):
         """extra arguments of a GEMM whose output rows feed a LayerNorm"""
-        return {"rowstat": self._fx_arena if self._fx_arena is not None else True} if self.ln_fold else {}
+        return {"rowstat": self._fx_arena if self._fx_arena is not None else True} if self._ln_on else {}
 
     def _ff(self, tb, h_rows):
         ops, w = self.ops, self.w
@@ -533,8 +537,13 @@ class _Engine:
         self.gn_from_colsums = 0        # GroupNorms of this forward that took their statistics from column sums
         self.ln_folded = 0              # LayerNorms of this forward that ran inside the consuming GEMM
         self._fx = None
-        fx_gn = self.gn_fx and self.gn_colsums and self.shard is None
-        if (fx_gn or self.ln_fold) and hasattr(ops, "FxArena"):
+        # both forms trade a fixed cost per norm (a launch) for atomics in proportion to the rows: ahead up to ~100 k rows at the
+        # finest level (config 2: 24 576 rows -0.35 ms; 64x64 latent, 98 304 rows: -0.1 ms; bridge, 131 072 rows: +0.4 ms --
+        # profiles/r04_fx_ln_other_configs.log), off above
+        small = B * Fr * H * W <= FX_MAX_ROWS
+        fx_gn = self.gn_fx and self.gn_colsums and self.shard is None and small
+        self._ln_on = self.ln_fold and small
+        if (fx_gn or self._ln_on) and hasattr(ops, "FxArena"):
             # fixed-point accumulators of the evaluation: a [reps, B, 2, C] slot per colsum producer, a [rows, 2] slot per producer
             # of LayerNorm rows; reset() = one fill over what the last evaluation took
             need = (self.n_groupnorms() + 16) * B * 4 * max(boc) * 2 + 5 * 16 * B * Fr * H * W * 2
