@@ -334,22 +334,17 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
         }
     }
 
-    // folded LayerNorm (seer_gemm_desc::ln_rowstat): thread t < BM reads the accumulated (sum, sum of squares) of tile row t and
-    // keeps (mean * rstd, rstd) through the K loop; the epilogue hands them to the lanes that own the row through LDS
+    // folded LayerNorm (seer_gemm_desc::ln_rowstat): thread t < BM REQUESTS the accumulated (sum, sum of squares) of tile row t here
+    // and keeps the raw pair through the K loop; the epilogue converts it and hands (mean * rstd, rstd) to the lanes that own the
+    // row through LDS.  (Converting here put a wait for the load -- an L2 round trip -- in front of the first LDS-DMA of every
+    // tile: +3 us on the GEGLU projections with their 7.5 tiles per CU, profiles/r04_ln_fold_overheads.md.)
     constexpr bool LN_OK = !SPLIT && !F16 && tile_ln_ok<BM, BN, NS, WM, WN>();
-    float ln_mr = 0.f, ln_r = 1.f;
+    typedef __attribute__((ext_vector_type(2))) long long i64x2;
+    i64x2 ln_raw = {0, 0};
     if constexpr (LN_OK) {
         if (p.ln_rowstat && tid < BM) {
             const int m = min(m0 + tid, p.M - 1);
-            const long long* q = reinterpret_cast<const long long*>(p.ln_rowstat) + (int64_t)m * 2;
-            const float sm = (float)((double)q[0] * (1.0 / (double)(1 << SEER_LN_FX_SHIFT)));
-            const float sq = (float)((double)q[1] * (1.0 / (double)(1 << SEER_LN_FX_SHIFT)));
-            const float inv = 1.0f / (float)p.K;
-            const float mean = sm * inv;
-            float var = sq * inv - mean * mean;
-            var = var > 0.f ? var : 0.f;
-            ln_r = rsqrtf(var + p.ln_eps);
-            ln_mr = mean * ln_r;
+            ln_raw = *reinterpret_cast<const i64x2*>(reinterpret_cast<const long long*>(p.ln_rowstat) + (int64_t)m * 2);
         }
     }
     // ... and the lane's wsum quads, requested before the K loop like the bias (a dependent L2 round trip at the head of the
@@ -849,7 +844,16 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
         do_ln = p.ln_rowstat != nullptr && staged;
         if (do_ln) {
             float* lnrow = reinterpret_cast<float*>(smem + LNROW_OFF);
-            if (tid < BM) *reinterpret_cast<f32x2*>(lnrow + tid * 2) = f32x2{ln_mr, ln_r};
+            if (tid < BM) {
+                const float sm = (float)((double)ln_raw[0] * (1.0 / (double)(1 << SEER_LN_FX_SHIFT)));
+                const float sq = (float)((double)ln_raw[1] * (1.0 / (double)(1 << SEER_LN_FX_SHIFT)));
+                const float inv = 1.0f / (float)p.K;
+                const float mean = sm * inv;
+                float var = sq * inv - mean * mean;
+                var = var > 0.f ? var : 0.f;
+                const float r = rsqrtf(var + p.ln_eps);
+                *reinterpret_cast<f32x2*>(lnrow + tid * 2) = f32x2{mean * r, r};
+            }
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
