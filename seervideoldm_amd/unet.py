@@ -189,7 +189,8 @@ class SeerUNet(nn.Module):
 
 
 # =====================================================================================================================
-FX_MAX_ROWS = 100_000        # rows at the finest level up to which the accumulated-statistics forms are used (see _Engine._forward)
+FX_MAX_ROWS = 100_000        # rows at the finest level up to which the LayerNorms are folded (see _Engine._forward)
+FX_MAX_ROWS_PB = int(os.environ.get("SEER_FX_MAX_ROWS_PB", "4096"))        # rows per batch element up to which a GroupNorm's statistics are accumulated in fixed point (_Engine._cb)
 
 
 class _Engine:
@@ -369,11 +370,15 @@ class _Engine:
         return ops.groupnorm_apply(x1, x2, B, self.G, stats, count, eps, self.w[name + ".weight"],
                                    self.w[name + ".bias"], silu)
 
-    def _cb(self, B):
-        """`colsum_batch` of a launch whose output feeds a GroupNorm: (B, arena) = accumulate in fixed point, B = per-tile sums."""
+    def _cb(self, B, rows_pb):
+        """`colsum_batch` of a launch whose output (rows_pb rows per batch element) feeds a GroupNorm: (B, arena) = accumulate in
+        fixed point, B = per-tile sums.  The accumulated form wins where the tensor is small (its apply launch owns slices of
+        64..128 channels: 160-byte pieces of a 640-byte row at the 32x32 level, ~20 % below the full-row kernel's bandwidth, and
+        eight replicas to add per block): from the 16x16 level down 7.5 / 9.6 / 5.7 / 3.8 us against 8.4 / 12.1 / 7.6 / 5.7 for
+        finalize + apply, at the 32x32 level 12.6 / 27.9 against 11.3 / 25.6 (profiles/r04_gn_fx_by_level.log)."""
         if not self.gn_colsums:
             return 0
-        return (B, self._fx) if self._fx is not None else B
+        return (B, self._fx) if (self._fx is not None and rows_pb <= FX_MAX_ROWS_PB) else B
 
     def _resnet(self, p, x, skip, geo):
         """ResnetBlock3D (resnet.py:174-208); `skip` is the channel-concat partner of unet_3d_blocks.py:596,712."""
@@ -382,7 +387,7 @@ class _Engine:
         rows_pb = Fr * H * W
         off, n = self.temb_slices[p]
         temb = self._temb[:, off:off + n]
-        cb = self._cb(B)                   # outputs that feed a GroupNorm leave their column sums behind
+        cb = self._cb(B, rows_pb)          # outputs that feed a GroupNorm leave their column sums behind
         h = self._gn(x, skip, B, rows_pb, p + ".norm1", self.eps, True)
         h = ops.conv3x3(h, w[p + ".conv1.weight"], B * Fr, H, W, bias=w[p + ".conv1.bias"], rowvec=temb,
                         rows_per_batch=rows_pb, colsum_batch=cb)
@@ -449,7 +454,7 @@ class _Engine:
         ops.gemm(a, w[tb + ".attn2.to_out.0.weight"], bias=w[tb + ".attn2.to_out.0.bias"], residual=h, out=h, **self._rs())
         self._ff(tb, h)
         return ops.gemm(h, w[p + ".proj_out.weight"], bias=w[p + ".proj_out.bias"], residual=x,
-                        colsum_batch=self._cb(B))
+                        colsum_batch=self._cb(B, Fr * HW))
 
     def _cross_scores(self, q, k, B, Fr, H, W, heads, d, L):
         """`attention_scores` of the text cross attention (attention.py:556-584: scale * Q K^T before the softmax) as
@@ -515,7 +520,7 @@ class _Engine:
             for b in range(B):
                 self._ff(tb, h[b * Fr * HW + skip_f * HW:(b + 1) * Fr * HW])
         return ops.gemm(h, w[p + ".proj_out.weight"], bias=w[p + ".proj_out.bias"], residual=x,
-                        colsum_batch=self._cb(B))
+                        colsum_batch=self._cb(B, Fr * HW))
 
     # ---- the schedule ---------------------------------------------------------------------------------------------
     def n_groupnorms(self):
@@ -537,11 +542,11 @@ class _Engine:
         self.gn_from_colsums = 0        # GroupNorms of this forward that took their statistics from column sums
         self.ln_folded = 0              # LayerNorms of this forward that ran inside the consuming GEMM
         self._fx = None
-        # both forms trade a fixed cost per norm (a launch) for atomics in proportion to the rows: ahead up to ~100 k rows at the
-        # finest level (config 2: 24 576 rows -0.35 ms; 64x64 latent, 98 304 rows: -0.1 ms; bridge, 131 072 rows: +0.4 ms --
+        # the folded LayerNorm trades a launch per norm for atomics in proportion to the rows: ahead up to ~100 k rows at the finest
+        # level (config 2: 24 576 rows -0.19 ms; 64x64 latent, 98 304 rows: even; bridge, 131 072 rows: +0.15 ms --
         # profiles/r04_fx_ln_other_configs.log), off above
         small = B * Fr * H * W <= FX_MAX_ROWS
-        fx_gn = self.gn_fx and self.gn_colsums and self.shard is None and small
+        fx_gn = self.gn_fx and self.gn_colsums and self.shard is None      # (per tensor: _cb)
         self._ln_on = self.ln_fold and small
         if (fx_gn or self._ln_on) and hasattr(ops, "FxArena"):
             # fixed-point accumulators of the evaluation: a [reps, B, 2, C] slot per colsum producer, a [rows, 2] slot per producer
@@ -570,7 +575,8 @@ class _Engine:
                 skips.append(x)
             if i < n - 1:
                 x = ops.conv3x3(x, w[f"{p}.downsamplers.0.conv.weight"], B * Fr, geo[2], geo[3], stride=2,
-                                bias=w[f"{p}.downsamplers.0.conv.bias"], colsum_batch=self._cb(B))
+                                bias=w[f"{p}.downsamplers.0.conv.bias"],
+                                colsum_batch=self._cb(B, Fr * ((geo[2] - 1) // 2 + 1) * ((geo[3] - 1) // 2 + 1)))
                 geo = (B, Fr, (geo[2] - 1) // 2 + 1, (geo[3] - 1) // 2 + 1)
                 skips.append(x)
         x = self._resnet("mid_block.resnets.0", x, None, geo)
@@ -586,7 +592,7 @@ class _Engine:
                     x = self._temporal_transformer(f"{p}.temporal_attentions.{j}", x, geo, cond_frame)
             if i < n - 1:
                 x = ops.conv_up2x(x, w[f"{p}.upsamplers.0.conv.weight_up4"], B * Fr, geo[2], geo[3],
-                                  bias=w[f"{p}.upsamplers.0.conv.bias"], colsum_batch=self._cb(B))
+                                  bias=w[f"{p}.upsamplers.0.conv.bias"], colsum_batch=self._cb(B, Fr * 4 * geo[2] * geo[3]))
                 geo = (B, Fr, geo[2] * 2, geo[3] * 2)
         x = self._gn(x, None, B, Fr * geo[2] * geo[3], "conv_norm_out", self.eps, True)
         out = ops.conv_out(x, w["conv_out.weight"], w["conv_out.bias"], B, Fr, geo[2], geo[3])
