@@ -131,7 +131,7 @@ class SeerTrainer:
         self.lr, self.betas, self.weight_decay, self.eps, self.max_grad_norm = lr, betas, weight_decay, eps, max_grad_norm
         self.pg = process_group
         self.unet, self.fstext = unet, fstext
-        self.eng = _Engine(unet, ops=ops)
+        self.eng = _Engine(unet, ops=ops, fold_ln=False)
         self.device = self.eng.device
         self.step_count = 0
         sd_u = {k: v for k, v in unet.state_dict().items()}
@@ -478,6 +478,8 @@ class SeerTrainer:
             need = (eng.n_groupnorms() + 16) * B * 4 * max(boc) * 2
             if getattr(self, "_fx_arena", None) is None or self._fx_arena.buf.numel() < need:
                 assert not torch.cuda.is_current_stream_capturing(), "the accumulator arena must exist before a graph capture"
+                if getattr(self, "_fx_arena", None) is not None:
+                    self._fx_retired = getattr(self, "_fx_retired", []) + [self._fx_arena]     # captured steps keep theirs by address
                 self._fx_arena = ops.FxArena(sample.device, need)
             self._fx_arena.reset()
             self._fx = self._fx_arena

@@ -196,7 +196,7 @@ FX_MAX_ROWS_PB = int(os.environ.get("SEER_FX_MAX_ROWS_PB", "4096"))        # row
 class _Engine:
     """packed weights + the kernel schedule of one SeerUNet forward."""
 
-    def __init__(self, model: SeerUNet, ops=hip_ops, shard=None):
+    def __init__(self, model: SeerUNet, ops=hip_ops, shard=None, fold_ln=True):
         self.ops = ops
         self.cfg = model.config
         self.shard = shard              # parallel.FrameShard or None
@@ -218,11 +218,13 @@ class _Engine:
         # apply launch reads them directly -- no finalize launch either (model.gn_fx = False / SEER_GN_FX=0: the forms above)
         self.gn_fx = bool(getattr(model, "gn_fx", os.environ.get("SEER_GN_FX", "1") != "0"))
         self._fx_arena = None
+        self._fx_retired: List[object] = []
         self._fx = None
         # LayerNorm folded into the consuming GEMM: the producers of the residual stream leave per-row (sum, sum of squares) next
         # to it (ops.RowStats), the q|k|v / to_q / ff.net.0 GEMMs normalise in their epilogue -- no LayerNorm launch
         # (model.ln_fold = False / SEER_LN_FOLD=0: the layernorm kernel everywhere)
-        self.ln_fold = bool(getattr(model, "ln_fold", os.environ.get("SEER_LN_FOLD", "1") != "0")) and hasattr(self.ops, "fold_layernorm")
+        self.ln_fold = bool(fold_ln) and bool(getattr(model, "ln_fold", os.environ.get("SEER_LN_FOLD", "1") != "0")) and \
+            hasattr(self.ops, "fold_layernorm")       # (fold_ln=False: the trainer's engine -- its weights move, it runs its own forward)
         self.ln_folded = 0
         self._ln_on = False
         self.gn_from_colsums = 0
@@ -554,6 +556,8 @@ class _Engine:
             need = (self.n_groupnorms() + 16) * B * 4 * max(boc) * 2 + 5 * 16 * B * Fr * H * W * 2
             if self._fx_arena is None or self._fx_arena.buf.numel() < need:
                 assert not torch.cuda.is_current_stream_capturing(), "the accumulator arena must exist before a graph capture"
+                if self._fx_arena is not None:
+                    self._fx_retired.append(self._fx_arena)     # captured steps of smaller shapes keep adding into theirs by address
                 self._fx_arena = ops.FxArena(sample.device, need)
             self._fx_arena.reset()
             self._fx = self._fx_arena if fx_gn else None
