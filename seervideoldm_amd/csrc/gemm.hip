@@ -67,9 +67,6 @@ constexpr int BK = 64;
 #endif
 // measurement-only builds (scripts/probe_gemm.sh; results are WRONG): bit 0 = no global->LDS refills inside the K loop,
 // bit 1 = no LDS fragment reads, bit 2 = no MFMAs.  The shipped library is built with 0.
-#ifndef SEER_RS_PROBE
-#define SEER_RS_PROBE 0
-#endif
 #ifndef SEER_GEMM_PROBE
 #define SEER_GEMM_PROBE 0
 #endif
@@ -1138,18 +1135,12 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 float sm = rsum[i], sq = rsq[i];
-#if SEER_RS_PROBE != 2
                 sm += __shfl_xor(sm, 16); sq += __shfl_xor(sq, 16);
                 sm += __shfl_xor(sm, 32); sq += __shfl_xor(sq, 32);
-#endif
                 // ONE instruction for both: lanes fq = 0 add the sums, lanes fq = 1 the squares of the same 16 rows -- 256 contiguous
                 // bytes = four fully used 64-byte atomic requests (the requests are the cost: ~12 ns each per CU)
                 const int m = m0 + wm * WTM + i * 16 + frow;
-#if SEER_RS_PROBE == 1        // measurement builds: no atomic (keep the sums alive) / no lane exchange
-                if (fq < 2 && m < p.M) asm volatile("" ::"v"(fq ? sq : sm));
-#else
                 if (fq < 2 && m < p.M) fx_add_ln(p.rowstat + (int64_t)m * 2 + fq, fq ? sq : sm);
-#endif
             }
         }
     }
