@@ -40,6 +40,53 @@ def test_engine_schedule_matches_oracle(mini, B, Fr, H, cond_frame):
     assert rel < 3e-2, rel
 
 
+def test_engine_folds_layernorms_into_the_consuming_gemm(mini):
+    """host logic of the folded LayerNorm (ops.fold_layernorm: W' = gamma (.) W, its row sums, beta W^T + b, with the GEGLU row
+    order; unet._Engine._ln_gemm): every norm1 -> q|k|v, norm2 -> to_q, norm3 -> ff.net.0 of attention.py:198-200, 231-246,
+    275-277, 308-327 runs as one GEMM over the un-normalised rows and lands on the oracle like the layernorm form does"""
+    sd, m = mini
+    x, ctx, t = _randn((1, 4, 2, 16, 16), 1), _randn((1, 2, 77, 256), 2), torch.tensor([501])
+    eng = _Engine(m, ops=tob)
+    n_ln = sum(1 for k in sd if ".transformer_blocks." in k and k.endswith((".norm1.weight", ".norm2.weight", ".norm3.weight")))
+    with torch.no_grad():
+        got = eng.run(x, t, ctx, 0)
+        assert eng.ln_fold and eng.ln_folded == n_ln == len(eng.wln), (eng.ln_folded, n_ln, len(eng.wln))
+        plain = _Engine(m, ops=tob, fold_ln=False)
+        two = plain.run(x, t, ctx, 0)
+        assert plain.ln_folded == 0
+        ref = O.unet_forward(sd, CFG_MINI, x, t, ctx, cond_frame=0)
+    e_fold, e_two = ((got - ref).norm() / ref.norm()).item(), ((two - ref).norm() / ref.norm()).item()
+    assert e_fold < 3e-2 and e_fold < 1.5 * e_two + 1e-3, (e_fold, e_two)
+    # cond_frame > 0: the temporal feed-forward runs on row subsets (no statistics attached): those norms keep the layernorm kernel
+    with torch.no_grad():
+        x3, c3 = _randn((1, 4, 3, 8, 8), 3), _randn((1, 3, 77, 256), 4)
+        got3 = eng.run(x3, t, c3, 1)
+        assert 0 < eng.ln_folded < n_ln
+        ref3 = O.unet_forward(sd, CFG_MINI, x3, t, c3, cond_frame=1)
+    assert ((got3 - ref3).norm() / ref3.norm()).item() < 3e-2
+
+
+def test_fold_layernorm_identity():
+    """ops.fold_layernorm in exact arithmetic: LN(x) W^T + b == rstd (x W'^T - mean wsum) + b' (fp64, W' unrounded apart from bf16)"""
+    from seervideoldm_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((37, 64), generator=g, dtype=torch.float64) * 3 + 2
+    w = torch.randn((24, 64), generator=g) * 0.2
+    gamma, beta, b = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1, torch.randn(24, generator=g)
+    wp, wsum, bp = ops.fold_layernorm(w, gamma, beta, b)
+    assert wp.dtype == torch.bfloat16 and wsum.dtype == torch.float32 and bp.dtype == torch.float32
+    mean, var = x.mean(1, keepdim=True), x.var(1, unbiased=False, keepdim=True)
+    rstd = (var + 1e-5).rsqrt()
+    folded = rstd * (x @ wp.double().t() - mean * wsum.double()[None, :]) + bp.double()
+    # against the same LayerNorm with the ROUNDED gamma (.) W: identical up to fp64 rounding -- the fold itself adds nothing
+    ln = (x - mean) * rstd
+    exact = ln @ wp.double().t() + bp.double()
+    assert (folded - exact).abs().max().item() < 1e-9
+    # ... and against nn.LayerNorm + nn.Linear in fp64: only the bf16 rounding of gamma (.) W separates them
+    ref = (ln * gamma.double() + beta.double()) @ w.double().t() + b.double()
+    assert (folded - ref).abs().max().item() < 3e-2 * ref.abs().max().item()
+
+
 def test_engine_counts_groupnorms(mini):
     _, m = mini
     eng = _Engine(m, ops=tob)

@@ -41,11 +41,44 @@ def _epilogue(acc, bias, geglu, rowvec, rows_per_batch, silu, residual, out_f32,
     return res
 
 
+class RowStats:
+    """stand-in of ops.RowStats: (sum, sum of squares) per row of a GEMM output, here as fp64"""
+    def __init__(self, tot):
+        self.tot = tot
+
+
+def fold_layernorm(w, gamma, beta, bias=None):
+    """the product's own host-side folding (pure torch): the thing under test on CPU"""
+    from seervideoldm_amd import ops as product_ops
+    return product_ops.fold_layernorm(w, gamma, beta, bias)
+
+
 def gemm(a, w, *, bias=None, residual=None, rowvec=None, rows_per_batch=0, a2=None, geglu=False, silu=False,
-         out_f32=False, out=None, tile=0, splits=0, rotary=None, col_scale=None, colsum_batch=0):
+         out_f32=False, out=None, tile=0, splits=0, rotary=None, col_scale=None, colsum_batch=0, rowstat=False, ln=None):
     A = a.float() if a2 is None else torch.cat([a.float(), a2.float()], 1)
     assert A.shape[1] % 64 == 0 and w.dtype == bf16 and a.dtype == bf16
     acc = A @ w.float().t()
+    if ln is not None:
+        # seer_gemm_desc::ln_rowstat: rstd * (x W'^T - mean * wsum), the term the kernel applies before everything else
+        rs, wsum, eps = ln
+        K = A.shape[1]
+        mean = (rs.tot[:, 0] / K).float()
+        var = (rs.tot[:, 1] / K).float() - mean * mean
+        rstd = torch.rsqrt(var.clamp_min(0) + eps)
+        acc = acc * rstd[:, None] - (mean * rstd)[:, None] * wsum[None, :]
+    res = _gemm_tail(acc, bias, residual, rowvec, rows_per_batch, geglu, silu, out_f32, out, rotary, col_scale)
+    if rowstat:
+        v = res.double()
+        res.rowstats = RowStats(torch.stack([v.sum(1), (v * v).sum(1)], 1))
+    elif hasattr(res, "rowstats"):
+        res.rowstats = None
+    return res
+
+
+def _gemm_tail(acc, bias, residual, rowvec, rows_per_batch, geglu, silu, out_f32, out, rotary, col_scale):
+    if (rotary is not None or col_scale is not None) and bias is not None:
+        acc = acc + bias                # the kernel's order: bias, (GEGLU, row vector,) rotary, column scale, residual
+        bias = None
     if rotary is not None:
         table, tpb, pos_off, hd, rd, cols = rotary
         assert bias is None and residual is None and not geglu
