@@ -1534,10 +1534,11 @@ int prepare(seer_gemm_desc& d, int* splits) {
             // the 4x4 level (x16) and, with fewer frames or one CFG half per rank, the same levels sliced deeper.
             const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
             const long blocks64 = (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
-            // a plain GEMM whose 64x64 grid already holds ~2 blocks per CU and whose K is only moderately long (the 8x8-level
-            // feed-forward output projection, K = 5120): the 5-stage 64x64 ring unsplit beats 128x128 x 4 slices + the reduce
-            // pass, 40.8 vs 47.4 us (profiles/r02_tile_sweep_fastepi.log)
-            const bool unsplit_ring = d.mode == SEER_GEMM_PLAIN && nk < 128 && blocks64 >= 384;
+            // (round 2 kept a plain GEMM whose 64x64 grid already holds ~2 blocks per CU and whose K is only moderately long -- the
+            // 8x8-level feed-forward output projection, 1536 x 1280 x 5120 -- on the 5-stage 64x64 ring unsplit, 40.8 against 47.4 us
+            // for 128x128 x 4 slices + the reduce pass; since the staging path lost its address arithmetic the slices win, 35.2
+            // against 40.0: profiles/r04_ff2_tile_sweep.log)
+            const bool unsplit_ring = false;
             int s128 = 1;
             if (d.N % 128 == 0 && d.N >= 640 && d.M >= 256 && t128 < 256 && nk >= 64 && !unsplit_ring)
                 while (t128 * s128 < 400 && s128 < 16 && nk / (2 * s128) >= 11) s128 *= 2;
@@ -1595,6 +1596,12 @@ int resolve_tile(const seer_gemm_desc& d) {
         else if ((d.epilogue & SEER_EPI_ROTARY) && d.N == 1920 && nk >= 5 && (long)((d.M + 95) / 96) * 12 * d.batch >= 256)
             tile = SEER_TILE_G96x160_2;      // 6 144 x 1 920 x 640 rotary: 24.0 us against 26.8 on 128x128 (same log)
         else if (t128 >= 256 && n_fits_128 && d.N >= 640) tile = SEER_TILE_G128x128_2;
+        // a conv whose 128x128 grid just misses one round of the chip but whose 96x128 grid fills it (the 16x16-level 320 -> 640
+        // conv: 240 / 320 tiles): 34.5 against 45.0 us on 128x64 (profiles/r04_conv_tile_sweep.log); plain GEMMs of those sizes stay
+        // on 128x64 (ff.net.2 at that level: 34.0 against 31.5, r04_ff2_tile_sweep.log)
+        else if (d.mode == SEER_GEMM_CONV3X3 && n_fits_128 && d.N >= 640 && t128 >= 192 && nk >= 40 &&
+                 (long)((d.M + 95) / 96) * ((d.N + 127) / 128) * d.batch >= 256)
+            tile = SEER_TILE_G96x128_2;
         else if (t12864 >= 256 && nk >= 5) tile = SEER_TILE_G128x64_3;   // (K = 320 too: 8.9 vs 9.7 us on 12 288 x 320, r02_half_rows.log)
         else if (nk >= 64) tile = SEER_TILE_G64x64_5;        // long K on few tiles: deeper ring (see prepare(), unsplit_ring)
         else if (nk >= 12) tile = SEER_TILE_G64x64_3;
