@@ -1595,7 +1595,14 @@ int resolve_tile(const seer_gemm_desc& d) {
         }
         else if ((d.epilogue & SEER_EPI_ROTARY) && d.N == 1920 && nk >= 5 && (long)((d.M + 95) / 96) * 12 * d.batch >= 256)
             tile = SEER_TILE_G96x160_2;      // 6 144 x 1 920 x 640 rotary: 24.0 us against 26.8 on 128x128 (same log)
-        else if (t128 >= 256 && n_fits_128 && d.N >= 640) tile = SEER_TILE_G128x128_2;
+        else if (t128 >= 256 && n_fits_128 && d.N >= 640) {
+            // 128x128, unless 96-row tiles leave the last round of resident workgroups (two per CU) clearly fuller: the q|k|v
+            // projections of the 8x8 / 16x16 level are 360 / 720 tiles of 128 rows (0.70 of one / two rounds) but 480 / 960 of 96
+            // rows (0.94): 22.0 -> 19.0, 23.1 -> 20.2 (rotary), 22.3 -> 20.9 us (profiles/r04_plain_tile_sweep.log)
+            const long t96128 = (long)((d.M + 95) / 96) * ((d.N + 127) / 128) * d.batch;
+            auto fill2 = [](long t) { return (double)t / (512.0 * (double)((t + 511) / 512)); };
+            tile = (d.mode == SEER_GEMM_PLAIN && fill2(t96128) > fill2(t128) + 0.15) ? SEER_TILE_G96x128_2 : SEER_TILE_G128x128_2;
+        }
         // a conv whose 128x128 grid just misses one round of the chip but whose 96x128 grid fills it (the 16x16-level 320 -> 640
         // conv: 240 / 320 tiles): 34.5 against 45.0 us on 128x64 (profiles/r04_conv_tile_sweep.log); plain GEMMs of those sizes stay
         // on 128x64 (ff.net.2 at that level: 34.0 against 31.5, r04_ff2_tile_sweep.log)
