@@ -558,3 +558,39 @@ def test_context_length_and_batch(device, B, L):
     t = torch.tensor([3 + 331 * i for i in range(B)])
     y = m(x.to(device), t.to(device), ctx.to(device), cond_frame=1)
     _check(y, O.unet_forward(sd, cfg, x, t, ctx, cond_frame=1), f"B={B} L={L}")
+
+
+def test_statistics_forms_fall_back_and_agree(device, monkeypatch):
+    """The accumulated GroupNorm statistics and the folded LayerNorm are optimisations with fall-backs: an arena that runs out hands
+    later producers the per-tile form (a GroupNorm whose two sources then disagree on the form takes the statistics pass), and every
+    combination of the switches lands on the oracle (resnet.py:179,197, attention.py:133, 198-200)."""
+    from seervideoldm_amd import ops
+    cfg, sd, m = _model("mini", device)
+    x, ctx, t = _randn((2, 4, 3, 16, 16), 5), _randn((2, 3, 77, cfg["cross_attention_dim"]), 6), torch.tensor([300, 300])
+    ref = O.unet_forward(sd, cfg, x, t, ctx, cond_frame=0)
+    outs = {}
+    for fx, ln in ((True, True), (False, True), (True, False), (False, False)):
+        m._engine = None
+        m.gn_fx, m.ln_fold = fx, ln
+        try:
+            outs[(fx, ln)] = m(x.to(device), t.to(device), ctx.to(device)).clone()
+            eng = m._engine
+            assert (eng.ln_folded > 0) == ln
+        finally:
+            del m.gn_fx, m.ln_fold
+            m._engine = None
+        _check(outs[(fx, ln)], ref, f"unet gn_fx={fx} ln_fold={ln}")
+    # an arena that refuses every third request: mixed forms inside one evaluation
+    real_take, calls = ops.FxArena.take, [0]
+
+    def flaky_take(self, reps, batch, C_):
+        calls[0] += 1
+        return None if calls[0] % 3 == 0 else real_take(self, reps, batch, C_)
+    monkeypatch.setattr(ops.FxArena, "take", flaky_take)
+    m._engine = None
+    try:
+        mixed = m(x.to(device), t.to(device), ctx.to(device)).clone()
+    finally:
+        m._engine = None
+    assert calls[0] > 10
+    _check(mixed, ref, "unet with an arena that runs out")
