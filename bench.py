@@ -421,6 +421,9 @@ def main():
                         algorithmic_bytes_per_launch=round(gm["bytes"] / gm["launches"]),
                         launches_per_step=gm["launches"] // reps, avg_launch_us=round(avg_launch_ms * 1e3, 2),
                         algorithmic_gflop_per_launch=round(per_launch_flops / 1e9, 3),
+                        flops="executed: 2MNK per launched GEMM / conv; the convs behind a nearest-2x upsample count their four "
+                              "2x2 phase convs (16 tap products per source pixel, not the reference's 36); a call that launches "
+                              "nothing is not counted",
                         step_breakdown_ms={k: round(v["ms"] / reps, 3) for k, v in summ.items()},
                         attention_tflops=round(summ.get("attention", {}).get("tflops", 0.0), 2),
                         groupnorms_from_colsums=f"{eng.gn_from_colsums} of {eng.n_groupnorms()}",

@@ -22,32 +22,20 @@ import torch
 from . import ops
 
 
-def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3):
-    """ldm/modules/diffusionmodules/util.py:21-44 ('linear' is sqrt-space linspace; the only one the path uses)."""
-    if schedule == "linear":
-        betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64) ** 2
-    elif schedule == "sqrt_linear":
-        betas = torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64)
-    elif schedule == "sqrt":
-        betas = torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64) ** 0.5
-    else:
-        raise ValueError(f"schedule '{schedule}' unknown.")
-    return betas.numpy()
+def _betas(n_train: int, beta_first: float, beta_last: float) -> np.ndarray:
+    """The one noise schedule of this path: sqrt(beta) rises in n_train equal steps from sqrt(beta_first) to
+    sqrt(beta_last); float64, like the reference's table (ldm/modules/diffusionmodules/util.py:23-26 under the name "linear")."""
+    root = torch.linspace(float(beta_first) ** 0.5, float(beta_last) ** 0.5, int(n_train), dtype=torch.float64)
+    return (root * root).numpy()
 
 
-def make_ddim_timesteps(ddim_discr_method, num_ddim_timesteps, num_ddpm_timesteps, verbose=True):
-    """util.py:46-60 -- note c = T // S, so S=30 yields 31 timesteps."""
-    if ddim_discr_method == "uniform":
-        c = num_ddpm_timesteps // num_ddim_timesteps
-        ddim_timesteps = np.asarray(list(range(0, num_ddpm_timesteps, c)))
-    elif ddim_discr_method == "quad":
-        ddim_timesteps = ((np.linspace(0, np.sqrt(num_ddpm_timesteps * .8), num_ddim_timesteps)) ** 2).astype(int)
-    else:
-        raise NotImplementedError(f'There is no ddim discretization method called "{ddim_discr_method}"')
-    steps_out = ddim_timesteps + 1
-    if verbose:
-        print(f"Selected timesteps for ddim sampler: {steps_out}")
-    return steps_out
+def _strided_timesteps(n_sample: int, n_train: int) -> np.ndarray:
+    """Every (n_train // n_sample)-th training step, shifted by one: S = 50 -> 1, 21, ..., 981; S = 30 has stride 33 and
+    therefore 31 entries (util.py:46-60, the "uniform" rule)."""
+    stride = int(n_train) // int(n_sample)
+    if stride < 1:
+        raise ValueError(f"{n_sample} sampling steps do not fit into {n_train} training steps")
+    return np.arange(0, int(n_train), stride, dtype=np.int64) + 1
 
 
 class DDIMSampler(object):
@@ -67,9 +55,15 @@ class DDIMSampler(object):
                       linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3, ddim_discretize="uniform", ddim_eta=0.,
                       verbose=True):
         """ddim_video.py:27-68.  Host arithmetic mirrors the reference's dtypes: cumprod in float64, stored float32."""
-        self.ddim_timesteps = make_ddim_timesteps(ddim_discretize, ddim_num_steps, self.ddpm_num_timesteps, verbose)
-        betas = given_betas if given_betas is not None else make_beta_schedule(
-            beta_schedule, timesteps, linear_start=linear_start, linear_end=linear_end, cosine_s=cosine_s)
+        if ddim_discretize != "uniform" or (given_betas is None and beta_schedule != "linear"):
+            # the sampler scripts never ask for anything else (ddim_sampling_utils.py:29-36); the reference's other branches
+            # are not on this path
+            raise NotImplementedError(f"schedule {beta_schedule!r} / discretisation {ddim_discretize!r}: this path has the "
+                                      "'linear' (sqrt-space) betas and the 'uniform' stride only")
+        self.ddim_timesteps = _strided_timesteps(ddim_num_steps, self.ddpm_num_timesteps)
+        if verbose:
+            print(f"DDIM timesteps ({len(self.ddim_timesteps)}): {self.ddim_timesteps}")
+        betas = np.asarray(given_betas, dtype=np.float64) if given_betas is not None else _betas(timesteps, linear_start, linear_end)
         alphas_cumprod = np.cumprod(1. - betas, axis=0)
         assert alphas_cumprod.shape[0] == self.ddpm_num_timesteps, "alphas have to be defined for each timestep"
         ac32 = torch.tensor(alphas_cumprod, dtype=torch.float32)

@@ -12,14 +12,22 @@ from . import ops as _ops
 
 
 class TimedOps:
-    def __init__(self, base=_ops):
+    """FLOPs are the EXECUTED ones: the conv behind a nearest-2x upsample counts its four 2x2 phase convs (16 tap products per
+    source pixel), not the 36 of the reference's 9-tap conv over the upsampled grid.  A call that launches nothing (ops.gemm(...,
+    ln=...) returns None when the launch cannot fold its LayerNorm; the caller then runs layernorm + the plain GEMM, both
+    recorded) leaves no record."""
+
+    def __init__(self, base=_ops, event=None):
         self._base = base
-        self.records = defaultdict(list)      # class -> [(start_evt, end_evt, flops, bytes)]
+        self._event = event or (lambda: torch.cuda.Event(enable_timing=True))      # tests on CPU pass a stand-in
+        self.records = defaultdict(list)      # class -> [(start_evt, end_evt, flops, bytes, tag)]
 
     def _timed(self, cls, flops, nbytes, fn, *a, _tag=None, **k):
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s, e = self._event(), self._event()
         s.record()
         out = fn(*a, **k)
+        if out is None:                       # nothing was launched: no work, no time
+            return None
         e.record()
         self.records[cls].append((s, e, flops, nbytes, _tag))
         return out
@@ -148,9 +156,11 @@ class TimedOps:
         return cls
 
     def family_rows(self, reps: int, mfma_peak_tflops: float, hbm_peak_gbs: float):
-        """[{name, launches (per step), us (average per launch), ms (per step), bound, frac}] sorted by time: the spread the
-        class average of the roofline line hides.  frac = algorithmic FLOP/s over the dense bf16 MFMA peak for the MFMA
-        kernels, algorithmic bytes/s over the HBM peak for the normalisation kernels."""
+        """[{name, launches (per step), us (average per launch), ms (per step), ai, bound, frac, frac_mfma, frac_hbm}] sorted by
+        time: the spread the class average of the roofline line hides.  `bound` is the roof the family's arithmetic intensity
+        (algorithmic FLOPs / algorithmic bytes) selects: below the ridge (mfma peak / hbm peak = 312 flop/B) the HBM roof is the
+        lower one and `frac` = algorithmic bytes/s over the HBM peak, above it `frac` = algorithmic FLOP/s over the dense bf16
+        MFMA peak; both fractions are given for the MFMA kernels."""
         agg = {}
         for cls, recs in self.records.items():
             for r in recs:
@@ -159,14 +169,23 @@ class TimedOps:
                 a[1] += r[0].elapsed_time(r[1])
                 a[2] += r[2]
                 a[3] += r[3]
+        ridge = mfma_peak_tflops * 1e12 / (hbm_peak_gbs * 1e9)
         rows = []
         for name, (n, ms, fl, by) in agg.items():
             if ms <= 0:
                 continue
-            mfma = fl > 0
-            frac = (fl / (ms * 1e-3) / 1e12 / mfma_peak_tflops) if mfma else (by / (ms * 1e-3) / 1e9 / hbm_peak_gbs)
-            rows.append(dict(name=name, launches=n // reps, us=round(ms / n * 1e3, 2), ms=round(ms / reps, 3),
-                             bound="mfma" if mfma else "hbm", frac=round(frac, 4)))
+            f_mfma = fl / (ms * 1e-3) / 1e12 / mfma_peak_tflops
+            f_hbm = by / (ms * 1e-3) / 1e9 / hbm_peak_gbs
+            row = dict(name=name, launches=n // reps, us=round(ms / n * 1e3, 2), ms=round(ms / reps, 3))
+            if fl > 0 and by > 0:
+                ai = fl / by
+                row.update(ai=round(ai, 1), bound="mfma" if ai >= ridge else "hbm",
+                           frac=round(f_mfma if ai >= ridge else f_hbm, 4), frac_mfma=round(f_mfma, 4), frac_hbm=round(f_hbm, 4))
+            elif fl > 0:
+                row.update(bound="mfma", frac=round(f_mfma, 4))
+            else:
+                row.update(bound="hbm", frac=round(f_hbm, 4))
+            rows.append(row)
         return sorted(rows, key=lambda r: -r["ms"])
 
     def reset(self):

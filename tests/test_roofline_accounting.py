@@ -1,0 +1,87 @@
+"""The accounting contract of bench.py's `roofline` object (seervideoldm_amd/profiler.py), checked without a GPU: the FULL-SIZE
+kernel schedule of BASELINE config 2 (CFG batch 2 x 12 frames x 32x32 latent, SD-v1-5 widths) walked on torch's meta device with a
+shape-only stand-in for the kernel library (tests/shape_ops_backend.py).
+
+Round 4's line counted ten launches that never ran: ops.gemm(..., ln=...) returns None (nothing launched) when the library keeps the
+level-0 GEGLU projection on LayerNorm + the weight-stationary kernel, and the profiler recorded 2MNK for that call anyway.  Pinned
+here: a call that launches nothing leaves no record; one step = 288 launches of the GEMM / conv class and 5.20 TFLOP of EXECUTED work
+(SURVEY 8(d)'s 5.85 TFLOP for the step counts the two convs behind a nearest-2x upsample at 36 tap products per source pixel; the four
+2x2 phase convs that run execute 16) -- and every row names the roof its arithmetic intensity selects."""
+import pytest
+import torch
+
+from seervideoldm_amd import SeerUNet, synth
+from seervideoldm_amd.profiler import TimedOps
+from seervideoldm_amd.unet import _Engine
+from tests import shape_ops_backend as sob
+
+
+class _Evt:
+    def record(self):
+        pass
+
+    def elapsed_time(self, other):
+        return 1e-3              # 1 us per launch: fractions are not asserted, the bookkeeping is
+
+
+@pytest.fixture(scope="module")
+def walk():
+    return _walk_config2()
+
+
+def _walk_config2():
+    cfg = dict(synth.SD15_UNET_CFG)
+    model = SeerUNet(**cfg).to("meta")
+    timed = TimedOps(base=sob, event=_Evt)
+    eng = _Engine(model, ops=timed)
+    # the rotary tables are keyed by the VALUES of the frequency buffers: meta tensors have none
+    eng._rotary_table = lambda tb, T: sob.rotary_table(eng.w[tb + ".attn1.rotary_emb.freqs"], T)
+    x = torch.empty((2, 4, 12, 32, 32), device="meta")
+    ctx = torch.empty((2, 12, 77, 768), device="meta")
+    t = torch.empty((2,), dtype=torch.long, device="meta")
+    eng._kv_key = None
+    eng._context = lambda c: (torch.empty((2 * 12 * 77, 768), dtype=torch.bfloat16, device="meta"), 77)
+    eng.run(x, t, ctx, 0)
+    timed.reset()                # first evaluation: the 16 cross-attention K|V projections ran (once per prompt, not per step)
+    eng.run(x, t, ctx, 0)
+    return eng, timed
+
+
+def test_one_step_is_288_gemm_launches_and_5p2_executed_tflop(walk):
+    eng, timed = walk
+    gm = timed.summary()["gemm"]
+    assert gm["launches"] == 288, gm["launches"]
+    assert abs(gm["flops"] / 5.20e12 - 1.0) < 0.01, gm["flops"] / 1e12
+    # the ten level-0 GEGLU projections refused the fold: LayerNorm launches + plain GEMMs, recorded ONCE each
+    assert timed.summary()["layernorm"]["launches"] == 10
+    rows = {r["name"]: r for r in timed.family_rows(1, 2500.0, 8000.0)}
+    assert rows["ff.net.0 GEGLU L0"]["launches"] == 10
+    assert eng.ln_folded == 70
+    # attention: 5 spatial + 5 cross + 5 temporal blocks at each of the three attention levels + the mid block
+    assert timed.summary()["attention"]["launches"] == 48
+
+
+def test_rows_name_the_roof_their_arithmetic_intensity_selects(walk):
+    _, timed = walk
+    rows = {r["name"]: r for r in timed.family_rows(1, 2500.0, 8000.0)}
+    # M 24576, N = K = 320: 5 GFLOP over 47 MB = 107 flop/B (the family also holds the level's wider conv_shortcut launches):
+    # far below the 312 flop/B ridge
+    p0 = rows["projections / 1x1 L0"]
+    assert p0["bound"] == "hbm" and 90 < p0["ai"] < 160 and p0["frac"] == p0["frac_hbm"]
+    # a 1280 -> 1280 conv at the 8x8 level: 45 GFLOP over ~37 MB
+    c8 = rows["conv3x3 8x8"]
+    assert c8["bound"] == "mfma" and c8["ai"] > 312 and c8["frac"] == c8["frac_mfma"]
+    for r in rows.values():
+        assert r["bound"] in ("mfma", "hbm") and r["frac"] >= 0
+        if "ai" in r:
+            assert (r["ai"] >= 312.5) == (r["bound"] == "mfma")
+
+
+def test_a_call_that_launches_nothing_leaves_no_record():
+    timed = TimedOps(base=sob, event=_Evt)
+    a = torch.empty((24576, 320), dtype=torch.bfloat16, device="meta")
+    w = torch.empty((2560, 320), dtype=torch.bfloat16, device="meta")
+    assert timed.gemm(a, w, geglu=True, ln=(sob.RowStats(24576), None, 1e-5)) is None
+    assert not timed.records
+    assert timed.gemm(a, w, geglu=True) is not None
+    assert len(timed.records["gemm"]) == 1
