@@ -845,14 +845,14 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
         if (do_ln) {
             float* lnrow = reinterpret_cast<float*>(smem + LNROW_OFF);
             if (tid < BM) {
-                const float sm = (float)((double)ln_raw[0] * (1.0 / (double)(1 << SEER_LN_FX_SHIFT)));
-                const float sq = (float)((double)ln_raw[1] * (1.0 / (double)(1 << SEER_LN_FX_SHIFT)));
-                const float inv = 1.0f / (float)p.K;
-                const float mean = sm * inv;
-                float var = sq * inv - mean * mean;
-                var = var > 0.f ? var : 0.f;
-                const float r = rsqrtf(var + p.ln_eps);
-                *reinterpret_cast<f32x2*>(lnrow + tid * 2) = f32x2{mean * r, r};
+                // E[x^2] - mean^2 in DOUBLE on the exact integer totals: a row whose mean is 100 standard deviations away keeps
+                // its variance (in fp32 the difference of the two ~1e4-times-larger terms loses it); BM threads, once per tile
+                const double k = 1.0 / ((double)(1 << SEER_LN_FX_SHIFT) * (double)p.K);
+                const double mean = (double)ln_raw[0] * k;
+                double var = (double)ln_raw[1] * k - mean * mean;
+                var = var > 0.0 ? var : 0.0;
+                const float r = (float)(1.0 / __builtin_sqrt(var + (double)p.ln_eps));
+                *reinterpret_cast<f32x2*>(lnrow + tid * 2) = f32x2{(float)mean * r, r};
             }
             __syncthreads();
 #pragma unroll

@@ -728,6 +728,18 @@ int seer_gemm_t320_launch(const seer_gemm_desc& d0, int splits, hipStream_t st) 
     const int tiles = ((d.M + 255) / 256) * (d.N / 320);
     const int batch = d.batch > 1 ? d.batch : 1;
     if (splits > 1) {
+        // the slices of a tile WAIT for each other inside the launch: all of them must be resident at once (one workgroup per CU at
+        // this LDS size).  A request that does not fit runs with the largest split that does (same result up to the order of the
+        // fp32 additions) instead of relying on dispatch order and the bounded wait.
+        static const int n_cu = [] {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+                return v;
+            return 256;
+        }();
+        if ((int64_t)tiles * splits > n_cu) splits = tiles >= n_cu ? 1 : n_cu / tiles;
+    }
+    if (splits > 1) {
         if (geglu || batch > 1 || splits > SMAX || splits > d.K / 64) return SEER_EINVAL;
         if (!d.workspace || d.workspace_bytes < seer_gemm_t320_workspace_bytes(d, splits)) return SEER_EINVAL;
         if (!d.sync || d.sync_bytes < seer_gemm_t320_sync_bytes(d, splits)) return SEER_EINVAL;

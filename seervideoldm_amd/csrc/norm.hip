@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(256) gn_apply_cs_kernel(const bf16* __restrict
                                                           float inv_count, float eps, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int silu, bf16* __restrict__ y,
                                                           float* __restrict__ stats_out) {
-    __shared__ float part[12][128][2];                  // [tile lane][channel of the slice][sum, sumsq]
+    __shared__ float part[16][128][2];                  // [tile lane][channel of the slice][sum, sumsq]: sc >= 64 -> at most 256 / 16 tile lanes
     __shared__ float mean_s[16], rstd_s[16];
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(256) gn_apply_cs_kernel(const bf16* __restrict
     // item, 8..12 tile lanes, four items (eight 16-byte loads) in flight -- three dependent rounds at the 32x32 level instead of
     // the eleven a channel-per-thread form needs
     const int nq = g.sc / 4;                            // channel quads in the slice (20 or 30)
-    const int ntl = 256 / nq;                           // tile lanes (12 or 8)
+    const int ntl = 256 / nq;                           // tile lanes (12 or 8 at the UNet's widths; 16 at sc = 64, 14 at sc = 72)
     if constexpr (FX) {
         // the producers ACCUMULATED the sums per (batch element, channel) in 64-bit fixed point (seer_gemm_desc::colsum_fx): one
         // 16-byte load per channel, the group's channels added as integers (exact, order-free), one conversion per group

@@ -105,20 +105,22 @@ def fold_layernorm(w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, bia
 
 
 class FxArena:
-    """Bump allocator over one int64 buffer for the ColSumsFx of a UNet evaluation: reset() once per evaluation zeroes what the
-    previous evaluation of the same schedule used (one fill launch), take() hands out [batch, C, 2] slices.  Pass
-    colsum_batch=(B, arena) to gemm / conv3x3 / conv_up2x."""
+    """Bump allocator over one int64 buffer for the ColSumsFx of a UNet evaluation: reset() once per evaluation zeroes everything
+    that has EVER been handed out (one fill launch), take() hands out [batch, C, 2] slices.  Pass colsum_batch=(B, arena) to
+    gemm / conv3x3 / conv_up2x.
+    The zeroed prefix never shrinks: a replayed hipGraph adds into the slots baked into it without this object seeing it, so the
+    slots a larger shape took once may hold sums again whatever the evaluations in between asked for (capture shape A, run a
+    smaller shape eagerly, replay A, run A eagerly: that last reset must cover A's slots, not the small shape's)."""
 
     def __init__(self, device, int64_elems: int):
         self.buf = torch.zeros((int64_elems,), device=device, dtype=torch.int64)
         self.used = 0
-        self.high = int64_elems        # everything is zero now; reset() zeroes the prefix that has been handed out since
+        self.high = 0                  # high-water mark over the arena's whole life
 
     def reset(self):
         if self.high:
             self.buf[:self.high].zero_()
         self.used = 0
-        self.high = 0
 
     def take_rows(self, rows: int) -> Optional[torch.Tensor]:
         n = rows * 2

@@ -909,7 +909,10 @@ def test_cfg_ddim_step(device):
 
 @pytest.mark.parametrize("C1,C2,rows,tile", [(320, 0, 1536, 0), (640, 0, 768, 0), (1280, 0, 512, 0), (640, 320, 768, 0), (1280, 1280, 256, 0),
                                              (320, 320, 1536, 0), (1280, 640, 512, 0), (320, 0, 2048, 22), (1280, 0, 1024, 22),
-                                             (640, 0, 3072, 0), (640, 640, 3072, 0)])
+                                             (640, 0, 3072, 0), (640, 640, 3072, 0),
+                                             # slice widths 64 and 72 (16 and 14 tile lanes in the statistics pass: past the 12 the
+                                             # UNet's own widths use), group widths 16 / 32 / 64 / 24
+                                             (512, 0, 768, 0), (1024, 0, 512, 0), (2048, 0, 256, 0), (768, 0, 512, 0), (512, 512, 512, 0)])
 def test_groupnorm_apply_from_colsums(device, C1, C2, rows, tile):
     """One launch = seer_groupnorm_stats_from_colsums + seer_groupnorm_apply: every block re-derives the statistics of its own
     groups from the producers' column sums (resnet.py:179,197 / attention.py:133 normalise the 5-D tensor per (batch, group)).

@@ -53,6 +53,27 @@ def test_unet_changing_shapes_under_graph_replay(device):
             assert torch.equal(m(x, t, c, cond_frame=cf), ref[i]), (rnd, i)
 
 
+def test_unet_graph_replay_between_eager_forwards_of_two_shapes(device):
+    """The fixed-point accumulators of an evaluation (ops.FxArena) are zeroed by reset() at its head.  A replayed hipGraph adds into
+    the slots baked into it without the host-side bump allocator seeing it: capture the LARGE shape, run a SMALL shape eagerly
+    (fewer slots handed out), replay the large graph, then run the large shape EAGERLY on the same engine (what a return_attn
+    forward or the capture-failure fallback does) -- its slots beyond the small shape's must have been zeroed too."""
+    big = (_randn((2, 4, 3, 16, 16), 1).to(device), torch.tensor([300, 300], device=device), _randn((2, 3, 77, 192), 2).to(device))
+    small = (_randn((1, 4, 2, 8, 8), 3).to(device), torch.tensor([301], device=device), _randn((1, 2, 77, 192), 4).to(device))
+    ref_big, ref_small = _unet(device)(*big, cond_frame=0).clone(), _unet(device)(*small, cond_frame=0).clone()
+    m = _unet(device)
+    m.use_graph = True
+    assert torch.equal(m(*big, cond_frame=0), ref_big)            # eager warm-up + capture + first replay
+    m.use_graph = False
+    assert torch.equal(m(*small, cond_frame=0), ref_small)        # eager, fewer accumulator slots
+    m.use_graph = True
+    assert torch.equal(m(*big, cond_frame=0), ref_big)            # replay: adds into the large shape's slots
+    m.use_graph = False
+    assert torch.equal(m(*big, cond_frame=0), ref_big)            # eager on the same arena
+    out, _attn = m(*big, cond_frame=0, return_attn=True)          # the analysis path is eager too
+    assert torch.equal(out, ref_big)
+
+
 def test_fstext_changing_frames_and_batch(device):
     ctxs = [_randn((b, 77, 192), 20 + b).to(device) for b in (1, 2, 3)]
     plan = [(4, 0), (6, 1), (16, 2), (4, 1), (6, 0), (4, 0)]
