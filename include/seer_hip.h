@@ -240,7 +240,8 @@ typedef struct seer_attn_desc {
     /* kernel selection, a descriptor field so that A/B runs need no global state: 0 = auto; 1 = generic kernel, one K|V LDS
      * buffer; 6 = generic kernel, ping-pong buffers; head_dim 40 only: 3 = the d = 40 kernel (fast path with the in-launch
      * fallback; 32 queries per wave), 2 = the same with 64 queries per wave (what 0 picks from four rounds of resident workgroups
-     * up), 5 = the kernel running its tracked-reference form directly (what lse != NULL selects) */
+     * up), 5 = the kernel running its tracked-reference form directly (what lse != NULL selects), 7 = the 64-query form on a
+     * three-stage K|V ring in LDS (Sq % 256 == 0, Sk % 128 == 0, not causal, not windowed: what 0 picks for such launches) */
     int32_t variant;
     /* head strides (elements): head h of Q / K / V starts h * q_hs / k_hs / v_hs elements after the batch element's base.
      * 0 = head_dim: the heads are adjacent column groups of token-major rows (the layout of a fused [tokens, 3C] projection).

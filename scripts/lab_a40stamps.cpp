@@ -25,6 +25,7 @@ int main() {
     ad.q_ss = ad.k_ss = ad.v_ss = ld; ad.o_ss = C;
     ad.q_bs = ad.k_bs = ad.v_bs = (int64_t)S * ld; ad.o_bs = (int64_t)S * C;
     ad.batch = batch; ad.heads = heads; ad.head_dim = d; ad.Sq = S; ad.Sk = S; ad.scale = 0.158f;
+    if (getenv("LAB_VARIANT")) ad.variant = atoi(getenv("LAB_VARIANT"));
     for (int i = 0; i < 3; ++i) { int rc = seer_attn_fwd(&ad, nullptr); if (rc) { printf("rc %d\n", rc); return 1; } }
     CK(hipDeviceSynchronize());
     long long* dst = seer_lab_a40_stamps();
@@ -40,7 +41,7 @@ int main() {
             printf("]");
             i += 8;
         }
-        printf(" | total %lld ticks of 10 ns\n", t[i] - t[0]);
+        printf(" | loop end %lld, epilogue %lld, total %lld ticks of 10 ns\n", t[i] - t[0], t[i + 1] - t[i], t[i + 1] - t[0]);
     }
     return 0;
 }

@@ -18,9 +18,10 @@ replay difference" of round 2 and the 1 % gradient mismatches of the co-tenant t
 `v_pk_mov_b32` is exempt: its low result reads only src0.
 
 Rule `attn40_vregs` -- attention40.hip issues its V'^T LDS reads in one asm statement (`lds_issue_kv`, ends with
-`s_waitcnt lgkmcnt(8)`) and waits for them in a later one (`lds_wait_v`, `s_waitcnt lgkmcnt(0)`): the hardware writes those
-eight register pairs AFTER the first statement has ended, behind the register allocator's back.  Between the two statements no
-instruction may name one of them (a copy or a spill would move stale data).
+`s_waitcnt lgkmcnt(8)`; ring form: `lds_issue_v`, and `lds_prefetch_k` for the next sub tile's K' fragments, neither with a wait)
+and waits for them in a later one (`lds_wait_v` / `lds_wait_vk`, `s_waitcnt lgkmcnt(0)`): the hardware writes those registers
+AFTER the issuing statement has ended, behind the register allocator's back.  Between the two statements no instruction may name
+one of them (a copy or a spill would move stale data).
 """
 from __future__ import annotations
 
@@ -94,12 +95,16 @@ def check_attn40_vregs(lines: Iterable[str], fname: str = "") -> Tuple[List[str]
                 block.append(lines[j])
                 j += 1
             text = "".join(block)
-            if "ds_read_b64_tr_b16" in text and "lgkmcnt(8)" in text:
+            # an ISSUE statement: LDS reads whose results are not (all) waited for inside the statement -- lds_issue_kv (waits for
+            # its three K' reads, lgkmcnt(8): the eight V'^T destinations stay live), lds_issue_v / lds_prefetch_k of the ring form
+            # (no wait: every destination stays live)
+            dests = [r.group(1) for r in (re.match(r"\s*ds_read_\w+\s+(v\[\d+:\d+\]|v\d+)", b) for b in block) if r]
+            wm = re.search(r"lgkmcnt\((\d+)\)", text)
+            n_live = len(dests) if wm is None else min(int(wm.group(1)), len(dests))
+            if dests and n_live > 0:
                 live: Set[int] = set()
-                for b in block:
-                    r = re.match(r"\s*ds_read_b64_tr_b16\s+(v\[\d+:\d+\])", b)
-                    if r:
-                        live |= _regs(r.group(1))
+                for dreg in dests[len(dests) - n_live:]:
+                    live |= _regs(dreg)
                 # scan to the wait statement
                 k = j + 1
                 found = False

@@ -139,6 +139,34 @@ __device__ __forceinline__ void lds_wait_v(VRegs& v, bf16x8& v00, bf16x8& v01, b
     v11 = __builtin_bit_cast(bf16x8, u32x4{v.r[6][0], v.r[6][1], v.r[7][0], v.r[7][1]});      // key step 1, d tile 1
 }
 
+// Ring form (NST = 3): the K' fragments of sub tile i + 1 are requested right behind the Q K^T MFMAs of sub tile i (no wait: they land
+// under the exponentials), sub tile i + 1 then issues only its V'^T reads.  LDS returns in order, so lgkmcnt(0) in lds_wait_vk covers
+// both; the three K registers obey the same rule as the V registers: between the issuing statement and the waiting one nothing may
+// name them (seervideoldm_amd/asm_check.py, rule attn40_vregs).
+struct KRegs { u32x4 r[3]; };
+__device__ __forceinline__ void lds_prefetch_k(unsigned a01, unsigned a2, KRegs& k) {
+    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:32\n\tds_read_b128 %2, %4"
+                 : "=&v"(k.r[0]), "=&v"(k.r[1]), "=&v"(k.r[2]) : "v"(a01), "v"(a2) : "memory");
+}
+__device__ __forceinline__ void lds_issue_v(unsigned v0, unsigned v1, VRegs& v) {
+    asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:160\n\t"
+                 "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:160\n\t"
+                 "ds_read_b64_tr_b16 %4, %8 offset:1280\n\tds_read_b64_tr_b16 %5, %8 offset:1440\n\t"
+                 "ds_read_b64_tr_b16 %6, %9 offset:1280\n\tds_read_b64_tr_b16 %7, %9 offset:1440"
+                 : "=&v"(v.r[0]), "=&v"(v.r[1]), "=&v"(v.r[2]), "=&v"(v.r[3]), "=&v"(v.r[4]), "=&v"(v.r[5]), "=&v"(v.r[6]), "=&v"(v.r[7])
+                 : "v"(v0), "v"(v1) : "memory");
+}
+__device__ __forceinline__ void lds_wait_vk(VRegs& v, KRegs& k, bf16x8& v00, bf16x8& v01, bf16x8& v10, bf16x8& v11) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(v.r[0]), "+v"(v.r[1]), "+v"(v.r[2]), "+v"(v.r[3]), "+v"(v.r[4]), "+v"(v.r[5]), "+v"(v.r[6]), "+v"(v.r[7]),
+                   "+v"(k.r[0]), "+v"(k.r[1]), "+v"(k.r[2])
+                 :: "memory");
+    v00 = __builtin_bit_cast(bf16x8, u32x4{v.r[0][0], v.r[0][1], v.r[1][0], v.r[1][1]});
+    v01 = __builtin_bit_cast(bf16x8, u32x4{v.r[2][0], v.r[2][1], v.r[3][0], v.r[3][1]});
+    v10 = __builtin_bit_cast(bf16x8, u32x4{v.r[4][0], v.r[4][1], v.r[5][0], v.r[5][1]});
+    v11 = __builtin_bit_cast(bf16x8, u32x4{v.r[6][0], v.r[6][1], v.r[7][0], v.r[7][1]});
+}
+
 template <bool B> struct BoolTag { static constexpr bool value = B; };
 
 // TRACK_ONLY: run the tracked-reference form directly (variant 4 / 5, and whenever lse is requested)
@@ -161,17 +189,22 @@ extern "C" long long* seer_lab_a40_stamps() {
 // PLAIN: not causal, not windowed (the spatial self-attention and text cross-attention blocks): the window / diagonal
 // arithmetic folds away -- and the two uses of the kernel carry different names in a profile (the spatial [192,1024,40] block is
 // the north star's kernel target; the causal window form serves the temporal blocks at 36 us, and one name for both reads 43)
-template <int QB, bool TRACK_ONLY, bool PLAIN>
-__global__ void __launch_bounds__(256, QB == 1 ? 3 : 2) seer_attn40_kernel(const seer_attn_desc p, const int ws_log2_arg, const int nqb) {
+// NST: K|V stages in LDS.  2 = the next tile is requested behind this tile's barrier (five LDS-DMA pieces per wave in one burst) and
+// waited for with vmcnt(0) at the top of the next tile.  3 (ring): tile t + 2 is requested DURING tile t, one piece per sub tile behind
+// the sub tile's Q K^T MFMAs, and the top of a tile waits only for ITS pieces (vmcnt(5): the next tile's five stay in flight) -- the
+// per-tile wait + barrier + issue burst was a third of a tile period (profiles/r02_attn40_stamps.log).
+template <int QB, bool TRACK_ONLY, bool PLAIN, int NST = 2>
+__global__ void __launch_bounds__(256, (QB == 1 && NST == 2) ? 3 : 2) seer_attn40_kernel(const seer_attn_desc p, const int ws_log2_arg, const int nqb) {
     const int ws_log2 = PLAIN ? -1 : ws_log2_arg;
     const bool causal = PLAIN ? false : (p.causal != 0);
     constexpr int D = A40_D;
     constexpr int QW = 32 * QB;                      // queries per wave
-    // two K|V stages + the constant region
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * A40_STAGE + A40_ZBYTES];
+    // NST K|V stages + the constant region
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NST * A40_STAGE + A40_ZBYTES];
     unsigned char* const stage_a = lds;
     unsigned char* const stage_b = lds + A40_STAGE;
-    unsigned char* const zreg = lds + 2 * A40_STAGE;
+    [[maybe_unused]] unsigned char* const stage_c = lds + (NST - 1) * A40_STAGE;
+    unsigned char* const zreg = lds + NST * A40_STAGE;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -247,44 +280,70 @@ __global__ void __launch_bounds__(256, QB == 1 ? 3 : 2) seer_attn40_kernel(const
         const int64_t tk = tok(kg);
         return (unsigned)((tk * (is_v ? p.v_ss : p.k_ss) + c8) * 2);      // < 2^32: checked by the launcher
     };
-    auto issue_tile = [&](int t, unsigned char* stage) {
+    auto issue_piece = [&](int t, unsigned char* stage, int i) {   // piece i (0..4) of this wave's share of tile t
         const bool partial = (t + 1) * A40_KT > p.Sk;                 // wave-uniform
+        const int e = wave + 4 * i;
+        const bool is_v = e >= 10;
+        const int j = is_v ? e - 10 : e;
+        const unsigned off = partial ? dma_off(i, t * A40_KT) : dma_o[i];
+        dma_o[i] += (unsigned)(tok_step * (is_v ? p.v_ss : p.k_ss) * 2);
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(is_v ? Vg : Kg);      // wave-uniform
+        unsigned char* dst = stage + (is_v ? A40_HALF : 0) + j * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+    auto issue_tile = [&](int t, unsigned char* stage) {
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int e = wave + 4 * i;
-            const bool is_v = e >= 10;
-            const int j = is_v ? e - 10 : e;
-            const unsigned off = partial ? dma_off(i, t * A40_KT) : dma_o[i];
-            dma_o[i] += (unsigned)(tok_step * (is_v ? p.v_ss : p.k_ss) * 2);
-            const unsigned char* base = reinterpret_cast<const unsigned char*>(is_v ? Vg : Kg);      // wave-uniform
-            unsigned char* dst = stage + (is_v ? A40_HALF : 0) + j * 1024;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        }
+        for (int i = 0; i < 5; ++i) issue_piece(t, stage, i);
     };
 
     // ---- Q' fragments (B operand of S^T = K' Q'^T: col = query, k = 16 s + 8 h + j), scaled to the exp2 domain
     const float cscale = (p.flags & SEER_ATTN_Q_PRESCALED) ? 1.0f : p.scale * 1.4426950408889634f;
+    // start of the K|V stream: tile 0 (ring: and tile 1) requested behind the Q loads, in front of everything that waits for Q
+    // (ring: tile 1 follows in start_stream_2, BEHIND the conversion of Q -- the compiler's wait for the Q loads is vmcnt(0), and
+    //  the cold start is bandwidth-bound: every workgroup of the chip asks for Q and its first tile at once, ~11 B per cycle and CU)
+    auto start_stream = [&]() {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) dma_o[i] = dma_off(i, 0);
+        issue_tile(0, stage_a);
+    };
+    auto start_stream_2 = [&]() {
+        if constexpr (NST == 3) {
+            if (ntiles > 1) issue_tile(1, stage_b);
+        }
+    };
     bf16x8 qf[QB][3];
+    {
+        // all 3 QB loads in flight together (a wait per load serialised six L2 / HBM round trips in front of the first tile)
+        u32x4 qraw[QB][3];
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        int qi = q0w + 32 * qb + lq;
-        qi = qi < p.Sq ? qi : p.Sq - 1;
-        const bf16* qrow = Qg + (int64_t)tok(qi) * p.q_ss;
+        for (int qb = 0; qb < QB; ++qb) {
+            int qi = q0w + 32 * qb + lq;
+            qi = qi < p.Sq ? qi : p.Sq - 1;
+            const bf16* qrow = Qg + (int64_t)tok(qi) * p.q_ss;
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            u32x4 raw = {0u, 0u, 0u, 0u};
-            if (s < 2 || lh == 0) raw = *reinterpret_cast<const u32x4*>(qrow + 16 * s + 8 * lh);
-            if (p.flags & SEER_ATTN_Q_PRESCALED) {
-                qf[qb][s] = __builtin_bit_cast(bf16x8, raw);
-            } else {
+            for (int s = 0; s < 3; ++s) {
+                // (s, lh) = (2, 1) is the padding: those lanes re-read chunk (2, 0) and drop it -- no divergent load
+                const u32x4 v = *reinterpret_cast<const u32x4*>(qrow + 16 * s + ((s == 2) ? 0 : 8 * lh));
+                qraw[qb][s] = v;
+            }
+        }
+        start_stream();
+        const bool pre = (p.flags & SEER_ATTN_Q_PRESCALED) != 0;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                u32x4 raw = qraw[qb][s];
+                if (s == 2 && lh) raw = u32x4{0u, 0u, 0u, 0u};
                 float f[8];
                 unpack8(raw, f);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) f[j] *= cscale;
-                qf[qb][s] = __builtin_bit_cast(bf16x8, pack8(f));
+                const u32x4 scaled = pack8(f);
+                qf[qb][s] = __builtin_bit_cast(bf16x8, pre ? raw : scaled);
             }
-        }
+        start_stream_2();
     }
 
     // ---- per-lane LDS offsets (bytes, relative to the sub tile's first row)
@@ -330,11 +389,12 @@ __global__ void __launch_bounds__(256, QB == 1 ? 3 : 2) seer_attn40_kernel(const
     // (Measured and dropped, profiles/r02_attn40_variants.log: issuing the QK^T MFMAs of block i+1 before the exponentials of
     //  block i -- +16 registers for the second score tile, 0...-8 %: with three waves per SIMD the other waves already fill
     //  the matrix pipe, and the extra registers cost the 64-query form its third wave.)
-    auto run = [&](auto track) {
+    auto run = [&](auto track, const bool started) {
         constexpr bool TRACK = decltype(track)::value;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) dma_o[i] = dma_off(i, 0);
-        issue_tile(0, stage_a);
+        if (!started) {
+            start_stream();
+            start_stream_2();
+        }
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             oacc[qb][0] = zero16;
@@ -342,15 +402,26 @@ __global__ void __launch_bounds__(256, QB == 1 ? 3 : 2) seer_attn40_kernel(const
             set_ref(qb, 0.f);
         }
 
+        // st_a: LDS address of tile t's stage; st_next: the stage of the tile requested during tile t (t + 1, ring: t + 2)
         auto tile = [&](const int t, const unsigned st_a, unsigned char* st_next) {
             A40_STAMP();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of tile t (and, at t = 0, Q) has landed
+            // this wave's part of tile t (and, at t = 0, Q) has landed; ring: the five pieces of tile t + 1 stay in flight
+            if (NST == 3 && t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             A40_STAMP();
             __builtin_amdgcn_s_barrier();                         // all of tile t has landed; everyone left tile t-1
             A40_STAMP();
-            if (t + 1 < ntiles) issue_tile(t + 1, st_next);
+            if (NST == 2 && t + 1 < ntiles) issue_tile(t + 1, st_next);
             A40_STAMP();
             const int kt0 = t * A40_KT;
+            const bool ring_issue = NST == 3 && t + 2 < ntiles;   // wave-uniform
+            // ring: this wave's pieces of tile t + 2, spread over the sub tiles (piece 4 rides with piece 1: sub tile 0 already
+            // pays the K' read behind the barrier)
+            auto ring_pieces = [&](int sub) {
+                if (!ring_issue) return;
+                issue_piece(t + 2, st_next, sub);
+                if (sub == 1) issue_piece(t + 2, st_next, 4);
+            };
 
             if (t == 0) {
                 // reference of the softmax: the maximum over the first 32 keys (every query sees key 0)
@@ -368,20 +439,39 @@ __global__ void __launch_bounds__(256, QB == 1 ? 3 : 2) seer_attn40_kernel(const
                 }
             }
 
+            [[maybe_unused]] KRegs knext;                         // ring: K' fragments requested one sub tile ahead
+            // ring fast path: whole tiles only (the launcher admits Sq % 256 == 0 and Sk % 128 == 0), so which sub tiles carry
+            // prefetched K' is known at compile time -- a run-time choice between two issue statements would make the register
+            // allocator merge (copy) registers the LDS is still writing
+            constexpr bool RING_FAST = NST == 3 && QB == 2 && PLAIN && !TRACK;
 #pragma unroll
             for (int sub = 0; sub < 4; ++sub) {
                 const int kb = kt0 + 32 * sub;
                 // wave-uniform: past the last key, or above the causal diagonal of every query of the wave
-                if (kb >= k_end || q0w >= p.Sq || (causal && kb > q0w + QW - 1 + q_off)) continue;
+                if (!RING_FAST && (kb >= k_end || q0w >= p.Sq || (causal && kb > q0w + QW - 1 + q_off))) {
+                    if constexpr (NST == 3) ring_pieces(sub);     // the wave still owes its share of the K|V stream
+                    continue;
+                }
                 const unsigned kst = st_a + sub * 32 * A40_ROWB;
                 bf16x8 kf[3];
                 VRegs vraw;
-                {
+                if constexpr (RING_FAST) {
+                    const unsigned kp = kst + k_off, va = kst + v_off;
+                    if (sub > 0) {                                // K' landed under the previous sub tile (lds_wait_vk waited)
+                        lds_issue_v(va, v1_pad ? v1_const : va + 64, vraw);
+                        kf[0] = __builtin_bit_cast(bf16x8, knext.r[0]);
+                        kf[1] = __builtin_bit_cast(bf16x8, knext.r[1]);
+                        kf[2] = __builtin_bit_cast(bf16x8, knext.r[2]);
+                    } else {
+                        lds_issue_kv(kp, lh ? ZONE : kp + 64, va, v1_pad ? v1_const : va + 64, kf[0], kf[1], kf[2], vraw);
+                    }
+                } else {
                     const unsigned kp = kst + k_off, va = kst + v_off;
                     lds_issue_kv(kp, lh ? ZONE : kp + 64, va, v1_pad ? v1_const : va + 64, kf[0], kf[1], kf[2], vraw);
                 }
                 bf16x8 vf[2][2];                                  // [key step][d tile], shared by the wave's query blocks
                 bool v_ready = false;
+                if constexpr (NST == 3 && !RING_FAST) ring_pieces(sub);
                 if constexpr (QB == 2 && PLAIN && !TRACK) {
                     // two query blocks, software-pipelined: both score tiles are issued before the first exponentials, so the
                     // matrix pipe works on block 1's Q K^T under block 0's exponentials and on block 0's P V under block 1's
@@ -408,8 +498,22 @@ __global__ void __launch_bounds__(256, QB == 1 ? 3 : 2) seer_attn40_kernel(const
                         }
                     };
                     u32x4 pk0[2], pk1[2];
+                    if constexpr (NST == 3) {
+                        // behind the six score MFMAs (192 cycles of the matrix pipe): the next sub tile's K' reads and this wave's
+                        // LDS-DMA piece, so that neither stands between a barrier and the first MFMA of a sub tile
+                        if (sub < 3) {
+                            const unsigned kpn = kst + 32 * A40_ROWB + k_off;
+                            lds_prefetch_k(kpn, lh ? ZONE : kpn + 64, knext);
+                        }
+                        ring_pieces(sub);
+                    }
                     exp_pack(s0, pk0);
-                    lds_wait_v(vraw, vf[0][0], vf[0][1], vf[1][0], vf[1][1]);
+                    if constexpr (NST == 3) {
+                        if (sub < 3) lds_wait_vk(vraw, knext, vf[0][0], vf[0][1], vf[1][0], vf[1][1]);
+                        else lds_wait_v(vraw, vf[0][0], vf[0][1], vf[1][0], vf[1][1]);
+                    } else {
+                        lds_wait_v(vraw, vf[0][0], vf[0][1], vf[1][0], vf[1][1]);
+                    }
                     pv(0, pk0);
                     exp_pack(s1, pk1);
                     pv(1, pk1);
@@ -465,9 +569,17 @@ __global__ void __launch_bounds__(256, QB == 1 ? 3 : 2) seer_attn40_kernel(const
             }
         };
         const unsigned st0 = lds_addr(stage_a);
-        for (int t = 0; t < ntiles; t += 2) {
-            tile(t, st0, stage_b);
-            if (t + 1 < ntiles) tile(t + 1, st0 + A40_STAGE, stage_a);
+        if constexpr (NST == 3) {
+            for (int t = 0; t < ntiles; t += 3) {
+                tile(t, st0, stage_c);
+                if (t + 1 < ntiles) tile(t + 1, st0 + A40_STAGE, stage_a);
+                if (t + 2 < ntiles) tile(t + 2, st0 + 2 * A40_STAGE, stage_b);
+            }
+        } else {
+            for (int t = 0; t < ntiles; t += 2) {
+                tile(t, st0, stage_b);
+                if (t + 1 < ntiles) tile(t + 1, st0 + A40_STAGE, stage_a);
+            }
         }
         __syncthreads();                              // every wave has left the stages (re-run, or the O staging below)
     };
@@ -489,12 +601,12 @@ __global__ void __launch_bounds__(256, QB == 1 ? 3 : 2) seer_attn40_kernel(const
     };
 
     if constexpr (TRACK_ONLY) {
-        run(BoolTag<true>{});
+        run(BoolTag<true>{}, true);
     } else {
-        run(BoolTag<false>{});
+        run(BoolTag<false>{}, true);
         // a score more than 2^127 above the reference taken from the first 32 keys: exp2 overflowed.  The workgroup shares
         // the K / V stream, so it re-runs as a whole, with the tracked reference.
-        if (__syncthreads_or(!accumulators_finite())) run(BoolTag<true>{});
+        if (__syncthreads_or(!accumulators_finite())) run(BoolTag<true>{}, false);
     }
 
     A40_STAMP();
@@ -531,6 +643,7 @@ __global__ void __launch_bounds__(256, QB == 1 ? 3 : 2) seer_attn40_kernel(const
             *reinterpret_cast<u32x4*>(Og + (int64_t)tok(qi) * p.o_ss + c * 8) = v;
         }
     }
+    A40_STAMP();
 }
 
 }  // namespace
@@ -555,6 +668,16 @@ int seer_attn40_launch(const seer_attn_desc& d, int ws_log2, hipStream_t st) {
     // (profiles/r03_lab_attn_qb2.log).  Taken by non-causal launches that fill at least one round of the 512 resident workgroups;
     // variant 2 forces it, variant 3 the 32-query form (A/B runs, tests)
     const int nqb2 = (d.Sq + 255) / 256;
+    // the 64-query form on a three-stage ring: whole tiles only (RING_FAST).  [192, 1024, 40] 54.1 -> 50.6 us, [192, 4096, 40]
+    // 583 -> 566 us back to back (profiles/r05_attn40_ring.log); variant 7 forces it, variant 2 keeps the two-stage form (A/B runs)
+    const bool ring_ok = plain && d.Sq % 256 == 0 && d.Sk % A40_KT == 0;
+    if (d.variant == 7 && (track || !ring_ok)) return SEER_EINVAL;
+    if (!track && ring_ok && (d.variant == 7 || (d.variant == 0 && (long)nqb2 * nbatch * d.heads >= 512))) {
+        dim3 grid7((unsigned)(nqb2 * nbatch * d.heads));
+        hipLaunchKernelGGL((seer_attn40_kernel<2, false, true, 3>), grid7, dim3(256), 0, st, d, ws_log2, nqb2);
+        SEER_LAUNCH_CHECK();
+        return SEER_OK;
+    }
     // (plain launches only: under a causal mask the 64-query wave does the work of its later query block for the earlier
     //  one too -- temporal window block 47 vs 36 us)
     if (!track && (d.variant == 2 || (d.variant == 0 && plain && (long)nqb2 * nbatch * d.heads >= 512))) {

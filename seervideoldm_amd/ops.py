@@ -64,10 +64,11 @@ class ColSumsFx:
     """Column sums ACCUMULATED per batch element in 64-bit fixed point (seer_gemm_desc::colsum_fx): buf [reps, batch, 2, C] int64
     out of an FxArena (planes: sum, sum of squares at scale 2^20; the replicas are added by the reader).  groupnorm_apply_fx
     normalises with them in one launch."""
-    __slots__ = ("buf", "C")
+    __slots__ = ("buf", "C", "reduced")
 
     def __init__(self, buf: torch.Tensor, C_: int):
         self.buf, self.C = buf, C_
+        self.reduced = False        # frame shards: the sums of all shards have been added in (parallel.FrameShard.reduce_fx)
 
     @property
     def reps(self) -> int:

@@ -7,7 +7,9 @@ axis of the per-step UNet:
   * batch groups first: the CFG-doubled batch B = 2b splits with ZERO per-layer communication (uc half / c half);
   * frame shards inside a batch group: each rank keeps F/P frames of every activation.  Per-frame work (convs, spatial
     and text attention, LayerNorm, FF) stays local.  Two exchanges are REQUIRED for parity (SURVEY finding 3, 8(e)):
-      - every GroupNorm spans all frames -> all-reduce of the (sum, sumsq) statistics, B_local*32*2 floats, 77 per step;
+      - every GroupNorm spans all frames -> all-reduce of its (sum, sumsq) statistics, 77 per step: the producers' accumulated
+        fixed-point column sums (int64 [B_local, 2, C]: exact, order-free) where the producer leaves them, B_local*32*2 floats
+        otherwise;
       - temporal attention is causal over frames -> all-gather of the (rotary-applied) K|V of the frame group, 16 per step;
         the local queries then attend with `causal_offset` = sequence position of their first frame.
   * the epsilon prediction [B,4,F,h,w] (tiny) is all-gathered so every rank runs the same DDIM update.
@@ -131,6 +133,28 @@ class FrameShard:
         if self.P > 1:
             grp = self.frame_group()
             run(lambda: dist.all_reduce(stats, group=grp))
+        elif self.debug_boundaries:
+            run(lambda: None)
+        return count_local / self.local_frames * self.total_frames
+
+    def reduce_fx(self, sums, count_local: float, sync=None) -> float:
+        """all-reduce the ACCUMULATED fixed-point column sums (ops.ColSumsFx, int64) of a GroupNorm's sources over the frame
+        group -- integer addition is exact and order-free, so every shard normalises with bit for bit the statistics the
+        unsharded step computes from the same activations, and the apply launch reads them directly: no finalize launch, no fp32
+        statistics tensor.  A producer's sums are exchanged once (an output that feeds two GroupNorms keeps the totals).
+        Shards may hold different replica counts (uneven frame counts pick different tiles): replicas are folded first, so every
+        rank sends [1, B, 2, C]."""
+        run = sync if sync is not None else (lambda fn: fn())
+        if self.P > 1:
+            grp = self.frame_group()
+            for cs in sums:
+                if cs is None or cs.reduced:
+                    continue
+                if cs.buf.shape[0] > 1:
+                    cs.buf = cs.buf.sum(dim=0, keepdim=True)
+                buf = cs.buf
+                run(lambda buf=buf: dist.all_reduce(buf, group=grp))
+                cs.reduced = True
         elif self.debug_boundaries:
             run(lambda: None)
         return count_local / self.local_frames * self.total_frames

@@ -343,9 +343,15 @@ class _Engine:
         cs2 = getattr(x2, "colsums", None) if x2 is not None else None
         C = x1.shape[1] + (0 if x2 is None else x2.shape[1])
         FX = getattr(ops, "ColSumsFx", ())
+        exchanged = False
         if isinstance(cs1, FX) or isinstance(cs2, FX):
             if isinstance(cs1, FX) and (x2 is None or isinstance(cs2, FX)):
-                y = ops.groupnorm_apply_fx(x1, x2, cs1, cs2, B, self.G, rows_pb * (C // self.G), eps,
+                count = rows_pb * (C // self.G)
+                if self.shard is not None:
+                    # frame shards: the integer sums of all shards are added in place (exact: the statistics are the unsharded ones)
+                    count = self.shard.reduce_fx((cs1, cs2), count, sync=self.sync_point)
+                    exchanged = True
+                y = ops.groupnorm_apply_fx(x1, x2, cs1, cs2, B, self.G, count, eps,
                                            self.w[name + ".weight"], self.w[name + ".bias"], silu)
                 self.gn_from_colsums += 1
                 if y is not None:
@@ -368,7 +374,10 @@ class _Engine:
             ops.groupnorm_stats(x1, x2, B, self.G, stats)
         count = rows_pb * (C // self.G)
         if self.shard is not None:
-            count = self.shard.reduce_gn_stats(stats, count, sync=self.sync_point)
+            if exchanged:           # the statistics above came from sums that already hold every shard's share
+                count = count / self.shard.local_frames * self.shard.total_frames
+            else:
+                count = self.shard.reduce_gn_stats(stats, count, sync=self.sync_point)
         return ops.groupnorm_apply(x1, x2, B, self.G, stats, count, eps, self.w[name + ".weight"],
                                    self.w[name + ".bias"], silu)
 
@@ -548,7 +557,7 @@ class _Engine:
         # level (config 2: 24 576 rows -0.19 ms; 64x64 latent, 98 304 rows: even; bridge, 131 072 rows: +0.15 ms --
         # profiles/r04_fx_ln_other_configs.log), off above
         small = B * Fr * H * W <= FX_MAX_ROWS
-        fx_gn = self.gn_fx and self.gn_colsums and self.shard is None      # (per tensor: _cb)
+        fx_gn = self.gn_fx and self.gn_colsums      # (per tensor: _cb; frame shards all-reduce the integer sums: FrameShard.reduce_fx)
         self._ln_on = self.ln_fold and small
         if (fx_gn or self._ln_on) and hasattr(ops, "FxArena"):
             # fixed-point accumulators of the evaluation: a [reps, B, 2, C] slot per colsum producer, a [rows, 2] slot per producer

@@ -465,16 +465,24 @@ def _rel_l2(got, ref):
     return ((got - ref).norm() / ref.norm().clamp_min(1e-30)).item()
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 5])
+@pytest.mark.parametrize("variant", [1, 2, 3, 5, 7])
 @pytest.mark.parametrize("Sq,Sk,causal", [(1024, 1024, False), (768, 768, True), (1000, 930, False), (333, 333, True),
-                                           (130, 2049, False), (64, 256, False),
+                                           (130, 2049, False), (64, 256, False), (256, 128, False), (512, 1152, False),
                                            (4096, 4096, False)])      # BASELINE config 4: spatial attention of a 64x64 latent
 def test_attention_d40_kernels(device, variant, Sq, Sk, causal):
-    """head_dim 40: the generic kernel (variant 1), the d = 40 kernel's fast path (3; 2 = its 64-queries-per-wave shape) and its tracked form (5) against the
-    fp32 formula (xformers MEA as called at attention.py:622-630)"""
+    """head_dim 40: the generic kernel (variant 1), the d = 40 kernel's fast path (3; 2 = its 64-queries-per-wave shape; 7 = that shape
+    on the three-stage K|V ring, whole tiles only: one, nine and many tiles) and its tracked form (5) against the fp32 formula
+    (xformers MEA as called at attention.py:622-630)"""
     from seervideoldm_amd import ops
+    from seervideoldm_amd._lib import SeerHipError
     B, Hh, d = 2, 8, 40
     C = Hh * d
+    if variant == 7 and (causal or Sq % 256 or Sk % 128):
+        x = torch.zeros((B * max(Sq, Sk), C), device=device, dtype=bf16)
+        with pytest.raises(SeerHipError):        # the ring form refuses what it cannot run instead of running something else
+            ops.attention(x[:B * Sq], x[:B * Sk], x[:B * Sk], torch.zeros((B * Sq, C), device=device, dtype=bf16), batch=B, heads=Hh,
+                          head_dim=d, Sq=Sq, Sk=Sk, causal=causal, causal_offset=(Sk - Sq if causal else 0), variant=7)
+        return
     q = _rand((B, Sq, Hh, d), device, 1).to(bf16)
     k = _rand((B, Sk, Hh, d), device, 2).to(bf16)
     v = _rand((B, Sk, Hh, d), device, 3).to(bf16)
@@ -490,7 +498,7 @@ def test_attention_d40_kernels(device, variant, Sq, Sk, causal):
     _close(out, ref, rtol=2e-2, atol=1e-2, what=f"d40 variant {variant} {Sq}x{Sk} causal={causal}")
 
 
-@pytest.mark.parametrize("d,variant", [(40, 1), (40, 2), (40, 3), (40, 5), (80, 0), (96, 0), (160, 0)])
+@pytest.mark.parametrize("d,variant", [(40, 1), (40, 2), (40, 3), (40, 5), (40, 7), (80, 0), (96, 0), (160, 0)])
 @pytest.mark.parametrize("amp", [3.0, 6.0])
 def test_attention_sharp_softmax(device, d, variant, amp):
     """scores hundreds of log2 units apart (cdna guide, rule 26: the rare branch needs its own test).  This is the case that
