@@ -321,6 +321,13 @@ int seer_groupnorm_apply_from_colsums(const void* x1, int32_t C1, const void* x2
 int seer_groupnorm_apply_fx(const void* x1, int32_t C1, const void* x2, int32_t C2, const int64_t* fx1, int32_t reps1,
                             const int64_t* fx2, int32_t reps2, int32_t batch, int64_t rows_per_batch, int32_t groups, double count, float eps, const float* gamma,
                             const float* beta, int32_t silu, void* y, float* stats_out, void* stream);
+/* The same accumulated sums from the ACTIVATIONS: fx [batch][2][C] int64 (one replica; ADDED to: zero it first) receives
+ * sum_r round(x[r][c] * 2^20) and sum_r round(x[r][c]^2 * 2^20) over the rows of each batch element.  Every element is rounded on
+ * its own, so the totals are exact integer sums: independent of the order of the additions and -- frame shards -- of which rank
+ * held which rows (an int64 all-reduce of the shards' sums IS the unsharded result).  The statistics pass of a frame-sharded step
+ * for GroupNorm sources without accumulated producer sums (resnet.py:179,197, attention.py:133 normalise over all frames). */
+int seer_groupnorm_stats_fx(const void* x, int32_t C, int32_t batch, int64_t rows_per_batch, int64_t* fx, int32_t dtype,
+                            void* stream);
 /* the same two with the storage type of x1 / x2 / y chosen by `dtype` (SEER_DT_*): the VAE's nn.GroupNorm(32, eps 1e-6)
  * (ldm/modules/diffusionmodules/model.py:38-40) on fp16 activations */
 int seer_groupnorm_stats_dt(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t batch,

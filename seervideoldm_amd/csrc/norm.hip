@@ -697,6 +697,77 @@ extern "C" int seer_groupnorm_apply_fx(const void* x1, int32_t C1, const void* x
     return SEER_OK;
 }
 
+// (sum, sum of squares) per (batch element, column) in the 64-bit fixed point of seer_gemm_desc::colsum_fx, from the activations:
+// every ELEMENT is rounded on its own (v * 2^20 and v * v * 2^20: a bf16 value and the fp32 product of two are exact, the rounding
+// only cuts what lies below 2^-21), so the totals are sums of integers -- exact, independent of the order of the additions, of the
+// block decomposition and, across frame shards, of which rank held which rows.  The statistics pass of a frame-sharded step for
+// the GroupNorm sources whose producer leaves no accumulated sums (conv_in's output; tensors above the producers' row limit).
+namespace {
+template <bool F16>
+__global__ void __launch_bounds__(256) gn_stats_fx_kernel(const bf16* __restrict__ x, int C, int64_t rows_per_batch, int rows_per_block,
+                                                          long long* __restrict__ fx) {
+    __shared__ long long part[4][64][16];                // [row lane][column chunk][8 sums | 8 sums of squares]
+    const int tid = threadIdx.x, cl = tid & 63, rl = tid >> 6;
+    const int b = blockIdx.z;
+    const int cq = blockIdx.x * 64 + cl;                 // 8-column chunk
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    r1 = r1 < rows_per_batch ? r1 : rows_per_batch;
+    long long sm[8], sq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sm[j] = sq[j] = 0;
+    if (cq * 8 < C) {
+        const bf16* base = x + ((int64_t)b * rows_per_batch) * C + cq * 8;
+        for (int64_t r = r0 + rl; r < r1; r += 4) {
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(base + r * C);
+            float f[8];
+            if constexpr (F16) unpack8t<true>(raw, f); else unpack8(raw, f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                sm[j] += __float2ll_rn(f[j] * (float)(1 << SEER_GN_FX_SHIFT));
+                sq[j] += __float2ll_rn(f[j] * f[j] * (float)(1 << SEER_GN_FX_SHIFT));
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        part[rl][cl][j] = sm[j];
+        part[rl][cl][8 + j] = sq[j];
+    }
+    __syncthreads();
+    // thread t < 64 * 4: column chunk cl, quarter rl of its 16 totals -> 4 atomic adds each
+    if (cq * 8 < C) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = rl * 4 + k;                    // 0..15: 0..7 sums, 8..15 sums of squares
+            const long long v = part[0][cl][e] + part[1][cl][e] + part[2][cl][e] + part[3][cl][e];
+            long long* dst = fx + ((int64_t)(b * 2 + (e >> 3))) * C + cq * 8 + (e & 7);
+            if (v) atomicAdd(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)v);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int seer_groupnorm_stats_fx(const void* x, int32_t C, int32_t batch, int64_t rows_per_batch, int64_t* fx, int32_t dtype,
+                                       void* stream) {
+    if (!x || !fx || C <= 0 || C % 8 || batch <= 0 || rows_per_batch <= 0) return SEER_EINVAL;
+    if (dtype != SEER_DT_BF16 && dtype != SEER_DT_F16) return SEER_EINVAL;
+    // ~2 blocks per CU at least, at most 64 adds per address
+    int rpb = 256;
+    while (rpb > 16 && (int64_t)batch * ((rows_per_batch + rpb - 1) / rpb) * ((C / 8 + 63) / 64) < 512) rpb >>= 1;
+    while ((rows_per_batch + rpb - 1) / rpb > 64) rpb <<= 1;
+    dim3 grid((unsigned)((C / 8 + 63) / 64), (unsigned)((rows_per_batch + rpb - 1) / rpb), (unsigned)batch);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == SEER_DT_F16)
+        hipLaunchKernelGGL(gn_stats_fx_kernel<true>, grid, dim3(256), 0, st, reinterpret_cast<const bf16*>(x), C, rows_per_batch, rpb,
+                           reinterpret_cast<long long*>(fx));
+    else
+        hipLaunchKernelGGL(gn_stats_fx_kernel<false>, grid, dim3(256), 0, st, reinterpret_cast<const bf16*>(x), C, rows_per_batch, rpb,
+                           reinterpret_cast<long long*>(fx));
+    SEER_LAUNCH_CHECK();
+    return SEER_OK;
+}
+
 extern "C" int seer_layernorm(const void* x, int64_t rows, int32_t C, int32_t ldx, const float* gamma,
                               const float* beta, float eps, void* y, int32_t ldy, void* stream) {
     if (!x || !y || !gamma || !beta || rows <= 0 || C <= 0 || C % 8 || ldx % 8 || ldy % 8) return SEER_EINVAL;

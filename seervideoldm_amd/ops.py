@@ -561,6 +561,20 @@ def groupnorm_apply_fx(x1: torch.Tensor, x2: Optional[torch.Tensor], fx1: ColSum
     return out
 
 
+def groupnorm_stats_fx(x: torch.Tensor, batch: int, arena: Optional[FxArena] = None) -> ColSumsFx:
+    """accumulated fixed-point (sum, sum of squares) per (batch element, column) FROM THE ACTIVATIONS x [batch * rows, C]: exact
+    integer sums (every element rounded on its own), so shards of the rows can be added in any order.  The slot comes out of
+    `arena` (zeroed at the head of the evaluation) or is a fresh zeroed tensor."""
+    dt = _req16(x, "x")
+    assert x.dim() == 2 and x.is_contiguous() and x.shape[0] % batch == 0
+    C_ = x.shape[1]
+    buf = arena.take(1, batch, C_) if arena is not None else None
+    if buf is None:
+        buf = torch.zeros((1, batch, 2, C_), device=x.device, dtype=torch.int64)
+    check(_lib.load().seer_groupnorm_stats_fx(_p(x), C_, batch, x.shape[0] // batch, _p(buf), dt, _stream()), "seer_groupnorm_stats_fx")
+    return ColSumsFx(buf, C_)
+
+
 def groupnorm_stats_from_fx(fx1: ColSumsFx, fx2: Optional[ColSumsFx], batch: int, groups: int, stats: torch.Tensor) -> torch.Tensor:
     """stats[b][g] = (sum, sumsq) from accumulated column sums (torch ops; the fall-back of a layout groupnorm_apply_fx refuses)."""
     v = fx1.totals() if fx2 is None else torch.cat([fx1.totals(), fx2.totals()], dim=1)

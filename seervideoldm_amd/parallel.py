@@ -44,6 +44,7 @@ class FrameShard:
         self.world, self.rank = world, rank
         self.forced_G = batch_groups
         self._pgs = {}
+        self._xbuf = {}                 # static K|V exchange buffers (_gather_frames)
         self._probed = set()
         self.G = self.P = None
         self.total_frames = self.frame_offset = self.local_frames = 0
@@ -175,14 +176,26 @@ class FrameShard:
         rows_l = self.local_frames * rows_per_frame
         even = all(c == fmax for c in self.frame_counts)
         grp = self.frame_group()
-        out = torch.empty((B * self.total_frames * rows_per_frame, C), device=x.device, dtype=x.dtype)
+        # exchange buffers: one set per (site shape) for the life of the partition -- no allocation per call outside a capture
+        # (inside one the graph's pool owns them anyway, and buffers of an eager run must not be baked into a graph)
+        capturing = x.is_cuda and torch.cuda.is_current_stream_capturing()
+        key = (self.G, self.P, B, rows_per_frame, C, x.dtype, x.device)
+        bufs = None if capturing else self._xbuf.get(key)
+        if bufs is None:
+            out = torch.empty((B * self.total_frames * rows_per_frame, C), device=x.device, dtype=x.dtype)
+            send = recv = None
+            if not (even and B == 1):
+                send = torch.zeros((B, fmax * rows_per_frame, C), device=x.device, dtype=x.dtype)
+                recv = [torch.empty_like(send) for _ in range(self.P)]
+            bufs = (out, send, recv)
+            if not capturing:
+                self._xbuf[key] = bufs
+        out, send, recv = bufs
         if even and B == 1:
             # [P][F_l*rows, C] in rank order IS the global frame order: gather straight into the output
             run(lambda: dist.all_gather_into_tensor(out, x, group=grp))
             return out
-        send = torch.zeros((B, fmax * rows_per_frame, C), device=x.device, dtype=x.dtype)
         send[:, :rows_l] = x.reshape(B, rows_l, C)
-        recv = [torch.empty_like(send) for _ in range(self.P)]
         outv = out.reshape(B, self.total_frames * rows_per_frame, C)
         starts, counts = self.frame_starts, self.frame_counts
 

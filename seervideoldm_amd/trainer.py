@@ -477,7 +477,8 @@ class SeerTrainer:
         if getattr(self, "gn_fx", os.environ.get("SEER_GN_FX", "1") != "0") and hasattr(ops, "FxArena"):
             need = (eng.n_groupnorms() + 16) * B * 4 * max(boc) * 2
             if getattr(self, "_fx_arena", None) is None or self._fx_arena.buf.numel() < need:
-                assert not torch.cuda.is_current_stream_capturing(), "the accumulator arena must exist before a graph capture"
+                assert not (sample.is_cuda and torch.cuda.is_current_stream_capturing()), \
+                    "the accumulator arena must exist before a graph capture"
                 if getattr(self, "_fx_arena", None) is not None:
                     self._fx_retired = getattr(self, "_fx_retired", []) + [self._fx_arena]     # captured steps keep theirs by address
                 self._fx_arena = ops.FxArena(sample.device, need)

@@ -343,6 +343,14 @@ class _Engine:
         cs2 = getattr(x2, "colsums", None) if x2 is not None else None
         C = x1.shape[1] + (0 if x2 is None else x2.shape[1])
         FX = getattr(ops, "ColSumsFx", ())
+        if self.shard is not None and self._fx is not None and hasattr(ops, "groupnorm_stats_fx"):
+            # frame shards: EVERY GroupNorm normalises with exact integer statistics -- a source whose producer left no
+            # accumulated sums (conv_in's output, tensors above the producers' row limit) gets them from one pass over its rows;
+            # the sums stay with the tensor (a skip connection feeds a second GroupNorm with the totals already exchanged)
+            if not isinstance(cs1, FX):
+                cs1 = x1.colsums = ops.groupnorm_stats_fx(x1, B, self._fx)
+            if x2 is not None and not isinstance(cs2, FX):
+                cs2 = x2.colsums = ops.groupnorm_stats_fx(x2, B, self._fx)
         exchanged = False
         if isinstance(cs1, FX) or isinstance(cs2, FX):
             if isinstance(cs1, FX) and (x2 is None or isinstance(cs2, FX)):
@@ -564,7 +572,8 @@ class _Engine:
             # of LayerNorm rows; reset() = one fill over what the last evaluation took
             need = (self.n_groupnorms() + 16) * B * 4 * max(boc) * 2 + 5 * 16 * B * Fr * H * W * 2
             if self._fx_arena is None or self._fx_arena.buf.numel() < need:
-                assert not torch.cuda.is_current_stream_capturing(), "the accumulator arena must exist before a graph capture"
+                assert not (sample.is_cuda and torch.cuda.is_current_stream_capturing()), \
+                    "the accumulator arena must exist before a graph capture"
                 if self._fx_arena is not None:
                     self._fx_retired.append(self._fx_arena)     # captured steps of smaller shapes keep adding into theirs by address
                 self._fx_arena = ops.FxArena(sample.device, need)

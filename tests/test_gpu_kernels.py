@@ -1141,3 +1141,37 @@ def test_layernorm_folded_into_gemm(device, C, M, kind, ptile, ctile):
         assert e_fold <= 1.5 * e_two + 1e-4, (e_fold, e_two)
     again = ops.gemm(x, wf, bias=bf, ln=(x.rowstats, wsum, 1e-5), tile=ctile, **kw)
     assert torch.equal(got, again)
+
+
+@pytest.mark.parametrize("C,rows,B", [(320, 3072, 2), (640, 768, 1), (1280, 192, 2), (2560, 48, 1), (320, 12288, 1), (72, 100, 3)])
+def test_groupnorm_stats_fx_is_exact_and_shard_invariant(device, C, rows, B):
+    """seer_groupnorm_stats_fx: the accumulated fixed-point (sum, sum of squares) per (batch element, column) from the activations.
+    Every element is rounded on its own, so the totals are integer sums: EQUAL to the torch int64 reference, independent of the block
+    decomposition, and the sums of two row shards (what frame-sharded ranks all-reduce) ARE the unsharded sums -- and
+    seer_groupnorm_apply_fx normalises identically from either (resnet.py:179,197: GroupNorm statistics span all frames)."""
+    from seervideoldm_amd import ops
+    x = (_rand((B * rows, C), device, 5) * 3 + 0.7).to(bf16)
+    fx = ops.groupnorm_stats_fx(x, B)
+    v = x.float().reshape(B, rows, C)
+    ref = torch.stack([torch.round(v * 2.0 ** 20).to(torch.int64).sum(1), torch.round(v * v * 2.0 ** 20).to(torch.int64).sum(1)], 1)
+    assert torch.equal(fx.buf[0], ref)
+    assert torch.equal(ops.groupnorm_stats_fx(x, B).buf, fx.buf)
+    # two "frame shards" of every batch element, uneven
+    cut = (rows * 2 // 3) // 4 * 4 or rows // 2
+    xs = x.reshape(B, rows, C)
+    a, b = xs[:, :cut].reshape(-1, C).contiguous(), xs[:, cut:].reshape(-1, C).contiguous()
+    fa, fb = ops.groupnorm_stats_fx(a, B), ops.groupnorm_stats_fx(b, B)
+    assert torch.equal(fa.buf + fb.buf, fx.buf)
+    if C % 32 == 0 and C >= 320:
+        G = 32
+        gamma, beta = _rand((C,), device, 21) + 1.0, _rand((C,), device, 22)
+        count = rows * (C // G)
+        y_full = ops.groupnorm_apply_fx(x, None, fx, None, B, G, count, 1e-5, gamma, beta, True)
+        assert y_full is not None
+        tot = ops.ColSumsFx(fa.buf + fb.buf, C)
+        y_a = ops.groupnorm_apply_fx(a, None, tot, None, B, G, count, 1e-5, gamma, beta, True)
+        y_b = ops.groupnorm_apply_fx(b, None, tot, None, B, G, count, 1e-5, gamma, beta, True)
+        got = torch.cat([y_a.reshape(B, cut, C), y_b.reshape(B, rows - cut, C)], 1).reshape(-1, C)
+        assert torch.equal(got, y_full), "a shard normalises its rows exactly as the unsharded launch does"
+        refy = Fn.silu(Fn.group_norm(v.permute(0, 2, 1), G, gamma, beta, 1e-5)).permute(0, 2, 1).reshape(-1, C)
+        _close(y_full, refy, rtol=1e-2, atol=1e-2, what=f"groupnorm from exact sums C {C}")

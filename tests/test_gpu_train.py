@@ -44,7 +44,9 @@ def _compare(tr, gu, gf, tol, worst_tol):
         assert w < worst_tol, (name, w)
 
 
-@pytest.mark.parametrize("cfg,B,Fr,cond,H", [(CFG_MINI, 1, 3, 1, 16), (CFG_MINI, 2, 4, 2, 8), (CFG_WIDE, 1, 4, 2, 32)])
+# (width 320 at a 32x32 latent = the ws = 8 window regime at d = 40; the real widths -- head dims 40 / 80 / 160 -- at 16x16: the fp32
+#  autograd of the oracle at the real widths AND 32x32 cost 64 s of host time per run; the full-size step has its own properties test)
+@pytest.mark.parametrize("cfg,B,Fr,cond,H", [(CFG_MINI, 1, 3, 1, 16), (CFG_MINI, 2, 4, 2, 8), (CFG_MINI, 1, 3, 1, 32), (CFG_WIDE, 1, 4, 2, 16)])
 def test_train_step_matches_oracle(device, cfg, B, Fr, cond, H):
     usd, fsd, unet, fst = _models(cfg, device)
     fst.set_numframe(Fr)

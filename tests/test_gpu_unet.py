@@ -96,7 +96,7 @@ def _model(cfg_name, device):
 @pytest.mark.parametrize("cfg_name,B,Fr,H,cond_frame", [
     ("mini", 2, 3, 32, 0),      # window regimes ws=8 (32), ws=4 (16, 8), un-windowed mid (4)
     ("mini", 1, 4, 16, 2),      # cond_frame > 0: temporal FF skips the conditioning frames
-    ("wide", 2, 2, 16, 0),      # head dims 40 / 80 / 160, un-windowed at 4 and 2
+    ("wide", 1, 2, 16, 0),      # head dims 40 / 80 / 160, un-windowed at 4 and 2
     # (BASELINE config 4's regimes -- 64x64 latent -- are pinned to the reference itself: test_config4_regimes_against_the_reference)
 ])
 def test_unet_forward_matches_oracle(device, cfg_name, B, Fr, H, cond_frame):
@@ -128,19 +128,15 @@ def test_segmented_graph_replay(device):
     x = _randn((2, 4, 3, 16, 16), 11).to(device)
     ctx = _randn((2, 3, 77, cfg["cross_attention_dim"]), 12).to(device)
     t = torch.tensor([301, 301], device=device)
-    # (sharded engines take GroupNorm statistics from column sums like this one -- in the two-launch form: the statistics are
-    #  all-reduced between the launches; the reference engine is built the same way so that the comparison stays bit for bit)
-    m._engine = None
-    m.gn_fused = False
-    m.gn_fx = False
-    try:
-        ref = m(x, t, ctx).clone()
-    finally:
-        del m.gn_fused, m.gn_fx
-        m._engine = None
+    # (sharded engines normalise every GroupNorm with exact integer statistics -- accumulated by the producers or taken by
+    #  seer_groupnorm_stats_fx, exchanged as int64 -- so the reference is the SAME engine launched eagerly: the comparison stays bit
+    #  for bit, and the plain engine is compared to the calibrated tolerance)
+    plain = m(x, t, ctx).clone()
     shard = parallel.attach(m, 1, 0)
     shard.debug_boundaries = True
     try:
+        ref = m(x, t, ctx).clone()
+        _check(ref, plain.cpu(), "one-rank sharded engine (exact statistics) vs the plain engine")
         m.use_graph = True
         g1 = m(x, t, ctx).clone()
         g2 = m(x, t, ctx).clone()

@@ -15,6 +15,33 @@ import torch.nn.functional as F
 
 bf16 = torch.bfloat16
 
+# host-side containers of the product (pure torch, no kernel behind them): the accumulated fixed-point column sums and their arena
+from seervideoldm_amd.ops import ColSumsFx, FxArena, groupnorm_stats_from_fx  # noqa: E402,F401
+
+# EXACT = True: every contraction accumulates in float64 (then rounds once to fp32), so a row's result does not depend on how many
+# OTHER rows the call holds -- what the sharded-vs-unsharded tests need to compare bit for bit (an fp32 BLAS blocks by shape)
+EXACT = False
+FX_SCALE = float(1 << 20)
+
+
+def _mm(a, bt):
+    return (a.double() @ bt.double()).float() if EXACT else a @ bt
+
+
+def _fx_sums(res, colsum_batch):
+    """ColSumsFx of a stored output for colsum_batch = (B, arena): every element rounded on its own, as
+    seer_groupnorm_stats_fx does (the MFMA producers round per tile partial: the same statistics to 2^-21 per partial)"""
+    if not isinstance(colsum_batch, tuple):
+        return None
+    B, arena = colsum_batch
+    v = res.float().reshape(B, -1, res.shape[1])
+    buf = arena.take(1, B, res.shape[1]) if arena is not None else None
+    if buf is None:
+        buf = torch.zeros((1, B, 2, res.shape[1]), dtype=torch.int64)
+    buf[0, :, 0] += torch.round(v * FX_SCALE).to(torch.int64).sum(1)
+    buf[0, :, 1] += torch.round(v * v * FX_SCALE).to(torch.int64).sum(1)
+    return ColSumsFx(buf, res.shape[1])
+
 
 def _deinterleave_geglu(acc):
     M, N = acc.shape
@@ -57,7 +84,7 @@ def gemm(a, w, *, bias=None, residual=None, rowvec=None, rows_per_batch=0, a2=No
          out_f32=False, out=None, tile=0, splits=0, rotary=None, col_scale=None, colsum_batch=0, rowstat=False, ln=None):
     A = a.float() if a2 is None else torch.cat([a.float(), a2.float()], 1)
     assert A.shape[1] % 64 == 0 and w.dtype == bf16 and a.dtype == bf16
-    acc = A @ w.float().t()
+    acc = _mm(A, w.float().t())
     if ln is not None:
         # seer_gemm_desc::ln_rowstat: rstd * (x W'^T - mean * wsum), the term the kernel applies before everything else
         rs, wsum, eps = ln
@@ -67,6 +94,7 @@ def gemm(a, w, *, bias=None, residual=None, rowvec=None, rows_per_batch=0, a2=No
         rstd = torch.rsqrt(var.clamp_min(0) + eps)
         acc = acc * rstd[:, None] - (mean * rstd)[:, None] * wsum[None, :]
     res = _gemm_tail(acc, bias, residual, rowvec, rows_per_batch, geglu, silu, out_f32, out, rotary, col_scale)
+    res.colsums = _fx_sums(res, colsum_batch)
     if rowstat:
         v = res.double()
         res.rowstats = RowStats(torch.stack([v.sum(1), (v * v).sum(1)], 1))
@@ -114,8 +142,13 @@ def conv3x3(x, w, n_img, Hin, Win, *, stride=1, upsample=False, bias=None, resid
     if upsample:
         xi = F.interpolate(xi, scale_factor=2.0, mode="nearest")
     wt = w.float().reshape(Co, 3, 3, Ci).permute(0, 3, 1, 2)
-    y = F.conv2d(xi, wt, None, stride=stride, padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
-    return _epilogue(y, bias, False, rowvec, rows_per_batch, False, residual, False, out)
+    if EXACT:
+        y = F.conv2d(xi.double(), wt.double(), None, stride=stride, padding=1).float().permute(0, 2, 3, 1).reshape(-1, Co)
+    else:
+        y = F.conv2d(xi, wt, None, stride=stride, padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
+    res = _epilogue(y, bias, False, rowvec, rows_per_batch, False, residual, False, out)
+    res.colsums = _fx_sums(res, colsum_batch)
+    return res
 
 
 def conv_up2x(x, w4, n_img, Hin, Win, *, bias=None, out=None, tile=0, colsum_batch=0):
@@ -130,9 +163,11 @@ def conv_up2x(x, w4, n_img, Hin, Win, *, bias=None, out=None, tile=0, colsum_bat
             for ty in range(2):
                 for tx in range(2):
                     src = xi[:, a + ty:a + ty + Hin, b + tx:b + tx + Win, :]        # source (y + a - 1 + ty, x + b - 1 + tx)
-                    acc = acc + src @ wf[a * 2 + b, :, ty, tx, :].t()
-            y[:, a::2, b::2, :] = acc
-    return _epilogue(y.reshape(-1, Co), bias, False, None, 0, False, None, False, out)
+                    acc = acc + (src.double() @ wf[a * 2 + b, :, ty, tx, :].t().double() if EXACT else src @ wf[a * 2 + b, :, ty, tx, :].t())
+            y[:, a::2, b::2, :] = acc.float() if EXACT else acc
+    res = _epilogue(y.reshape(-1, Co), bias, False, None, 0, False, None, False, out)
+    res.colsums = _fx_sums(res, colsum_batch)
+    return res
 
 
 LOG2E = 1.4426950408889634
@@ -184,12 +219,14 @@ def attention(q, k, v, out, *, batch, heads, head_dim, Sq, Sk, causal=False, sca
         qq = gat(q, iq, Fq).permute(1, 0, 3, 2, 4).reshape(-1, heads, Sq, head_dim)
         kk = gat(k, ik, Fr).permute(1, 0, 3, 2, 4).reshape(-1, heads, Sk, head_dim)
         vv = gat(v, ik, Fr).permute(1, 0, 3, 2, 4).reshape(-1, heads, Sk, head_dim)
+    if EXACT:
+        qq, kk, vv = qq.double(), kk.double(), vv.double()
     s = torch.einsum("bhqd,bhkd->bhqk", qq, kk) * scale
     if causal:
         i = torch.arange(Sq)[:, None] + causal_offset
         j = torch.arange(Sk)[None, :]
         s = s.masked_fill(~(j <= i), float("-inf"))
-    o = torch.einsum("bhqk,bhkd->bhqd", s.softmax(-1), vv)              # [nb, heads, Sq, d]
+    o = torch.einsum("bhqk,bhkd->bhqd", s.softmax(-1), vv).float()      # [nb, heads, Sq, d]
     if window is None:
         res = o.permute(0, 2, 1, 3).reshape(batch * Sq, C)
     else:
@@ -243,6 +280,29 @@ def groupnorm_apply(x1, x2, batch, groups, stats, count, eps, gamma, beta, silu,
     return y.to(bf16)
 
 
+def groupnorm_stats_fx(x, batch, arena=None):
+    """stand-in of ops.groupnorm_stats_fx (seer_groupnorm_stats_fx): exact per-element fixed-point sums from the activations"""
+    return _fx_sums(x, (batch, arena))
+
+
+def groupnorm_apply_fx(x1, x2, fx1, fx2, batch, groups, count, eps, gamma, beta, silu, out=None, stats_out=None):
+    """stand-in of seer_groupnorm_apply_fx: replicas and a group's channels added as integers, one conversion per group (double)"""
+    tot = fx1.buf.sum(0) if fx2 is None else torch.cat([fx1.buf.sum(0), fx2.buf.sum(0)], dim=2)      # [B, 2, C] int64
+    C = tot.shape[2]
+    g = tot.reshape(batch, 2, groups, C // groups).sum(3).double() / FX_SCALE                          # [B, 2, G]
+    mean = g[:, 0] / count
+    var = (g[:, 1] / count - mean * mean).clamp_min(0)
+    stats = torch.stack([mean.float(), torch.rsqrt(var.float() + eps)], -1)                              # (mean, rstd) per (b, g)
+    xc = x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], 1)
+    xg = xc.reshape(batch, -1, groups, C // groups)
+    y = ((xg - stats[:, None, :, None, 0]) * stats[:, None, :, None, 1]).reshape(-1, C) * gamma + beta
+    if silu:
+        y = F.silu(y)
+    if stats_out is not None:
+        stats_out.copy_(g.permute(0, 2, 1).float())
+    return y.to(bf16)
+
+
 def layernorm(x, gamma, beta, eps=1e-5, out=None):
     y = F.layer_norm(x.float(), (x.shape[1],), gamma, beta, eps).to(bf16)
     if out is not None:
@@ -264,7 +324,7 @@ def timestep_embedding(t, dim, flip_sin_to_cos, freq_shift):
 
 def linear_smallm(x, w, bias, *, silu_in=False, silu_out=False):
     xi = F.silu(x) if silu_in else x
-    y = xi @ w.float().t()
+    y = _mm(xi, w.float().t())
     if bias is not None:
         y = y + bias
     return F.silu(y) if silu_out else y
@@ -273,7 +333,8 @@ def linear_smallm(x, w, bias, *, silu_in=False, silu_out=False):
 def conv_in(x, w_khwc, bias):
     B, Cin, Fr, H, W = x.shape
     wt = w_khwc.permute(3, 2, 0, 1)
-    y = F.conv2d(x.permute(0, 2, 1, 3, 4).reshape(B * Fr, Cin, H, W), wt, bias, padding=1)
+    xi = x.permute(0, 2, 1, 3, 4).reshape(B * Fr, Cin, H, W)
+    y = F.conv2d(xi.double(), wt.double(), bias.double(), padding=1).float() if EXACT else F.conv2d(xi, wt, bias, padding=1)
     return y.permute(0, 2, 3, 1).reshape(-1, y.shape[1]).to(bf16)
 
 
@@ -282,7 +343,8 @@ def conv_out(x, w_ohwc, bias, B, Fr, H, W):
     if w_ohwc.dim() == 2:      # bf16 [Cout, 9*C0] in conv3x3 packing (the MFMA path of the HIP backend)
         w_ohwc = w_ohwc.float().reshape(w_ohwc.shape[0], 3, 3, C0)
     xi = x.float().reshape(B * Fr, H, W, C0).permute(0, 3, 1, 2)
-    y = F.conv2d(xi, w_ohwc.permute(0, 3, 1, 2), bias, padding=1)
+    wt = w_ohwc.permute(0, 3, 1, 2)
+    y = F.conv2d(xi.double(), wt.double(), bias.double(), padding=1).float() if EXACT else F.conv2d(xi, wt, bias, padding=1)
     return y.reshape(B, Fr, -1, H, W).permute(0, 2, 1, 3, 4).contiguous()
 
 
