@@ -109,7 +109,7 @@ int main(int argc, char** argv) {
         {"sharp spatial (amp 5)", 4, 1024, 1024, 0, 0, 0, 0, 0, 5.0f},
         {"spatial 64^2 [192,4096,40]", 24, 4096, 4096, 0, 0, 0, 0, 0, 1.0f},
     };
-    const int variants[] = {1, 2, 3, 4, 5, 7, 8, 9};
+    const int variants[] = {1, 2, 3, 4, 5, 7};
     const char* only = getenv("LAB_CASE");
     hipStream_t st;
     CK(hipStreamCreate(&st));

@@ -427,8 +427,8 @@ extern "C" int seer_attn_fwd(const seer_attn_desc* desc, void* stream) {
         if (d.H % d.window_ws || d.W % d.window_ws) return SEER_EINVAL;
         if (d.Fq <= 0 || d.Sq != d.Fq * d.window_ws * d.window_ws || d.Sk != d.F * d.window_ws * d.window_ws) return SEER_EINVAL;
     }
-    if (d.variant < 0 || d.variant > 9 || d.variant == 4) return SEER_EINVAL;
-    if ((d.variant == 2 || d.variant == 3 || d.variant == 5 || d.variant >= 7) && d.head_dim != 40) return SEER_EINVAL;
+    if (d.variant < 0 || d.variant > 7 || d.variant == 4) return SEER_EINVAL;
+    if ((d.variant == 2 || d.variant == 3 || d.variant == 5 || d.variant == 7) && d.head_dim != 40) return SEER_EINVAL;
     if (d.causal_offset < 0 || (d.causal && d.Sq + d.causal_offset > d.Sk)) return SEER_EINVAL;
     switch (d.head_dim) {
         case 40:

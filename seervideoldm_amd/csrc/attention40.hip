@@ -476,10 +476,21 @@ __global__ void __launch_bounds__(256, (QB == 1 && NST == 2) ? 3 : 2) seer_attn4
                     // two query blocks, software-pipelined: both score tiles are issued before the first exponentials, so the
                     // matrix pipe works on block 1's Q K^T under block 0's exponentials and on block 0's P V under block 1's
                     f32x16 s0 = qk(kf, 0);
+                    if constexpr (RING_FAST) {
+                        // behind block 0's score MFMAs: the next sub tile's K' reads and this wave's LDS-DMA piece, so that neither
+                        // stands between a barrier and the first MFMA of a sub tile
+                        if (sub < 3) {
+                            const unsigned kpn = kst + 32 * A40_ROWB + k_off;
+                            lds_prefetch_k(kpn, lh ? ZONE : kpn + 64, knext);
+                        }
+                        ring_pieces(sub);
+                    }
                     f32x16 s1 = qk(kf, 1);
-                    if (kb + 31 >= p.Sk) {
-                        mask_scores(s0, kb, 0);
-                        mask_scores(s1, kb, 1);
+                    if constexpr (!RING_FAST) {       // (whole tiles only on the ring: no key is ever masked there -- hipcc turns this
+                        if (kb + 31 >= p.Sk) {        //  branch into 32 v_cndmask per sub tile, executed every time)
+                            mask_scores(s0, kb, 0);
+                            mask_scores(s1, kb, 1);
+                        }
                     }
                     auto exp_pack = [&](const f32x16& sc, u32x4 (&pk)[2]) {
 #pragma unroll
@@ -498,16 +509,9 @@ __global__ void __launch_bounds__(256, (QB == 1 && NST == 2) ? 3 : 2) seer_attn4
                         }
                     };
                     u32x4 pk0[2], pk1[2];
-                    if constexpr (NST == 3) {
-                        // behind the six score MFMAs (192 cycles of the matrix pipe): the next sub tile's K' reads and this wave's
-                        // LDS-DMA piece, so that neither stands between a barrier and the first MFMA of a sub tile
-                        if (sub < 3) {
-                            const unsigned kpn = kst + 32 * A40_ROWB + k_off;
-                            lds_prefetch_k(kpn, lh ? ZONE : kpn + 64, knext);
-                        }
-                        ring_pieces(sub);
-                    }
                     exp_pack(s0, pk0);
+                    // (measured and dropped, profiles/r05_attn40_ring.log: block 0's exponentials scheduled into the gaps of block 1's three
+                    //  score MFMAs by sched_group_barrier -- [192,1024,40] 50.9 -> 52.3 us, [192,4096,40] 556 -> 570 us)
                     if constexpr (NST == 3) {
                         if (sub < 3) lds_wait_vk(vraw, knext, vf[0][0], vf[0][1], vf[1][0], vf[1][1]);
                         else lds_wait_v(vraw, vf[0][0], vf[0][1], vf[1][0], vf[1][1]);
