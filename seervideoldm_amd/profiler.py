@@ -142,6 +142,8 @@ class TimedOps:
                 return f"ff.net.0 GEGLU {lvl}"
             if "+res" in t and K == 4 * N:
                 return f"ff.net.2 +res {lvl}"
+            if "+res" in t and K == 5 * N:
+                return f"ff.net.2 | proj_out +res {lvl}"
             if N == 3 * K:
                 return f"q|k|v projection {lvl}"
             return f"projections / 1x1 {lvl}"

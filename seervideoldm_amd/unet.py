@@ -227,6 +227,8 @@ class _Engine:
             hasattr(self.ops, "fold_layernorm")       # (fold_ln=False: the trainer's engine -- its weights move, it runs its own forward)
         self.ln_folded = 0
         self._ln_on = False
+        # ff.net.2 and proj_out as one two-source GEMM (model.ff_fold = False / SEER_FF_FOLD=0: two launches; see _pack)
+        self.ff_fold = bool(getattr(model, "ff_fold", os.environ.get("SEER_FF_FOLD", "1") != "0"))
         self.gn_from_colsums = 0
         self.w: Dict[str, torch.Tensor] = {}
         self._pack(sd)
@@ -312,6 +314,23 @@ class _Engine:
                 p = k[: -len(".to_q.weight")]
                 w[p + ".q"] = b16(sd[p + ".to_q.weight"])
                 w[p + ".kv"] = b16(torch.cat([sd[p + ".to_k.weight"], sd[p + ".to_v.weight"]], 0))
+        # ff.net.2 followed by proj_out (attention.py:742-747 then :126,141-145): two consecutive LINEAR maps with only the residual
+        # add of the block between them -- x + proj_out(h + ff2(g)) = x + [Wp | Wp W2] [h | g] + (Wp b2 + bp) -- run as ONE two-source
+        # GEMM over K = C + 4C (the same FLOPs: the second map's K = C rides in the first one's K loop).  The product Wp W2 is formed
+        # once, in fp32, from the fp32 weights.  One launch and one round trip of the block's residual stream fewer per transformer
+        # block, 32 per step.  The plain weights stay (row subsets under cond_frame > 0, return_attn, the training engine).
+        if self.ff_fold:
+            for k in sd:
+                if not k.endswith(".proj_out.weight") or (".attentions." not in k and ".temporal_attentions." not in k):
+                    continue
+                pth = k[: -len(".proj_out.weight")]
+                tb = pth + ".transformer_blocks.0"
+                if (tb + ".ff.net.2.weight") not in sd:
+                    continue
+                wp = pack_conv1x1(sd[k]).to(dev, torch.float32)
+                w2, b2 = f32(sd[tb + ".ff.net.2.weight"]), f32(sd[tb + ".ff.net.2.bias"])
+                w[pth + ".ffproj.w"] = torch.cat([wp, wp @ w2], dim=1).to(bf16).contiguous()           # [C, C + 4C]
+                w[pth + ".ffproj.b"] = (wp @ b2 + f32(sd[pth + ".proj_out.bias"])).contiguous()
         # LayerNorm folded into the GEMM that consumes it (ops.fold_layernorm): W' = gamma (.) W from the fp32 weights, its row
         # sums and beta W^T + b, next to the plain weights (a launch that cannot fold runs layernorm + the plain ones)
         self.wln: Dict[str, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = {}
@@ -441,6 +460,16 @@ class _Engine:
         g = self._ln_gemm(h_rows, tb, ".norm3", tb + ".ff.net.0.proj.weight", tb + ".ff.net.0.proj.bias", geglu=True)
         ops.gemm(g, w[tb + ".ff.net.2.weight"], bias=w[tb + ".ff.net.2.bias"], residual=h_rows, out=h_rows)
 
+    def _ff_proj_out(self, p, tb, h, x, cb):
+        """the feed-forward of block `tb` and the transformer's proj_out + residual x: folded into one two-source GEMM when the
+        block's weights were (see _pack), else ff.net.2 + residual and proj_out + residual as two launches"""
+        ops, w = self.ops, self.w
+        if (p + ".ffproj.w") in w:
+            g = self._ln_gemm(h, tb, ".norm3", tb + ".ff.net.0.proj.weight", tb + ".ff.net.0.proj.bias", geglu=True)
+            return ops.gemm(h, w[p + ".ffproj.w"], a2=g, bias=w[p + ".ffproj.b"], residual=x, colsum_batch=cb)
+        self._ff(tb, h)
+        return ops.gemm(h, w[p + ".proj_out.weight"], bias=w[p + ".proj_out.bias"], residual=x, colsum_batch=cb)
+
     def _text_transformer(self, p, x, geo):
         """SpatialTransformer3D + BasicTextTransformerBlock3D (attention.py:129-145, 308-327)."""
         ops, w = self.ops, self.w
@@ -471,9 +500,7 @@ class _Engine:
             self._attn_list.append(self._cross_scores(q, kv[:, :C], B, Fr, H, W, heads, d, L))
         ops.attention(q, kv[:, :C], kv[:, C:], a, batch=B * Fr, heads=heads, head_dim=d, Sq=HW, Sk=L, q_prescaled=True)
         ops.gemm(a, w[tb + ".attn2.to_out.0.weight"], bias=w[tb + ".attn2.to_out.0.bias"], residual=h, out=h, **self._rs())
-        self._ff(tb, h)
-        return ops.gemm(h, w[p + ".proj_out.weight"], bias=w[p + ".proj_out.bias"], residual=x,
-                        colsum_batch=self._cb(B, Fr * HW))
+        return self._ff_proj_out(p, tb, h, x, self._cb(B, Fr * HW))
 
     def _cross_scores(self, q, k, B, Fr, H, W, heads, d, L):
         """`attention_scores` of the text cross attention (attention.py:556-584: scale * Q K^T before the softmax) as
@@ -534,7 +561,7 @@ class _Engine:
         # FF skips the conditioning frames (attention.py:241-246); frames are the slow index inside a batch element
         skip_f = cond_frame if self.shard is None else self.shard.local_cond_frames(cond_frame)
         if skip_f <= 0:
-            self._ff(tb, h)
+            return self._ff_proj_out(p, tb, h, x, self._cb(B, Fr * HW))
         elif skip_f < Fr:
             for b in range(B):
                 self._ff(tb, h[b * Fr * HW + skip_f * HW:(b + 1) * Fr * HW])

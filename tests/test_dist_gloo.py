@@ -53,6 +53,7 @@ def _worker(rank, world, port, batch_groups, B, Fr, H, cond_frame, out_path):
         # kernel + plain weights) where a shard that holds no conditioning frame feeds it whole rows (folded into the GEMM) -- two
         # valid arithmetics of the same operator, not one
         m.ln_fold = False
+        m.ff_fold = False       # likewise ff.net.2 + proj_out as one GEMM (whole rows only) against the two launches of a row subset
         g = torch.Generator().manual_seed(7)
         x = torch.randn((B, 4, Fr, H, H), generator=g)
         ctx = torch.randn((B, Fr, 77, 256), generator=g)
