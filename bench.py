@@ -35,7 +35,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0                     # same guide: HBM3E 8 TB/s (spec)
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16
-PMC_TRAFFIC_FILE = "r04_pmc_traffic.json"
+PMC_TRAFFIC_FILE = "r05_pmc_traffic.json"
 WORKLOAD = dict(b=1, cond_frames=2, frames=12, latent=32, ddim_steps=50, scale=7.5)
 # BASELINE.json configs: [1] is the bench line (default); the others are parity-test cases that can be timed on request
 WORKLOADS = {
