@@ -76,73 +76,91 @@ def _regs(text: str) -> Set[int]:
     return s
 
 
+_BRANCH = re.compile(r"^\s*(s_cbranch_\w+|s_branch)\s+(\.L[\w$.]+)")
+_LOCAL = re.compile(r"^(\.L[\w$.]*):")
+
+
 def check_attn40_vregs(lines: Iterable[str], fname: str = "") -> Tuple[List[str], int]:
-    """returns (violations, number of issue/wait statement pairs checked)"""
-    out: List[str] = []
-    pairs = 0
+    """returns (violations, number of issue statements checked).  Control-flow aware: from every ISSUE statement (an asm block with
+    LDS reads that are not all waited for inside it) every path is followed -- fall-through and branch targets, inside the kernel --
+    until a WAIT statement (an asm block with `s_waitcnt lgkmcnt(0)` and no LDS read); an instruction on such a path that names
+    a register the LDS is still writing is a violation.  (A scan in file order is not enough: hipcc lays the blocks of the partial-tile
+    and re-run paths out between an issue and its wait.)"""
     lines = list(lines)
-    i, n = 0, len(lines)
-    in_kernel = False
-    while i < n:
-        line = lines[i]
-        lab = _LABEL.match(line)
-        if lab and not lab.group(1).startswith(".L"):
-            in_kernel = "seer_attn40_kernel" in lab.group(1)
-        if in_kernel and _asm_start(line):
-            j = i + 1
-            block = []
-            while j < n and not _asm_end(lines[j]):
-                block.append(lines[j])
-                j += 1
-            text = "".join(block)
-            # an ISSUE statement: LDS reads whose results are not (all) waited for inside the statement -- lds_issue_kv (waits for
-            # its three K' reads, lgkmcnt(8): the eight V'^T destinations stay live), lds_issue_v / lds_prefetch_k of the ring form
-            # (no wait: every destination stays live)
-            dests = [r.group(1) for r in (re.match(r"\s*ds_read_\w+\s+(v\[\d+:\d+\]|v\d+)", b) for b in block) if r]
+    out: List[str] = []
+    checked = 0
+    n = len(lines)
+    # kernel extents
+    starts = [i for i, l in enumerate(lines) if (m := _LABEL.match(l)) and not m.group(1).startswith(".L")]
+    for ki, k0 in enumerate(starts):
+        if "seer_attn40_kernel" not in lines[k0]:
+            continue
+        k1 = starts[ki + 1] if ki + 1 < len(starts) else n
+        labels = {}
+        for i in range(k0, k1):
+            m = _LOCAL.match(lines[i])
+            if m:
+                labels[m.group(1)] = i
+        # asm blocks: start index -> (end index, text)
+        blocks = {}
+        i = k0
+        while i < k1:
+            if _asm_start(lines[i]):
+                j = i + 1
+                while j < k1 and not _asm_end(lines[j]):
+                    j += 1
+                blocks[i] = (j, "".join(lines[i + 1:j]))
+                i = j + 1
+            else:
+                i += 1
+        for b0, (b1, text) in blocks.items():
+            body = lines[b0 + 1:b1]
+            dests = [r.group(1) for r in (re.match(r"\s*ds_read_\w+\s+(v\[\d+:\d+\]|v\d+)", b) for b in body) if r]
             wm = re.search(r"lgkmcnt\((\d+)\)", text)
             n_live = len(dests) if wm is None else min(int(wm.group(1)), len(dests))
-            if dests and n_live > 0:
-                live: Set[int] = set()
-                for dreg in dests[len(dests) - n_live:]:
-                    live |= _regs(dreg)
-                # scan to the wait statement
-                k = j + 1
-                found = False
-                while k < n:
-                    l2 = lines[k]
-                    lab2 = _LABEL.match(l2)
-                    if lab2 and not lab2.group(1).startswith(".L"):
-                        break
-                    if _asm_start(l2):
-                        k2 = k + 1
-                        blk = []
-                        while k2 < n and not _asm_end(lines[k2]):
-                            blk.append(lines[k2])
-                            k2 += 1
-                        t2 = "".join(blk)
+            if not dests or n_live == 0:
+                continue
+            live: Set[int] = set()
+            for dreg in dests[len(dests) - n_live:]:
+                live |= _regs(dreg)
+            checked += 1
+            seen: Set[int] = set()
+            stack = [b1 + 1]
+            reached_wait = False
+            while stack:
+                i = stack.pop()
+                while k0 <= i < k1 and i not in seen:
+                    seen.add(i)
+                    line = lines[i]
+                    if i in blocks:
+                        e1, t2 = blocks[i]
                         if "lgkmcnt(0)" in t2 and "ds_read" not in t2:
-                            found = True
-                            break
+                            reached_wait = True
+                            break                       # this path is closed: the data has landed
                         hit = _regs(t2) & live
                         if hit:
-                            out.append(f"{fname}:{k + 1}: asm statement names V registers {sorted(hit)} before lds_wait_v")
-                        k = k2 + 1
+                            out.append(f"{fname}:{i + 1}: asm statement names V registers {sorted(hit)} before their LDS reads are waited for")
+                        i = e1 + 1
                         continue
-                    code = l2.split(";")[0]
-                    if code.strip() and not code.strip().startswith("."):
+                    code = line.split(";")[0].strip()
+                    if code and not code.startswith(".") and not _LABEL.match(line) and not _LOCAL.match(line):
+                        if code.startswith("s_endpgm"):
+                            break
                         hit = _regs(code) & live
                         if hit:
-                            out.append(f"{fname}:{k + 1}: `{code.strip()}` names V registers {sorted(hit)} that lds_issue_kv's "
-                                       "LDS reads are still writing")
-                    k += 1
-                if found:
-                    pairs += 1
-                else:
-                    out.append(f"{fname}:{i + 1}: lds_issue_kv statement without a following lds_wait_v statement")
-            i = j + 1
-            continue
-        i += 1
-    return out, pairs
+                            out.append(f"{fname}:{i + 1}: `{code}` names V registers {sorted(hit)} that an LDS issue statement "
+                                       f"(line {b0 + 1}) is still writing")
+                        br = _BRANCH.match(line)
+                        if br:
+                            tgt = labels.get(br.group(2))
+                            if tgt is not None:
+                                stack.append(tgt)
+                            if br.group(1) == "s_branch":
+                                break
+                    i += 1
+            if not reached_wait:
+                out.append(f"{fname}:{b0 + 1}: LDS issue statement without a wait statement on any path behind it")
+    return out, checked
 
 
 def check_directory(objdir: Path, sources: Iterable[str] = ()) -> List[str]:

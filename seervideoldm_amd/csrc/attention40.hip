@@ -470,7 +470,10 @@ __global__ void __launch_bounds__(256, (QB == 1 && NST == 2) ? 3 : 2) seer_attn4
                     lds_issue_kv(kp, lh ? ZONE : kp + 64, va, v1_pad ? v1_const : va + 64, kf[0], kf[1], kf[2], vraw);
                 }
                 bf16x8 vf[2][2];                                  // [key step][d tile], shared by the wave's query blocks
-                bool v_ready = false;
+                // generic path: the V'^T reads (behind the K' reads in the same LDS queue: a few cycles later) are waited for here, in
+                // straight-line code -- a wait under a run-time flag inside the query-block loop leaves the assembly with a path from the
+                // issue statement to a use that skips it (never taken, but no check of the assembly can know)
+                if constexpr (!(QB == 2 && PLAIN && !TRACK)) lds_wait_v(vraw, vf[0][0], vf[0][1], vf[1][0], vf[1][1]);
                 if constexpr (NST == 3 && !RING_FAST) ring_pieces(sub);
                 if constexpr (QB == 2 && PLAIN && !TRACK) {
                     // two query blocks, software-pipelined: both score tiles are issued before the first exponentials, so the
@@ -557,10 +560,6 @@ __global__ void __launch_bounds__(256, (QB == 1 && NST == 2) ? 3 : 2) seer_attn4
                         else        // truncation: {e1[31:16], e0[31:16]}
                             pk[i >> 2][i & 3] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, e1),
                                                                       __builtin_bit_cast(unsigned, e0), 0x07060302u);
-                    }
-                    if (!v_ready) {                               // the V'^T reads have been in flight since the top of the sub tile
-                        lds_wait_v(vraw, vf[0][0], vf[0][1], vf[1][0], vf[1][1]);
-                        v_ready = true;
                     }
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2) {
