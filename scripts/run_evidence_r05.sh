@@ -39,3 +39,7 @@ S4=$(ls $O/rocprof4/*/*_kernel_stats.csv | head -1)
 python scripts/rocprof_summary.py $S4 63 > $O/r05_rocprof_summary_config4.md 2>&1
 rm -rf $O/rocprof4
 tail -c 600 $O/r05_bench_final.json.log; cat $O/r05_step_timeline.md | head -12; cat $O/r05_shard_sizes.log
+# 7. the whole GPU suite and the smoke test on the same tree
+python -m pytest tests -m gpu -q --durations=25 > $O/r05_gpu_tests.log 2>&1; echo "pytest rc $?" >> $O/r05_gpu_tests.log
+python -c "import __graft_entry__ as g; g.smoke()" >> $O/r05_gpu_tests.log 2>&1; echo "smoke rc $?" >> $O/r05_gpu_tests.log
+tail -8 $O/r05_gpu_tests.log

@@ -419,7 +419,7 @@ def test_full_size_step_matches_the_reference(device, cond):
 
 def test_bridge_config_single_gpu(device):
     """BASELINE config 3 on one GPU: CFG batch 8 (4 samples x [uc, c]) x 16 frames (1 conditioning) x 32^2, full-width UNet.
-    (a) finite, right shape; (b) a sample's result does not depend on its batch slot or on its neighbours: rows 0 and 4 of
+    (0) against the REAL reference's output at this size; (a) finite, right shape; (b) a sample's result does not depend on its batch slot or on its neighbours: rows 0 and 4 of
     the B = 8 step equal the B = 2 step of that sample up to the path's own rounding noise (tile / split-K choices differ
     with M, so fp32 sums are ordered differently and single bf16 roundings flip; through ~100 layers that is the same
     1.7e-2 the path has against the fp32 oracle -- measured 1.66e-2 -- and far from the 0.3+ of a batch mix-up);
@@ -431,6 +431,9 @@ def test_bridge_config_single_gpu(device):
     t8 = torch.full((8,), 621, dtype=torch.long, device=device)
     y8 = m(x8, t8, c8, cond_frame=1)
     assert y8.shape == (8, 4, 16, 32, 32) and torch.isfinite(y8).all()
+    # (0) one hop from the reference: its own output at this size (oracle/make_goldens_full.py::gen_bridge, 150 s of host time there)
+    g = _full_fixture("unet_full_bridge.npz", x8.cpu(), c8.cpu())
+    _check(y8, torch.from_numpy(g["y"]), "config 3 full size (CFG batch 8 x 16 frames, cond 1) vs the reference")
     y2 = m(torch.cat([xs[:1], xs[:1]]), t8[:2], torch.cat([ucs[:1], cs[:1]]), cond_frame=1)
     for a, b in ((y8[0], y2[0]), (y8[4], y2[1])):
         rel = ((a - b).norm() / b.norm()).item()
