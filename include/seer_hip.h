@@ -328,6 +328,17 @@ int seer_groupnorm_apply_fx(const void* x1, int32_t C1, const void* x2, int32_t 
  * for GroupNorm sources without accumulated producer sums (resnet.py:179,197, attention.py:133 normalise over all frames). */
 int seer_groupnorm_stats_fx(const void* x, int32_t C, int32_t batch, int64_t rows_per_batch, int64_t* fx, int32_t dtype,
                             void* stream);
+/* The feed-forward of a transformer block at the 320-channel level and the transformer's proj_out, ONE launch (csrc/ff_fused.hip):
+ *     y = x + [Wp | Wp W2] [h | g] + bcat,   g = GEGLU(LayerNorm(h; gamma, beta, eps) W1^T + b1)
+ * i.e. norm3 -> ff.net.0 -> ff.net.2 + residual -> proj_out + residual (seer/models/attention.py:231-248, 308-327, 742-747,
+ * 783-793, 126, 141-145).  h, x, y: [M][320] bf16 with row strides ldh, ldx, ldy (elements, multiples of 8; y may alias x);
+ * M a multiple of 96.  w1 [2560][320] bf16 and b1 [2560] fp32 in the interleaved GEGLU row order (16 value rows, 16 gate rows, ...);
+ * wcat [320][1600] bf16 = [Wp | Wp W2]; bcat [320] fp32 = Wp b2 + bp.  colsum_fx (or NULL): [fx_reps][M / fx_rows][2][320] int64,
+ * ADDED to, the fixed-point column sums of y as seer_gemm_desc::colsum_fx (fx_rows = rows per batch element, a multiple of 96).
+ * All pointers 16-byte aligned.  SEER_EINVAL otherwise. */
+int seer_ff_fused_c320(const void* h, int32_t ldh, const void* x, int32_t ldx, void* y, int32_t ldy, int64_t M,
+                       const float* gamma, const float* beta, float eps, const void* w1, const float* b1, const void* wcat,
+                       const float* bcat, int64_t* colsum_fx, int64_t fx_rows, int32_t fx_reps, void* stream);
 /* the same two with the storage type of x1 / x2 / y chosen by `dtype` (SEER_DT_*): the VAE's nn.GroupNorm(32, eps 1e-6)
  * (ldm/modules/diffusionmodules/model.py:38-40) on fp16 activations */
 int seer_groupnorm_stats_dt(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t batch,

@@ -13,7 +13,7 @@ _PKG = Path(__file__).resolve().parent
 _LIB_PATH = _PKG / "lib" / "libseer_hip.so"
 _lib = None
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 SEER_GEMM_PLAIN = 0
 SEER_GEMM_CONV3X3 = 1
@@ -106,6 +106,7 @@ SIGNATURES = {
                                            _i32, _vp, _vp], C.c_int),
     "seer_groupnorm_apply_fx": ([_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i64, _i32, _f64, _f32, _vp, _vp, _i32, _vp, _vp, _vp], C.c_int),
     "seer_groupnorm_stats_fx": ([_vp, _i32, _i32, _i64, _vp, _i32, _vp], C.c_int),
+    "seer_ff_fused_c320": ([_vp, _i32, _vp, _i32, _vp, _i32, _i64, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp], C.c_int),
     "seer_gemm_colsum_fx_layout": ([C.POINTER(GemmDesc), _i32, C.POINTER(C.c_int32)], C.c_int32),
     "seer_groupnorm_stats_dt": ([_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _i32, _vp], C.c_int),
     "seer_groupnorm_apply_dt": ([_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _f64, _f32, _vp, _vp, _i32, _vp, _i32, _vp], C.c_int),

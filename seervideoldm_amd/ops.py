@@ -593,6 +593,41 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     return out
 
 
+FF_FUSED_C, FF_FUSED_ROWS = 320, 96
+
+
+def ff_fused(h: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor,
+             wcat: torch.Tensor, bcat: torch.Tensor, *, eps: float = 1e-5, out: Optional[torch.Tensor] = None,
+             colsum_batch=0) -> Optional[torch.Tensor]:
+    """y = x + [Wp | Wp W2] [h | GEGLU(LayerNorm(h) W1^T + b1)] + bcat as ONE launch (seer_ff_fused_c320): the feed-forward of a
+    transformer block and the transformer's proj_out with both residual adds, at the 320-channel level.  w1 / b1 in the interleaved
+    GEGLU row order, wcat = [Wp | Wp W2] [320, 1600], bcat = Wp b2 + bp.  colsum_batch = (B, arena): out.colsums = the ColSumsFx
+    of y.  Returns None (nothing launched) when the shape is not the kernel's: C = 320, rows a multiple of 96."""
+    M, Cc = h.shape
+    if Cc != FF_FUSED_C or M % FF_FUSED_ROWS or M == 0:
+        return None
+    _req(h, bf16, "h"); _req(x, bf16, "x"); _req(w1, bf16, "w1"); _req(wcat, bf16, "wcat")
+    assert x.shape == h.shape and h.stride(1) == 1 and x.stride(1) == 1
+    assert w1.shape == (8 * Cc, Cc) and w1.is_contiguous() and wcat.shape == (Cc, 5 * Cc) and wcat.is_contiguous()
+    for t, n in ((gamma, "gamma"), (beta, "beta"), (b1, "b1"), (bcat, "bcat")):
+        _req(t, torch.float32, n)
+    if out is None:
+        out = torch.empty((M, Cc), device=h.device, dtype=bf16)
+    fx, fx_rows, cs = None, 0, None
+    if isinstance(colsum_batch, tuple):
+        B, arena = colsum_batch
+        if B > 0 and M % B == 0 and (M // B) % FF_FUSED_ROWS == 0:
+            fx = arena.take(8, B, Cc)
+            if fx is not None:
+                fx_rows, cs = M // B, ColSumsFx(fx, Cc)
+    check(_lib.load().seer_ff_fused_c320(_p(h), h.stride(0), _p(x), x.stride(0), _p(out), out.stride(0), M, _p(gamma), _p(beta),
+                                         float(eps), _p(w1), _p(b1), _p(wcat), _p(bcat), fx.data_ptr() if fx is not None else None,
+                                         fx_rows, fx.shape[0] if fx is not None else 0, _stream()), "seer_ff_fused_c320")
+    out.colsums = cs
+    out.rowstats = None
+    return out
+
+
 def softmax_rows(x: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None, dtype=None) -> torch.Tensor:
     """softmax(scale * x) over the last dim; x bf16 / fp16 / fp32 -> `dtype` (bf16 unless out / dtype say fp16)."""
     assert x.dtype in (bf16, f16, torch.float32) and x.is_cuda

@@ -1175,3 +1175,63 @@ def test_groupnorm_stats_fx_is_exact_and_shard_invariant(device, C, rows, B):
         assert torch.equal(got, y_full), "a shard normalises its rows exactly as the unsharded launch does"
         refy = Fn.silu(Fn.group_norm(v.permute(0, 2, 1), G, gamma, beta, 1e-5)).permute(0, 2, 1).reshape(-1, C)
         _close(y_full, refy, rtol=1e-2, atol=1e-2, what=f"groupnorm from exact sums C {C}")
+
+
+# ------------------------------------------------------------------------------ fused feed-forward, 320 channels
+@pytest.mark.parametrize("M,B,strided", [(96, 1, False), (960, 2, False), (24576, 2, False), (12288, 1, True)])
+def test_ff_fused_c320(device, M, B, strided):
+    """seer_ff_fused_c320: y = x + [Wp | Wp W2][h | GEGLU(LN(h) W1^T + b1)] + bcat in one launch, against (a) the fp32 formula on the
+    bf16-rounded operands with the intermediate roundings of the unfused path (LN(h) and g stored as bf16) and (b) the three
+    launches it replaces; the fixed-point column sums against the sums of the stored output."""
+    from seervideoldm_amd import ops
+    from seervideoldm_amd.weights import geglu_row_order
+    C, inner = 320, 1280
+    ld = C + 64 if strided else C
+    hbuf = _rand((M, ld), device, 1).to(bf16)
+    xbuf = _rand((M, ld), device, 2).to(bf16)
+    h, x = hbuf[:, :C], xbuf[:, :C]
+    gamma, beta = 1.0 + 0.2 * _rand((C,), device, 3), 0.1 * _rand((C,), device, 4)
+    w1 = _rand((2 * inner, C), device, 5, C ** -0.5).to(bf16)
+    b1 = 0.2 * _rand((2 * inner,), device, 6)
+    wcat = _rand((C, C + inner), device, 7, (C + inner) ** -0.5).to(bf16)
+    bcat = 0.2 * _rand((C,), device, 8)
+    order = geglu_row_order(inner, device)
+    w1p, b1p = w1[order].contiguous(), b1[order].contiguous()
+    arena = ops.FxArena(device, 1 << 16)
+    arena.reset()
+    y = ops.ff_fused(h, x, gamma, beta, w1p, b1p, wcat, bcat, colsum_batch=(B, arena))
+    assert y is not None and y.shape == (M, C)
+    torch.cuda.synchronize()
+    # (a) the formula
+    hn = Fn.layer_norm(h.float(), (C,), gamma, beta, 1e-5).to(bf16).float()
+    pre = hn @ w1.float().t() + b1
+    g = (pre[:, :inner] * Fn.gelu(pre[:, inner:])).to(bf16).float()
+    ref = x.float() + torch.cat([h.float(), g], 1) @ wcat.float().t() + bcat
+    _close(y, ref, what="ff_fused vs formula")
+    rel = ((y.float() - ref).norm() / ref.norm()).item()
+    assert rel < 4e-3, rel
+    # (b) the launches it replaces
+    n = ops.layernorm(h.contiguous(), gamma, beta)
+    gg = ops.gemm(n, w1p, bias=b1p, geglu=True)
+    y3 = ops.gemm(h.contiguous(), wcat, a2=gg, bias=bcat, residual=x.contiguous())
+    rel3 = ((y.float() - y3.float()).norm() / y3.float().norm()).item()
+    assert rel3 < 4e-3, rel3
+    # column sums of the stored values
+    cs = y.colsums
+    assert cs is not None
+    tot = cs.totals()                                                      # [B, C, 2] fp64
+    yb = y.double().reshape(B, M // B, C)
+    assert torch.allclose(tot[:, :, 0], yb.sum(1), rtol=0, atol=2e-2)
+    assert torch.allclose(tot[:, :, 1], (yb * yb).sum(1), rtol=1e-5, atol=2e-2)
+    # in place on the residual stream
+    x2 = x.contiguous().clone()
+    y2 = ops.ff_fused(h, x2, gamma, beta, w1p, b1p, wcat, bcat, out=x2)
+    assert torch.equal(y2, y)
+
+
+def test_ff_fused_c320_refuses_other_shapes(device):
+    from seervideoldm_amd import ops
+    z = torch.zeros((100, 320), device=device, dtype=bf16)
+    f = torch.zeros((2560,), device=device)
+    assert ops.ff_fused(z, z, f[:320], f[:320], torch.zeros((2560, 320), device=device, dtype=bf16), f,
+                        torch.zeros((320, 1600), device=device, dtype=bf16), f[:320]) is None
