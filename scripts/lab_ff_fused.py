@@ -21,6 +21,7 @@ gamma, beta = 1 + 0.1 * r(C), 0.1 * r(C)
 w1, b1 = r(2 * inner, C, sc=C ** -0.5).to(bf16), 0.1 * r(2 * inner)
 wcat, bcat = r(C, C + inner, sc=(C + inner) ** -0.5).to(bf16), 0.1 * r(C)
 arena = ops.FxArena(dev, 1 << 20)
+w1f, wcf = ops.ff_fused_pack(w1, wcat)
 
 
 def timed(fn, n=50):
@@ -45,11 +46,11 @@ def unfused():
 
 def fused():
     arena.reset()
-    return ops.ff_fused(h, x, gamma, beta, w1, b1, wcat, bcat, colsum_batch=(2, arena))
+    return ops.ff_fused(h, x, gamma, beta, w1f, b1, wcf, bcat, colsum_batch=(2, arena))
 
 
 def fused_nosum():
-    return ops.ff_fused(h, x, gamma, beta, w1, b1, wcat, bcat)
+    return ops.ff_fused(h, x, gamma, beta, w1f, b1, wcf, bcat)
 
 
 flop = 2.0 * M * C * 2 * inner + 2.0 * M * (C + inner) * C

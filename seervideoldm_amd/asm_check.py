@@ -22,6 +22,13 @@ Rule `attn40_vregs` -- attention40.hip issues its V'^T LDS reads in one asm stat
 and waits for them in a later one (`lds_wait_v` / `lds_wait_vk`, `s_waitcnt lgkmcnt(0)`): the hardware writes those registers
 AFTER the issuing statement has ended, behind the register allocator's back.  Between the two statements no instruction may name
 one of them (a copy or a spill would move stale data).
+
+Rule `ff_fused_vregs` -- ff_fused.hip requests its weight fragments with `global_load_dwordx4` into registers (req4 / req10) and its
+activation fragments with `ds_read_b128` (a_req) in asm statements WITHOUT a wait, and waits later with counted `s_waitcnt vmcnt(N)`
+/ `lgkmcnt(0)` statements -- across the chunk loop's back edge.  The rule interprets the kernel's assembly over its control-flow
+graph with the two counters modelled (in-order retirement; every vector-memory / LDS / scalar-memory instruction is an entry):
+an instruction that names a V register whose load has not been retired on SOME path to it is a violation.  The compiler's own loads
+pass through the same model.
 """
 from __future__ import annotations
 
@@ -163,6 +170,108 @@ def check_attn40_vregs(lines: Iterable[str], fname: str = "") -> Tuple[List[str]
     return out, checked
 
 
+_VM_LOAD = re.compile(r"^(global_load_|buffer_load_|flat_load_|scratch_load_)(\w+)\s+([va]\[\d+:\d+\]|[va]\d+),")
+_VM_OTHER = re.compile(r"^(global_|buffer_|flat_|scratch_)(load_lds_|store_|atomic_)")
+_DS_READ = re.compile(r"^ds_(read|load)\w*\s+([va]\[\d+:\d+\]|[va]\d+),")
+_CNT = re.compile(r"(vmcnt|lgkmcnt|expcnt)\((\d+)\)")
+
+
+def _regs_va(text: str) -> Set[int]:
+    """V registers as their numbers, accumulation registers as 1000 + number"""
+    s: Set[int] = set()
+    for cls, a, b in re.findall(r"\b([va])\[(\d+):(\d+)\]", text):
+        s.update(range(int(a) + (1000 if cls == "a" else 0), int(b) + 1 + (1000 if cls == "a" else 0)))
+    for cls, a in re.findall(r"\b([va])(\d+)\b", text):
+        s.add(int(a) + (1000 if cls == "a" else 0))
+    return s
+
+
+def _strip(q: tuple) -> tuple:
+    """entries older than the oldest one that still owns registers retire first and own nothing: irrelevant"""
+    i = 0
+    while i < len(q) and not q[i]:
+        i += 1
+    return q[i:]
+
+
+def check_async_vregs(lines: Iterable[str], kernel_substr: str, fname: str = "") -> Tuple[List[str], int]:
+    """returns (violations, number of register-destined vector-memory loads seen inside asm statements of the kernel)"""
+    lines = list(lines)
+    out: List[str] = []
+    n = len(lines)
+    starts = [i for i, l in enumerate(lines) if (m := _LABEL.match(l)) and not m.group(1).startswith(".L")]
+    n_async = 0
+    for ki, k0 in enumerate(starts):
+        if kernel_substr not in lines[k0]:
+            continue
+        k1 = starts[ki + 1] if ki + 1 < len(starts) else n
+        labels = {m.group(1): i for i in range(k0, k1) if (m := _LOCAL.match(lines[i]))}
+        in_asm = False
+        asm_line = [False] * n
+        for i in range(k0, k1):
+            if _asm_start(lines[i]):
+                in_asm = True
+            elif _asm_end(lines[i]):
+                in_asm = False
+            asm_line[i] = in_asm
+        seen = set()
+        reported = set()
+        work = [(k0 + 1, (), ())]
+        while work:
+            i, vm, lg = work.pop()
+            while k0 <= i < k1:
+                key = (i, vm, lg)
+                if key in seen:
+                    break
+                seen.add(key)
+                line = lines[i]
+                code = line.split(";")[0].strip()
+                if not code or code.startswith(".") or _LABEL.match(line) or _LOCAL.match(line) or code.startswith("//"):
+                    i += 1
+                    continue
+                if code.startswith("s_endpgm"):
+                    break
+                named = _regs_va(code)
+                pending = set().union(*vm, *lg) if (vm or lg) else set()
+                hit = named & pending
+                if hit and (i, tuple(sorted(hit))) not in reported:
+                    reported.add((i, tuple(sorted(hit))))
+                    out.append(f"{fname}:{i + 1}: `{code}` names registers {sorted(hit)} (accumulation registers: 1000 +) whose load is still in flight on some path")
+                if code.startswith("s_waitcnt"):
+                    if not _CNT.search(code):                       # raw immediate: assume it waits for everything
+                        vm, lg = (), ()
+                    for name, cnt in _CNT.findall(code):
+                        c = int(cnt)
+                        if name == "vmcnt":
+                            vm = _strip(vm[len(vm) - c:] if c < len(vm) else vm) if c else ()
+                        elif name == "lgkmcnt":
+                            lg = _strip(lg[len(lg) - c:] if c < len(lg) else lg) if c else ()
+                    i += 1
+                    continue
+                m = _VM_LOAD.match(code)
+                if m and "_lds_" not in code:
+                    vm = _strip(vm + (frozenset(_regs_va(m.group(3))),))
+                    if asm_line[i]:
+                        n_async += 1
+                elif _VM_OTHER.match(code) or m:
+                    vm = _strip(vm + (frozenset(),))
+                else:
+                    d = _DS_READ.match(code)
+                    if d:
+                        lg = _strip(lg + (frozenset(_regs_va(d.group(2))),))
+                    elif code.startswith("ds_") or code.startswith("s_load_") or code.startswith("s_buffer_load_"):
+                        lg = _strip(lg + (frozenset(),))
+                br = _BRANCH.match(line)
+                if br:
+                    tgt = labels.get(br.group(2))
+                    if tgt is not None:
+                        work.append((tgt, vm, lg))
+                    if br.group(1) == "s_branch":
+                        break
+                i += 1
+    return out, n_async
+
+
 def check_directory(objdir: Path, sources: Iterable[str] = ()) -> List[str]:
     """run every rule over the device assembly under `objdir`; returns the violations.  `sources`: the .hip files of the build --
     only their assembly is read (a stale .s of a removed source must neither fail nor mask a build); empty = every *gfx950.s.
@@ -177,6 +286,7 @@ def check_directory(objdir: Path, sources: Iterable[str] = ()) -> List[str]:
     if not files:
         return [f"no device assembly (*gfx950.s) under {objdir}: build with seervideoldm_amd.build"]
     pairs = 0
+    ff_seen = None
     for f in files:
         lines = f.read_text().splitlines(keepends=True)
         problems += check_pk_src1_hi(lines, f.name)
@@ -184,6 +294,11 @@ def check_directory(objdir: Path, sources: Iterable[str] = ()) -> List[str]:
             v, p = check_attn40_vregs(lines, f.name)
             problems += v
             pairs += p
+        if f.name.startswith("ff_fused"):
+            v, ff_seen = check_async_vregs(lines, "seer_ff_fused_c320_kernel", f.name)
+            problems += v
     if pairs == 0:
         problems.append("attention40: no lds_issue_kv / lds_wait_v statement pair found in the assembly (the check no longer sees the kernel)")
+    if ff_seen is not None and ff_seen < 30:
+        problems.append(f"ff_fused: only {ff_seen} asynchronous fragment requests found in the kernel's assembly (the check no longer sees them)")
     return problems

@@ -29,8 +29,17 @@ EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                # GEMM: the epilogue reads every accumulator once; VGPR form saves those moves (+0.7 % on the step, A/B in one run)
                "gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "gemm_ws.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
-               "gemm_t320.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
-               "ff_fused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+               "gemm_t320.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+# ff_fused.hip: default form -- its accumulators and its W1 fragment ring live in the accumulation registers (120 + 48 + 80), the
+# asynchronously written fragment registers must never meet a register-allocator copy (asm_check.py::check_async_vregs)
+
+
+# No packed fp32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) anywhere: on gfx950 those instructions do not run in the
+# shadow of MFMAs -- a loop of MFMAs with v_pk_fma_f32 between them takes the SUM of the two loops' times (plain v_fma_f32: 0.7 of
+# the shorter one hidden), also across the waves of a SIMD, so a wave in its epilogue stalls its neighbour's MFMAs; and with two
+# waves per SIMD a packed instruction costs 3.9 ns against 2.3 ns for a plain one (profiles/r05_lab_mfma_valu.log).  hipcc's SLP
+# vectoriser forms them freely from scalar code; this turns the feature off for the device code.
+NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 
 def _hipcc() -> str:
@@ -60,7 +69,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     objdir.mkdir(exist_ok=True)
     # -save-temps=obj: the device assembly of every source stays next to its object for asm_check (the other temporaries go)
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", f"-I{ROOT / 'include'}", f"-I{CSRC}",
-             "-fno-gpu-rdc", "-Wno-unused-result", "-save-temps=obj"]
+             "-fno-gpu-rdc", "-Wno-unused-result", "-save-temps=obj", *NO_PACKED_FP32]
 
     def compile_one(src: str) -> Path:
         obj = objdir / (src + ".o")

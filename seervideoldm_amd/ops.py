@@ -594,35 +594,53 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
 
 
 FF_FUSED_C, FF_FUSED_ROWS = 320, 96
+# the engine takes the fused launch from this many rows up (64 workgroups): below, the launches it replaces are as fast, and a CFG pair
+# evaluated as one batch or as two calls then runs the SAME kernels at every level (bit-equal rows: ddim_video.py:205-207's two branches)
+FF_FUSED_MIN_ROWS = 6144
 
 
-def ff_fused(h: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor,
-             wcat: torch.Tensor, bcat: torch.Tensor, *, eps: float = 1e-5, out: Optional[torch.Tensor] = None,
+def ff_fused_pack(w1: torch.Tensor, wcat: torch.Tensor):
+    """The two weight matrices of ff_fused in the kernel's fragment order (seer_ff_fused_pack_w1 / _wcat): w1 [2560, 320] bf16 in the
+    interleaved GEGLU row order, wcat [320, 1600] bf16 = [Wp | Wp W2].  Once per model."""
+    _req(w1, bf16, "w1"); _req(wcat, bf16, "wcat")
+    assert w1.shape == (8 * FF_FUSED_C, FF_FUSED_C) and w1.is_contiguous() and wcat.shape == (FF_FUSED_C, 5 * FF_FUSED_C) and wcat.is_contiguous()
+    w1f, wcf = torch.empty_like(w1), torch.empty_like(wcat)
+    check(_lib.load().seer_ff_fused_pack_w1(_p(w1), _p(w1f), _stream()), "seer_ff_fused_pack_w1")
+    check(_lib.load().seer_ff_fused_pack_wcat(_p(wcat), _p(wcf), _stream()), "seer_ff_fused_pack_wcat")
+    return w1f, wcf
+
+
+def ff_fused(h: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, w1f: torch.Tensor, b1: torch.Tensor,
+             wcf: torch.Tensor, bcat: torch.Tensor, *, eps: float = 1e-5, out: Optional[torch.Tensor] = None,
              colsum_batch=0) -> Optional[torch.Tensor]:
     """y = x + [Wp | Wp W2] [h | GEGLU(LayerNorm(h) W1^T + b1)] + bcat as ONE launch (seer_ff_fused_c320): the feed-forward of a
-    transformer block and the transformer's proj_out with both residual adds, at the 320-channel level.  w1 / b1 in the interleaved
-    GEGLU row order, wcat = [Wp | Wp W2] [320, 1600], bcat = Wp b2 + bp.  colsum_batch = (B, arena): out.colsums = the ColSumsFx
-    of y.  Returns None (nothing launched) when the shape is not the kernel's: C = 320, rows a multiple of 96."""
+    transformer block and the transformer's proj_out with both residual adds, at the 320-channel level.  w1f, wcf from
+    ff_fused_pack; b1 in the interleaved GEGLU row order, bcat = Wp b2 + bp.  colsum_batch as in gemm(): (B, arena) -> out.colsums =
+    the ColSumsFx of y, B -> the per-tile ColSums (96-row tiles).  Returns None (nothing launched) when the shape is not the kernel's: C = 320, rows a multiple of 96."""
     M, Cc = h.shape
     if Cc != FF_FUSED_C or M % FF_FUSED_ROWS or M == 0:
         return None
-    _req(h, bf16, "h"); _req(x, bf16, "x"); _req(w1, bf16, "w1"); _req(wcat, bf16, "wcat")
+    _req(h, bf16, "h"); _req(x, bf16, "x"); _req(w1f, bf16, "w1f"); _req(wcf, bf16, "wcf")
     assert x.shape == h.shape and h.stride(1) == 1 and x.stride(1) == 1
-    assert w1.shape == (8 * Cc, Cc) and w1.is_contiguous() and wcat.shape == (Cc, 5 * Cc) and wcat.is_contiguous()
+    assert w1f.numel() == 8 * Cc * Cc and w1f.is_contiguous() and wcf.numel() == 5 * Cc * Cc and wcf.is_contiguous()
     for t, n in ((gamma, "gamma"), (beta, "beta"), (b1, "b1"), (bcat, "bcat")):
         _req(t, torch.float32, n)
     if out is None:
         out = torch.empty((M, Cc), device=h.device, dtype=bf16)
-    fx, fx_rows, cs = None, 0, None
-    if isinstance(colsum_batch, tuple):
-        B, arena = colsum_batch
-        if B > 0 and M % B == 0 and (M // B) % FF_FUSED_ROWS == 0:
+    fx, fx_rows, cs, tiles = None, 0, None, None
+    B, arena = colsum_batch if isinstance(colsum_batch, tuple) else (colsum_batch, None)
+    if B > 0 and M % B == 0 and (M // B) % FF_FUSED_ROWS == 0:
+        if arena is not None:
             fx = arena.take(8, B, Cc)
-            if fx is not None:
-                fx_rows, cs = M // B, ColSumsFx(fx, Cc)
+        if fx is not None:
+            fx_rows, cs = M // B, ColSumsFx(fx, Cc)
+        else:
+            tiles = torch.empty((1, M // FF_FUSED_ROWS, Cc, 2), device=h.device, dtype=torch.float32)
+            cs = ColSums(tiles, Cc, 1, M // FF_FUSED_ROWS)
     check(_lib.load().seer_ff_fused_c320(_p(h), h.stride(0), _p(x), x.stride(0), _p(out), out.stride(0), M, _p(gamma), _p(beta),
-                                         float(eps), _p(w1), _p(b1), _p(wcat), _p(bcat), fx.data_ptr() if fx is not None else None,
-                                         fx_rows, fx.shape[0] if fx is not None else 0, _stream()), "seer_ff_fused_c320")
+                                         float(eps), _p(w1f), _p(b1), _p(wcf), _p(bcat), fx.data_ptr() if fx is not None else None,
+                                         fx_rows, fx.shape[0] if fx is not None else 0, _p(tiles) if tiles is not None else None,
+                                         _stream()), "seer_ff_fused_c320")
     out.colsums = cs
     out.rowstats = None
     return out

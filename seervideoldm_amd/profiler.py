@@ -40,6 +40,14 @@ class TimedOps:
         tag = f"gemm M{M} N{N} K{K}" + (" geglu" if k.get("geglu") else "") + (" +res" if k.get("residual") is not None else "")
         return self._timed("gemm", 2.0 * M * N * K, nbytes, self._base.gemm, a, w, _tag=tag, **k)
 
+    def ff_fused(self, h, x, gamma, beta, w1f, b1, wcf, bcat, **k):
+        # norm3 -> ff.net.0 (GEGLU) -> [proj_out | proj_out ff.net.2] + residuals as one launch: the MACs of the two GEMMs it holds
+        M, Cc = h.shape
+        flops = 2.0 * M * Cc * (8 * Cc) + 2.0 * M * (5 * Cc) * Cc
+        nbytes = 2 * (3 * M * Cc + w1f.numel() + wcf.numel())
+        return self._timed("gemm", flops, nbytes, self._base.ff_fused, h, x, gamma, beta, w1f, b1, wcf, bcat,
+                           _tag=f"ff_fused M{M} C{Cc}", **k)
+
     def gemm_batched(self, a, w, **k):
         Bt, M, K = a.shape
         N = w.shape[-2]
@@ -147,6 +155,9 @@ class TimedOps:
             if N == 3 * K:
                 return f"q|k|v projection {lvl}"
             return f"projections / 1x1 {lvl}"
+        if t[0] == "ff_fused":
+            lvl = {24576: "L0"}.get(int(t[1][1:]), t[1])
+            return f"fused feed-forward (norm3, ff.net.0 GEGLU, ff.net.2 | proj_out +res) {lvl}"
         if t[0] == "conv":
             return f"conv3x3 {t[2]}"
         if t[0] == "conv_up2x":

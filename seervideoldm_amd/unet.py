@@ -229,6 +229,8 @@ class _Engine:
         self._ln_on = False
         # ff.net.2 and proj_out as one two-source GEMM (model.ff_fold = False / SEER_FF_FOLD=0: two launches; see _pack)
         self.ff_fold = bool(getattr(model, "ff_fold", os.environ.get("SEER_FF_FOLD", "1") != "0"))
+        # ... and, at 320 channels, the whole feed-forward with it as ONE launch (model.ff_fused = False / SEER_FF_FUSED=0: off)
+        self.ff_fused = self.ff_fold and bool(getattr(model, "ff_fused", os.environ.get("SEER_FF_FUSED", "1") != "0"))
         self.gn_from_colsums = 0
         self.w: Dict[str, torch.Tensor] = {}
         self._pack(sd)
@@ -331,6 +333,11 @@ class _Engine:
                 w2, b2 = f32(sd[tb + ".ff.net.2.weight"]), f32(sd[tb + ".ff.net.2.bias"])
                 w[pth + ".ffproj.w"] = torch.cat([wp, wp @ w2], dim=1).to(bf16).contiguous()           # [C, C + 4C]
                 w[pth + ".ffproj.b"] = (wp @ b2 + f32(sd[pth + ".proj_out.bias"])).contiguous()
+                # 320 channels: norm3, ff.net.0, GEGLU and this GEMM run as ONE launch (ops.ff_fused, csrc/ff_fused.hip), which reads
+                # both matrices in its own fragment order
+                if self.ff_fused and wp.shape[0] == getattr(self.ops, "FF_FUSED_C", -1) and (tb + ".norm3.weight") in sd:
+                    w[pth + ".ff_fused.w1f"], w[pth + ".ff_fused.wcf"] = self.ops.ff_fused_pack(
+                        w[tb + ".ff.net.0.proj.weight"], w[pth + ".ffproj.w"])
         # LayerNorm folded into the GEMM that consumes it (ops.fold_layernorm): W' = gamma (.) W from the fp32 weights, its row
         # sums and beta W^T + b, next to the plain weights (a launch that cannot fold runs layernorm + the plain ones)
         self.wln: Dict[str, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = {}
@@ -460,10 +467,20 @@ class _Engine:
         g = self._ln_gemm(h_rows, tb, ".norm3", tb + ".ff.net.0.proj.weight", tb + ".ff.net.0.proj.bias", geglu=True)
         ops.gemm(g, w[tb + ".ff.net.2.weight"], bias=w[tb + ".ff.net.2.bias"], residual=h_rows, out=h_rows)
 
+    def _ff_fused_rows(self, p, h):
+        """will _ff_proj_out run transformer `p`'s feed-forward over the rows of h as the fused launch?"""
+        M = h.shape[0]
+        return (p + ".ff_fused.w1f") in self.w and M % self.ops.FF_FUSED_ROWS == 0 and M >= self.ops.FF_FUSED_MIN_ROWS
+
     def _ff_proj_out(self, p, tb, h, x, cb):
         """the feed-forward of block `tb` and the transformer's proj_out + residual x: folded into one two-source GEMM when the
         block's weights were (see _pack), else ff.net.2 + residual and proj_out + residual as two launches"""
         ops, w = self.ops, self.w
+        if self._ff_fused_rows(p, h):
+            y = ops.ff_fused(h, x, w[tb + ".norm3.weight"], w[tb + ".norm3.bias"], w[p + ".ff_fused.w1f"],
+                             w[tb + ".ff.net.0.proj.bias"], w[p + ".ff_fused.wcf"], w[p + ".ffproj.b"], colsum_batch=cb)
+            if y is not None:
+                return y
         if (p + ".ffproj.w") in w:
             g = self._ln_gemm(h, tb, ".norm3", tb + ".ff.net.0.proj.weight", tb + ".ff.net.0.proj.bias", geglu=True)
             return ops.gemm(h, w[p + ".ffproj.w"], a2=g, bias=w[p + ".ffproj.b"], residual=x, colsum_batch=cb)
@@ -499,7 +516,9 @@ class _Engine:
         if self._attn_list is not None and p in self._attn_wanted:
             self._attn_list.append(self._cross_scores(q, kv[:, :C], B, Fr, H, W, heads, d, L))
         ops.attention(q, kv[:, :C], kv[:, C:], a, batch=B * Fr, heads=heads, head_dim=d, Sq=HW, Sk=L, q_prescaled=True)
-        ops.gemm(a, w[tb + ".attn2.to_out.0.weight"], bias=w[tb + ".attn2.to_out.0.bias"], residual=h, out=h, **self._rs())
+        # (the fused feed-forward normalises its rows itself: no row statistics asked of their producer)
+        ops.gemm(a, w[tb + ".attn2.to_out.0.weight"], bias=w[tb + ".attn2.to_out.0.bias"], residual=h, out=h,
+                 **({} if self._ff_fused_rows(p, h) else self._rs()))
         return self._ff_proj_out(p, tb, h, x, self._cb(B, Fr * HW))
 
     def _cross_scores(self, q, k, B, Fr, H, W, heads, d, L):
@@ -557,9 +576,10 @@ class _Engine:
             else:
                 ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], a, batch=B, heads=heads, head_dim=d,
                               Sq=Fr * HW, Sk=Fr * HW, causal=True, q_prescaled=True)
-        ops.gemm(a, w[tb + ".attn1.to_out.0.weight"], bias=w[tb + ".attn1.to_out.0.bias"], residual=h, out=h, **self._rs())
         # FF skips the conditioning frames (attention.py:241-246); frames are the slow index inside a batch element
         skip_f = cond_frame if self.shard is None else self.shard.local_cond_frames(cond_frame)
+        ops.gemm(a, w[tb + ".attn1.to_out.0.weight"], bias=w[tb + ".attn1.to_out.0.bias"], residual=h, out=h,
+                 **({} if skip_f <= 0 and self._ff_fused_rows(p, h) else self._rs()))
         if skip_f <= 0:
             return self._ff_proj_out(p, tb, h, x, self._cb(B, Fr * HW))
         elif skip_f < Fr:

@@ -1197,9 +1197,10 @@ def test_ff_fused_c320(device, M, B, strided):
     bcat = 0.2 * _rand((C,), device, 8)
     order = geglu_row_order(inner, device)
     w1p, b1p = w1[order].contiguous(), b1[order].contiguous()
+    w1f, wcf = ops.ff_fused_pack(w1p, wcat)
     arena = ops.FxArena(device, 1 << 16)
     arena.reset()
-    y = ops.ff_fused(h, x, gamma, beta, w1p, b1p, wcat, bcat, colsum_batch=(B, arena))
+    y = ops.ff_fused(h, x, gamma, beta, w1f, b1p, wcf, bcat, colsum_batch=(B, arena))
     assert y is not None and y.shape == (M, C)
     torch.cuda.synchronize()
     # (a) the formula
@@ -1223,9 +1224,18 @@ def test_ff_fused_c320(device, M, B, strided):
     yb = y.double().reshape(B, M // B, C)
     assert torch.allclose(tot[:, :, 0], yb.sum(1), rtol=0, atol=2e-2)
     assert torch.allclose(tot[:, :, 1], (yb * yb).sum(1), rtol=1e-5, atol=2e-2)
+    # the per-tile form of the same sums
+    yt = ops.ff_fused(h, x, gamma, beta, w1f, b1p, wcf, bcat, colsum_batch=B)
+    assert torch.equal(yt, y) and isinstance(yt.colsums, ops.ColSums) and yt.colsums.tiles == M // 96
+    tt = yt.colsums.buf.double().reshape(B, M // B // 96, C, 2).sum(1)
+    assert torch.allclose(tt[:, :, 0], yb.sum(1), rtol=0, atol=2e-2) and torch.allclose(tt[:, :, 1], (yb * yb).sum(1), rtol=1e-5, atol=2e-2)
+    stats = torch.empty((B, 32, 2), device=device)
+    ops.groupnorm_stats_from_colsums(yt.colsums, None, B, 32, stats)
+    want = torch.stack([yb.reshape(B, M // B, 32, 10).sum((1, 3)), (yb * yb).reshape(B, M // B, 32, 10).sum((1, 3))], -1)
+    assert torch.allclose(stats.double(), want, rtol=1e-4, atol=1e-1)
     # in place on the residual stream
     x2 = x.contiguous().clone()
-    y2 = ops.ff_fused(h, x2, gamma, beta, w1p, b1p, wcat, bcat, out=x2)
+    y2 = ops.ff_fused(h, x2, gamma, beta, w1f, b1p, wcf, bcat, out=x2)
     assert torch.equal(y2, y)
 
 

@@ -577,6 +577,38 @@ def test_context_length_and_batch(device, B, L):
     _check(y, O.unet_forward(sd, cfg, x, t, ctx, cond_frame=1), f"B={B} L={L}")
 
 
+def test_fused_feed_forward_switch(device, monkeypatch):
+    """320-channel transformer blocks of 6144 rows and more run norm3 -> ff.net.0 -> ff.net.2 -> proj_out (+ both residuals) as ONE
+    launch (ops.ff_fused; attention.py:231-248, 308-327, 742-747, 126, 141-145); model.ff_fused = False runs the launches it replaces.
+    Both land on the oracle, next to each other; smaller levels keep the unfused launches."""
+    from seervideoldm_amd import ops
+    cfg, sd, m = _model("mini", device)
+    x, ctx, t = _randn((2, 4, 3, 32, 32), 15), _randn((2, 3, 77, cfg["cross_attention_dim"]), 16), torch.tensor([500, 500])
+    ref = O.unet_forward(sd, cfg, x, t, ctx, cond_frame=0)
+    real, calls = ops.ff_fused, [0]
+
+    def counting(*a, **k):
+        y = real(*a, **k)
+        assert y is not None
+        calls[0] += 1
+        return y
+    monkeypatch.setattr(ops, "ff_fused", counting)
+    outs = {}
+    for on in (True, False):
+        m._engine = None
+        m.ff_fused = on
+        try:
+            outs[on] = m(x.to(device), t.to(device), ctx.to(device)).clone()
+        finally:
+            del m.ff_fused
+            m._engine = None
+        _check(outs[on], ref, f"unet ff_fused={on}")
+    # the 32x32 level holds 6144 rows: a text and a temporal block in 1 down + 2 up layers; 16x16 and below (1536 rows and fewer) stay unfused
+    assert calls[0] == 2 * (1 + 2), calls
+    rel = ((outs[True].float() - outs[False].float()).norm() / outs[False].float().norm()).item()
+    assert rel < 2e-2, rel
+
+
 def test_statistics_forms_fall_back_and_agree(device, monkeypatch):
     """The accumulated GroupNorm statistics and the folded LayerNorm are optimisations with fall-backs: an arena that runs out hands
     later producers the per-tile form (a GroupNorm whose two sources then disagree on the form takes the statistics pass), and every
