@@ -84,6 +84,5 @@ for blk in (0, 1):
         ch = s[6:63].reshape(19, 3)
         nxt = np.append(ch[1:, 0], s[63])
         d = np.stack([ch[:, 1] - ch[:, 0], ch[:, 2] - ch[:, 1], nxt - ch[:, 2]], 1)
-        print("    per iteration, ns (median over 19): H (5 K steps) %d | barrier %d | Y step with GEGLU in its shadow, g write %d | iteration %d"
-              % (*np.median(d, 0), np.median(d.sum(1))))
-        print("    iteration durations:", " ".join(str(v) for v in d.sum(1)))
+        print("    per iteration, ns (median over 19): H, two halves (first half's GEGLU beside the second) %d | barrier %d | "
+              "Y step with the second half's GEGLU, g write, next requests %d | iteration %d" % (*np.median(d, 0), np.median(d.sum(1))))

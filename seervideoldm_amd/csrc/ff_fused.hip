@@ -16,14 +16,17 @@
 //     FRAGMENT order (seer_ff_fused_pack_*): every load is one contiguous KiB per wave.  A wave holds its 20 W1 fragments of a chunk
 //     and its 10 [Wp | Wp W2] fragments in 120 registers; a fragment is requested again, for the NEXT chunk, as soon as its last
 //     MFMA has issued (a whole chunk of lead, ~1.5 us), and every wait is a constant count: the order of issue never changes;
-//   * per chunk: H = LN(h) W1c^T (12 MFMAs per 32 of k and wave), + b1, GEGLU in registers, g (96 x 64 bf16) into one of TWO 12 KB LDS
-//     panels, ONE barrier, Y += g Wc^T (30 MFMAs per 32 of k); the activation fragments come from LDS one sub step ahead of their MFMAs;
+//   * per chunk: H = LN(h) W1c^T in two halves of 48 rows (6 MFMAs per 32 of k, half and wave), + b1, GEGLU in registers beside the
+//     next half's MFMAs (plain fp32 instructions: packed ones stall MFMAs, profiles/r05_lab_mfma_valu.log), g (96 x 64 bf16) into one of
+//     TWO 12 KB LDS panels, ONE barrier, Y += g Wc^T (30 MFMAs per 32 of k); the activation fragments come from LDS three sub steps
+//     ahead of their MFMAs, every wait counted;
 //   * epilogue: x arrives in T by LDS-DMA under the last chunk, y leaves T as whole rows; the tile's column sums (sum, sum of
 //     squares of the stored bf16 values), added in 64-bit fixed point, for the GroupNorm that consumes the block's output.
 // LDS: 61 440 (T) + 2 x 12 288 (g) + 12 800 (gamma, beta, b1) = 98 816 bytes.  MFMAs are issued "swapped" (the weight fragment is the
 // A operand), so a lane holds 4 consecutive output columns of one row.
 #include "seer_common.h"
 #include <mutex>
+#include <utility>
 
 // measurement builds (scripts/lab_ff_probe.py): bit mask of what to LEAVE OUT of the chunk loop -- wrong results, timing only
 //   1 the W1 stream, 2 the [Wp | Wp W2] stream, 4 the MFMAs, 8 the GELU, 16 the activation fragment reads
@@ -124,8 +127,20 @@ __device__ __forceinline__ void a_req(AFrag& f, unsigned addr) {
 __device__ __forceinline__ void a_got(AFrag& f) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.r[0]), "+v"(f.r[1]), "+v"(f.r[2]), "+v"(f.r[3]), "+v"(f.r[4]), "+v"(f.r[5])::"memory");
 }
-__device__ __forceinline__ void lds_read16x2(unsigned addr, f32x4& a, f32x4& b) {      // a = [addr], b = [addr + 64]
-    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:64\n\ts_waitcnt lgkmcnt(0)" : "=&v"(a), "=&v"(b) : "v"(addr) : "memory");
+struct AHalf { u32x4 r[3]; };               // three row fragments (48 rows) of one sub step
+__device__ __forceinline__ void h_req(AHalf& f, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:2048\n\tds_read_b128 %2, %3 offset:4096"
+                 : "=&v"(f.r[0]), "=&v"(f.r[1]), "=&v"(f.r[2]) : "v"(addr) : "memory");
+}
+// N: LDS operations issued behind this fragment's three reads that may stay in flight (the LDS returns in order)
+template <int N = 0> __device__ __forceinline__ void h_got(AHalf& f) {
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(f.r[0]), "+v"(f.r[1]), "+v"(f.r[2]) : "n"(N) : "memory");
+}
+__device__ __forceinline__ void bias_req(unsigned addr, f32x4& a, f32x4& b) {          // a = [addr], b = [addr + 64]: two operations
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:64" : "=&v"(a), "=&v"(b) : "v"(addr) : "memory");
+}
+template <int N> __device__ __forceinline__ void bias_got(f32x4& a, f32x4& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
 }
 __device__ __forceinline__ bf16x8 as_bf(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
 
@@ -277,112 +292,161 @@ __global__ void __launch_bounds__(256, 1) seer_ff_fused_c320_kernel(const FfArgs
     FF_STAMP();                             // 4
 
     // ================= phase 2: the chunks of the inner dimension =================
-    // Iteration c: H(c) = LN(h) W1c^T; barrier (g(c - 1) is complete); Y += g(c - 1) Wc^T with GEGLU(c) in the shadow of its MFMAs;
-    // g(c) into the other panel.  Order of this wave's requests, per iteration c: W1(c + 1) steps 0..4 (4 each: a step is requested
-    // again as soon as its MFMAs have issued), then slice(c) of [Wp | Wp W2] (10: its registers are free once Y(c - 1) has issued).
-    // Behind W1(c) step ks are therefore: steps ks + 1..4 of chunk c, slice(c - 1), steps 0..ks - 1 of chunk c + 1 = 26 requests
-    // (chunk 0: 16, no slice yet); behind slice(c - 1): the five steps of W1(c + 1) = 20.  Past the end the W1 requests wrap to
-    // chunk 0: loads nobody uses, so that every count stays a constant and no register with a request in flight meets a branch.
-    AFrag a0, a1;
+    // Iteration c: H(c) = LN(h) W1c^T in two halves of 48 rows -- the GEGLU of the first half runs in the shadow of the second half's
+    // MFMAs; barrier (g(c - 1) is complete); Y += g(c - 1) Wc^T with the GEGLU of the second half in the shadow of its MFMAs; g(c) into
+    // the other panel.  (Plain fp32 instructions only: packed ones do not run beside MFMAs, profiles/r05_lab_mfma_valu.log.)
+    // Order of this wave's requests, per iteration c: W1(c + 1) steps 0..4 (4 each, during the second half: a step is requested again
+    // as soon as its last MFMAs have issued), then slice(c) of [Wp | Wp W2] (10: its registers are free once Y(c - 1) has issued).
+    // Behind W1(c) step ks, when the first half waits for it, are therefore: steps ks + 1..4 of chunk c and slice(c - 1) = 26 - 4 ks
+    // requests (chunk 0: 16 - 4 ks, no slice yet); behind slice(c - 1): the five steps of W1(c + 1) = 20.  Past the end the W1
+    // requests wrap to chunk 0: loads nobody uses, so that every count stays a constant and no register with a request in flight
+    // meets a branch.
     f32x4 H[6][2];
-    auto mfma_h = [&](const u32x4* w2, const AFrag& a) {
+    auto mfma_h3 = [&](const u32x4* w2, const AHalf& a, int i0) {
         if (FF_PROBE & 4) {
             for (int j = 0; j < 2; ++j) asm volatile("" ::"a"(w2[j]));
-            for (int i = 0; i < 6; ++i) asm volatile("" ::"v"(a.r[i]));
+            for (int i = 0; i < 3; ++i) asm volatile("" ::"v"(a.r[i]));
             return;
         }
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            H[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w2[0]), as_bf(a.r[i]), H[i][0], 0, 0, 0);
-            H[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w2[1]), as_bf(a.r[i]), H[i][1], 0, 0, 0);
+        for (int i = 0; i < 3; ++i) {
+            H[i0 + i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w2[0]), as_bf(a.r[i]), H[i0 + i][0], 0, 0, 0);
+            H[i0 + i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w2[1]), as_bf(a.r[i]), H[i0 + i][1], 0, 0, 0);
         }
     };
-    // H = LN(h) W1c^T: K step ks = sub steps (ks, 0), (ks, 1); a0 holds (0, 0) on entry; PEND: requests behind a step of this chunk
-    auto h_phase = [&](const unsigned char* w1_next, auto pend) {
+    // GEGLU of row fragment i of H: g = (value + b) * gelu(gate + b), bf16: columns 16 wave + 4 fq .. + 3 of row 16 i + frow
+    f32x4 bv, bg, bvp, bgp;                 // biases of this wave's value / gate columns 4 fq .. 4 fq + 3: this chunk's, the previous chunk's
+    auto geglu = [&](int i, const f32x4& b_val, const f32x4& b_gate) {
+        const f32x4 val = H[i][0] + b_val, gat = H[i][1] + b_gate;
+        float ge[4];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) { H[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; H[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-        for (int ks = 0; ks < FF_KS; ++ks) {
-            if (!(FF_PROBE & 16)) a_req(a1, T0 + ks * FF_PANEL + fo1);
-            got4<(FF_PROBE & 3) ? 0 : decltype(pend)::value>(w1r[ks]);
-            mfma_h(&w1r[ks].r[0], a0);
-            if (!(FF_PROBE & 16)) a_got(a1);
-            if (ks + 1 < FF_KS && !(FF_PROBE & 16)) a_req(a0, T0 + (ks + 1) * FF_PANEL + fo0);
-            mfma_h(&w1r[ks].r[2], a1);
-            if (!(FF_PROBE & 1)) req4(w1r[ks], voff, w1_next + ks * 4096);
-            if (ks + 1 < FF_KS && !(FF_PROBE & 16)) a_got(a0);
-        }
-    };
-    // GEGLU of row fragment i of H: g = (value + b) * gelu(gate + b), bf16, row 16 i + frow, columns 16 wave + 4 fq .. + 3 of panel gbuf
-    const unsigned gcol = (unsigned)(frow * 128 + (fq & 1) * 8);
-    const unsigned gchunk = (unsigned)(2 * wave + (fq >> 1));
-    auto geglu = [&](int i, const f32x4& bv, const f32x4& bg, unsigned gbuf) {
-        const f32x4 val = H[i][0] + bv, gat = H[i][1] + bg;
-        const f32x2 ge0 = (FF_PROBE & 8) ? f32x2{gat[0], gat[1]} : gelu_erf_f2(f32x2{gat[0], gat[1]});
-        const f32x2 ge1 = (FF_PROBE & 8) ? f32x2{gat[2], gat[3]} : gelu_erf_f2(f32x2{gat[2], gat[3]});
+        for (int e = 0; e < 4; ++e) ge[e] = (FF_PROBE & 8) ? gat[e] : gelu_erf_f(gat[e]);
         u32x2 o;
-        o[0] = pack2(val[0] * ge0[0], val[1] * ge0[1]);
-        o[1] = pack2(val[2] * ge1[0], val[3] * ge1[1]);
-        lds_write8(gbuf + i * 2048 + gcol + ((gchunk ^ swz) * 16), o);          // (16 i + frow) & 7 = frow & 7
+        o[0] = pack2(val[0] * ge[0], val[1] * ge[1]);
+        o[1] = pack2(val[2] * ge[2], val[3] * ge[3]);
+        return o;
     };
-    auto mfma_y_row = [&](const u32x4* w5, const AFrag& a, int i) {
+    const unsigned gcell = (unsigned)(frow * 128 + (fq & 1) * 8) + (((unsigned)(2 * wave + (fq >> 1)) ^ swz) * 16);   // (16 i + frow) & 7 = frow & 7
+    auto mfma_y_row = [&](const u32x4* w5, const u32x4& a, int i) {
         if (FF_PROBE & 4) {
             for (int j = 0; j < 5; ++j) asm volatile("" ::"v"(w5[j]));
-            asm volatile("" ::"v"(a.r[i]));
+            asm volatile("" ::"v"(a));
             return;
         }
 #pragma unroll
-        for (int j = 0; j < 5; ++j) Y[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w5[j]), as_bf(a.r[i]), Y[i][j], 0, 0, 0);
+        for (int j = 0; j < 5; ++j) Y[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w5[j]), as_bf(a), Y[i][j], 0, 0, 0);
+    };
+    // The two halves of H(c) = 20 sub steps j = (half, ks, k32) of 6 MFMAs.  The activation fragments of sub step j + 3 are requested
+    // before the MFMAs of sub step j (four buffers in rotation, three requests in flight, every wait counted: the LDS returns in order).
+    // On entry both bias sets and the fragments of sub steps 0, 1 and 2 have been requested (pa, pb, pc), in this order.
+    // ALL of the GEGLU runs beside these MFMAs: the first half (rows 0..47 -> H[0..2]) carries the GEGLU of the PREVIOUS chunk's rows
+    // 48..95 (H[3..5] still hold them; its g values go straight to the previous chunk's panel gprev), the second half the GEGLU of this
+    // chunk's rows 0..47 (ga: written behind the barrier, when the panel is free).  `first`: chunk 0 (no slice in flight, no previous chunk).
+    u32x2 ga[3];
+    AHalf pa, pb, pc, pd;
+    auto sub_addr = [&](int j) {            // LDS address of sub step j's fragments
+        const int half = j / 10, ks = (j % 10) >> 1, k32 = j & 1;
+        return T0 + ks * FF_PANEL + half * 6144 + (k32 ? fo1 : fo0);
+    };
+    auto h_phase = [&](const unsigned char* w1_next, unsigned gprev, auto first) {
+        constexpr bool FIRST = decltype(first)::value;
+        constexpr int SL = FIRST ? 0 : 10;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { H[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; H[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        auto step = [&](int j, AHalf& cur, AHalf& nxt3) {
+            const int half = j / 10, ks = (j % 10) >> 1, k32 = j & 1;
+            if (!(FF_PROBE & 16)) {
+                if (j + 2 < 20) h_got<6>(cur); else if (j + 1 < 20) h_got<3>(cur); else h_got<0>(cur);
+                if (j + 3 < 20) h_req(nxt3, sub_addr(j + 3));
+            }
+            if (j == 10) {
+#pragma unroll
+                for (int i = 3; i < 6; ++i) { H[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; H[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            }
+            if (half == 0 && k32 == 0) {
+                if (ks == 0) got4<(FF_PROBE & 3) ? 0 : 16 + SL>(w1r[0]);
+                if (ks == 1) got4<(FF_PROBE & 3) ? 0 : 12 + SL>(w1r[1]);
+                if (ks == 2) got4<(FF_PROBE & 3) ? 0 : 8 + SL>(w1r[2]);
+                if (ks == 3) got4<(FF_PROBE & 3) ? 0 : 4 + SL>(w1r[3]);
+                if (ks == 4) got4<(FF_PROBE & 3) ? 0 : 0 + SL>(w1r[4]);
+            }
+            mfma_h3(&w1r[ks].r[2 * k32], cur, 3 * half);
+            if (k32 == 1 && ks < 3) {
+                if (half == 0) { if (!FIRST) lds_write8(gprev + (3 + ks) * 2048 + gcell, geglu(3 + ks, bvp, bgp)); }
+                else ga[ks] = geglu(ks, bv, bg);
+            }
+            if (half == 1 && k32 == 1 && !(FF_PROBE & 1)) req4(w1r[ks], voff, w1_next + ks * 4096);
+        };
+        // four buffers in rotation: sub step j lives in buffer j mod 4 (pa, pb, pc, pd); on entry sub steps 0, 1, 2 are requested
+        step(0, pa, pd);
+        bias_got<9>(bv, bg);                // (older than sub step 0's fragments: in)
+        bias_got<9>(bvp, bgp);
+        step(1, pb, pa); step(2, pc, pb); step(3, pd, pc);
+#pragma unroll
+        for (int j = 4; j < 20; j += 4) {
+            step(j, pa, pd);
+            step(j + 1, pb, pa);
+            step(j + 2, pc, pb);
+            step(j + 3, pd, pc);
+        }
+    };
+    // requests at the end of an iteration, for the next chunk cn: its biases and this chunk's again (the next iteration finishes this
+    // chunk's GEGLU), then its first three sub steps
+    auto next_requests = [&](int cn, int c) {
+        bias_req(CST0 + (2 * FF_C + 128 * cn + 32 * wave + 4 * fq) * 4, bv, bg);
+        bias_req(CST0 + (2 * FF_C + 128 * c + 32 * wave + 4 * fq) * 4, bvp, bgp);
+        if (!(FF_PROBE & 16)) { h_req(pa, sub_addr(0)); h_req(pb, sub_addr(1)); h_req(pc, sub_addr(2)); }
+    };
+    // Y += g Wc^T over one chunk: the 12 fragments of the panel, 10 MFMAs per row fragment
+    auto y_phase = [&](unsigned gpanel, auto pend) {
+        AHalf q0, q1, q2, q3;               // rows 0..47 of k32 0, 1, then rows 48..95
+        if (!(FF_PROBE & 16)) { h_req(q0, gpanel + fo0); h_req(q1, gpanel + fo1); h_req(q2, gpanel + 6144 + fo0); h_req(q3, gpanel + 6144 + fo1); }
+        got10<(FF_PROBE & 3) ? 0 : decltype(pend)::value>(wcr);
+        if (!(FF_PROBE & 16)) { h_got<6>(q0); h_got<6>(q1); }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { mfma_y_row(&wcr.r[0], q0.r[i], i); mfma_y_row(&wcr.r[5], q1.r[i], i); }
+        if (!(FF_PROBE & 16)) { h_got<0>(q2); h_got<0>(q3); }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { mfma_y_row(&wcr.r[0], q2.r[i], 3 + i); mfma_y_row(&wcr.r[5], q3.r[i], 3 + i); }
     };
 
-    a_req(a0, T0 + fo0);
-    a_got(a0);
+    next_requests(0, 0);
     FF_STAMP();                             // 5
     // ---- chunk 0: nothing to multiply yet
     {
-        h_phase(w1_wave + (int64_t)1 * 4 * FF_W1_BLOCK, IntTag<16>{});
-        f32x4 bv, bg;                       // biases of this wave's value / gate columns 4 fq .. 4 fq + 3 (packed order: 16 | 16)
-        lds_read16x2(CST0 + (2 * FF_C + 32 * wave + 4 * fq) * 4, bv, bg);
+        h_phase(w1_wave + (int64_t)1 * 4 * FF_W1_BLOCK, G0, IntTag<1>{});
 #pragma unroll
-        for (int i = 0; i < 6; ++i) geglu(i, bv, bg, G0);
+        for (int i = 0; i < 3; ++i) lds_write8(G0 + i * 2048 + gcell, ga[i]);
         if (!(FF_PROBE & 2)) req10(wcr, voff, wc_wave + (int64_t)(FF_KS + 0) * 4 * FF_WC_BLOCK);
-        if (!(FF_PROBE & 16)) { a_req(a0, T0 + fo0); a_got(a0); }
+        next_requests(1, 0);
     }
 #pragma unroll 1
     for (int c = 1; c < FF_NCHUNK; ++c) {
         FF_STAMP();                         // 6 + 3 (c - 1)
         const int cn = c + 1 < FF_NCHUNK ? c + 1 : 0;
-        h_phase(w1_wave + (int64_t)cn * 4 * FF_W1_BLOCK, IntTag<26>{});
+        const unsigned gprev = G0 + ((c - 1) & 1) * FF_PANEL, gbuf = G0 + (c & 1) * FF_PANEL;
+        h_phase(w1_wave + (int64_t)cn * 4 * FF_W1_BLOCK, gprev, IntTag<0>{});
         FF_STAMP();                         // + 1: H done
         barrier_lds();                      // g(c - 1) complete; every wave is past Y(c - 2), the last reader of the panel g(c) goes to
         FF_STAMP();                         // + 2
-        const unsigned gprev = G0 + ((c - 1) & 1) * FF_PANEL, gbuf = G0 + (c & 1) * FF_PANEL;
-        if (!(FF_PROBE & 16)) { a_req(a0, gprev + fo0); a_req(a1, gprev + fo1); }
-        f32x4 bv, bg;
-        lds_read16x2(CST0 + (2 * FF_C + 128 * c + 32 * wave + 4 * fq) * 4, bv, bg);        // (waits for the fragments too)
-        if (!(FF_PROBE & 16)) { a_got(a0); a_got(a1); }
-        got10<(FF_PROBE & 3) ? 0 : 20>(wcr);
-        // Y += g(c - 1) Wc^T, 5 MFMAs per row fragment, and GEGLU(c) between them
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            mfma_y_row(&wcr.r[0], a0, i);
-            mfma_y_row(&wcr.r[5], a1, i);
-            geglu(i, bv, bg, gbuf);
-        }
+        y_phase(gprev, IntTag<20>{});       // behind slice(c - 1): the five steps of W1(c + 1)
         if (!(FF_PROBE & 2)) req10(wcr, voff, wc_wave + (int64_t)(FF_KS + c) * 4 * FF_WC_BLOCK);
-        if (!(FF_PROBE & 16)) { a_req(a0, T0 + fo0); a_got(a0); }             // the next chunk's first activation fragments
+#pragma unroll
+        for (int i = 0; i < 3; ++i) lds_write8(gbuf + i * 2048 + gcell, ga[i]);
+        next_requests(cn, c);
     }
     FF_STAMP();                             // 63
-    // ---- the last chunk's product; x rides in under it (T is free: every wave is past its last H at the barrier)
+    // ---- the last chunk: the GEGLU of its rows 48..95, its product; x rides in under it (T is free: every wave is past its last H
+    // at the barrier)
     {
+        // (the requests for a chunk past the end are in flight: their registers stay theirs until this wait)
+        h_got<0>(pa); h_got<0>(pb); h_got<0>(pc); bias_got<0>(bv, bg); bias_got<0>(bvp, bgp);
+        const unsigned glast = G0 + ((FF_NCHUNK - 1) & 1) * FF_PANEL;
+#pragma unroll
+        for (int i = 3; i < 6; ++i) lds_write8(glast + i * 2048 + gcell, geglu(i, bvp, bgp));
         barrier_lds();
         load_tile(p.x, p.ldx);
-        const unsigned gprev = G0 + ((FF_NCHUNK - 1) & 1) * FF_PANEL;
-        a_req(a0, gprev + fo0); a_req(a1, gprev + fo1);
-        a_got(a0); a_got(a1);
-        got10<15>(wcr);                     // behind the slice: the x tile's 15 pieces (the wrapped W1 requests are older)
-#pragma unroll
-        for (int i = 0; i < 6; ++i) { mfma_y_row(&wcr.r[0], a0, i); mfma_y_row(&wcr.r[5], a1, i); }
+        y_phase(glast, IntTag<15>{});       // behind the slice: the x tile's 15 pieces (the wrapped W1 requests are older)
     }
 
     // ================= phase 3: y = Y + bias + x, through T; column sums of the tile =================
