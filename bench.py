@@ -394,7 +394,7 @@ def main():
         # scripts/pmc_summary.py; PMC cannot be collected from inside this process)
         # (scripts/pmc_step.py -> scripts/pmc_summary.py; PMC cannot be collected from inside this process).  The file carries
         # the digest of the library build it was taken on: a stale file is refused, not quoted.
-        traffic, traffic_note = None, None
+        traffic, traffic_note, ff_traffic = None, None, None
         try:
             if args.workload != "sthv2":
                 raise OSError("the PMC passes were taken on the default workload")
@@ -404,6 +404,7 @@ def main():
                 raise ValueError(f"{PMC_TRAFFIC_FILE} was taken on library build {str(pmc.get('build_sha256'))[:12]}, this is "
                                  f"{built[:12]}")
             traffic = round(pmc["kernels"]["seer_gemm_kernel"]["hbm_bytes_per_launch"])
+            ff_traffic = pmc["kernels"].get("seer_ff_fused_c320_kernel", {}).get("hbm_bytes_per_launch")
         except (OSError, KeyError, ValueError) as e:
             traffic_note = str(e)[:200]
         attn_block = time_attention_block(device)
@@ -414,7 +415,8 @@ def main():
         for tag, calls, ms, _tf in timed.shape_summary():
             if tag.startswith("attn b24 Sq1024 Sk1024 d40"):
                 attn_block["in_step_us"] = round(ms / calls * 1e3, 2)
-        roofline = dict(bound="mfma", kernel="seer_gemm_kernel (bf16 MFMA GEMM / implicit-GEMM conv3x3, all tiles)",
+        roofline = dict(bound="mfma", kernel="seer_gemm_kernel (bf16 MFMA GEMM / implicit-GEMM conv3x3, all tiles; the class also holds the "
+                                             "ten seer_ff_fused_c320_kernel launches, accounted with the MACs of the two GEMMs each contains)",
                         achieved=round(gm["tflops"], 2), peak=MFMA_BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=round(gm["tflops"] / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), traffic=traffic,
                         traffic_unit="bytes beyond L2 per launch (2*FETCH_SIZE + WRITE_SIZE, PMC)",
@@ -431,6 +433,15 @@ def main():
                         rows=timed.family_rows(reps, MFMA_BF16_DENSE_PEAK_TFLOPS, HBM_PEAK_GBS))
         if traffic_note:
             roofline["traffic_note"] = traffic_note
+        for r in roofline["rows"]:
+            if r["name"].startswith("fused feed-forward"):
+                # norm3 -> ff.net.0 (GEGLU) -> [proj_out | proj_out ff.net.2] + both residuals as one launch (csrc/ff_fused.hip)
+                roofline["fused_feed_forward"] = dict(
+                    kernel="seer_ff_fused_c320_kernel", launches_per_step=r["launches"], us_per_launch=r["us"], frac_mfma=r["frac_mfma"],
+                    algorithmic_bytes_per_launch=2 * (3 * 24576 * 320 + 2560 * 320 + 320 * 1600) if r["name"].endswith("L0") else None,
+                    traffic=round(ff_traffic) if ff_traffic else None,
+                    replaces="layernorm + ff.net.0 GEGLU GEMM + [proj_out | proj_out ff.net.2] GEMM: 9.7 + 53.0 + 39.4 us per block "
+                             "(profiles/r05_bench_before_ff_fused.json.log)")
 
     # ---- end-to-end clip latency: 50 DDIM steps + frozen VAE decode of the 10 predicted frames
     clip = None

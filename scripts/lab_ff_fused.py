@@ -60,3 +60,8 @@ for name, fn in (("layernorm + GEGLU projection + [proj_out | proj_out ff.net.2]
     print(f"{name:70s} {us:8.2f} us   {flop / us * 1e-6:7.1f} TFLOP/s   ({flop / us * 1e-6 / 2500:.3f} of the dense bf16 peak)")
 ya, yb = unfused().float(), fused().float()
 print("rel diff fused vs unfused:", ((ya - yb).norm() / ya.norm()).item())
+# where the fused launch wins: a workgroup owns 96 rows for the whole launch, so its time steps with ceil(rows / 96 / 256 CUs)
+print("rows     workgroups   three launches us   fused us")
+for Mr in (6144, 12288, 18432, 24576, 36864, 49152, 98304):
+    h, x = r(Mr, C).to(bf16), r(Mr, C).to(bf16)
+    print(f"{Mr:6d}   {Mr // 96:6d}       {timed(unfused, 20):10.2f}      {timed(fused, 20):8.2f}")

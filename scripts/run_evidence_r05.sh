@@ -28,6 +28,11 @@ build/lab_gemm 20 > $O/r05_lab_gemm_step_table.log 2>&1
 LAB_MMUL=4 build/lab_gemm 10 > $O/r05_lab_gemm_step_table_config4.log 2>&1
 build/lab_attn 30 > $O/r05_lab_attn.log 2>&1
 python scripts/bench_vendor_gemm.py > $O/r05_vendor_gemm_calibration.log 2>&1
+# 4b. the fused feed-forward launch: against the launches it replaces, with parts of it left out, its timeline; what one SIMD sustains
+python scripts/lab_ff_fused.py > $O/r05_lab_ff_fused.log 2>&1
+python scripts/lab_ff_probe.py 0 1 2 3 4 8 16 20 23 31 > $O/r05_lab_ff_probe.log 2>&1
+hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -mllvm -amdgpu-mfma-vgpr-form=1 scripts/lab_mfma_valu.cpp -o build/lab_mfma_valu 2>/dev/null && build/lab_mfma_valu > $O/r05_lab_mfma_valu.log 2>&1
+hipcc --offload-arch=gfx950 -O3 -Wno-unused-value scripts/lab_mfma_lds.cpp -o build/lab_mfma_lds 2>/dev/null && build/lab_mfma_lds > $O/r05_lab_mfma_lds.log 2>&1
 python scripts/exp_shard_sizes.py > $O/r05_shard_sizes.log 2>&1
 # 5. the other configurations
 for w in bridge sthv2_512 sthv2_14 bridge_17; do

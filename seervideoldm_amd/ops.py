@@ -594,9 +594,11 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
 
 
 FF_FUSED_C, FF_FUSED_ROWS = 320, 96
-# the engine takes the fused launch from this many rows up (64 workgroups): below, the launches it replaces are as fast, and a CFG pair
-# evaluated as one batch or as two calls then runs the SAME kernels at every level (bit-equal rows: ddim_video.py:205-207's two branches)
-FF_FUSED_MIN_ROWS = 6144
+# the engine takes the fused launch from this many rows up: a workgroup owns 96 rows for the whole launch, so the launch takes as long
+# at 64 workgroups as at 256 (74 us) -- from 192 workgroups (three quarters of the CUs) up it is ahead of the launches it replaces
+# (102 us at 24 576 rows, ~55 us at 12 288: a CFG half per rank keeps those).  Below, a CFG pair evaluated as one batch or as two calls
+# also runs the SAME kernels at every level (ddim_video.py:205-207's two branches stay bit-equal per row).
+FF_FUSED_MIN_ROWS = 18432
 
 
 def ff_fused_pack(w1: torch.Tensor, wcat: torch.Tensor):

@@ -45,7 +45,7 @@ def gemm(a, w, *, bias=None, residual=None, rowvec=None, rows_per_batch=0, a2=No
     return out
 
 
-FF_FUSED_C, FF_FUSED_ROWS, FF_FUSED_MIN_ROWS = 320, 96, 6144
+FF_FUSED_C, FF_FUSED_ROWS, FF_FUSED_MIN_ROWS = 320, 96, 18432
 
 
 def ff_fused_pack(w1, wcat):
