@@ -332,12 +332,12 @@ int seer_groupnorm_stats_fx(const void* x, int32_t C, int32_t batch, int64_t row
  *     y = x + [Wp | Wp W2] [h | g] + bcat,   g = GEGLU(LayerNorm(h; gamma, beta, eps) W1^T + b1)
  * i.e. norm3 -> ff.net.0 -> ff.net.2 + residual -> proj_out + residual (seer/models/attention.py:231-248, 308-327, 742-747,
  * 783-793, 126, 141-145).  h, x, y: [M][320] bf16 with row strides ldh, ldx, ldy (elements, multiples of 8; y may alias x);
- * M a multiple of 96.  w1f, wcf: the two weight matrices in the kernel's FRAGMENT order, made once by the pack entry points below from
+ * a workgroup owns 96 rows (the last one fewer when M is not a multiple).  w1f, wcf: the two weight matrices in the kernel's FRAGMENT order, made once by the pack entry points below from
  * w1 [2560][320] bf16 (interleaved GEGLU row order: 16 value rows, 16 gate rows, ...) and wcat [320][1600] bf16 = [Wp | Wp W2];
  * b1 [2560] fp32 in the same interleaved order; bcat [320] fp32 = Wp b2 + bp.  colsum_fx (or NULL): [fx_reps][M / fx_rows][2][320]
- * int64, ADDED to, the fixed-point column sums of y as seer_gemm_desc::colsum_fx (fx_rows = rows per batch element, a multiple of 96).
- * colsum_tiles (or NULL): [M / 96][320][2] fp32, WRITTEN, (sum, sum of squares) of the stored values per 96-row tile as
- * seer_gemm_desc::colsum.  All pointers 16-byte aligned.  SEER_EINVAL otherwise. */
+ * int64, ADDED to, the fixed-point column sums of y as seer_gemm_desc::colsum_fx (fx_rows = rows per batch element, a multiple of
+ * 16 and at least 96: a tile may straddle two batch elements).  colsum_tiles (or NULL; M a multiple of 96): [M / 96][320][2] fp32,
+ * WRITTEN, (sum, sum of squares) of the stored values per 96-row tile as seer_gemm_desc::colsum.  All pointers 16-byte aligned.  SEER_EINVAL otherwise. */
 int seer_ff_fused_c320(const void* h, int32_t ldh, const void* x, int32_t ldx, void* y, int32_t ldy, int64_t M,
                        const float* gamma, const float* beta, float eps, const void* w1f, const float* b1, const void* wcf,
                        const float* bcat, int64_t* colsum_fx, int64_t fx_rows, int32_t fx_reps, float* colsum_tiles, void* stream);

@@ -72,7 +72,7 @@ struct FfArgs {
     const unsigned char* w1f; const float* b1;      // W1 in fragment order (seer_ff_fused_pack_w1), its bias in the packed GEGLU order
     const unsigned char* wcf; const float* bcat;    // [Wp | Wp W2] in fragment order (seer_ff_fused_pack_wcat), Wp b2 + bp
     int64_t* colsum_fx;                     // [reps][M / fx_rows][2][FF_C] fixed-point column sums (seer_gemm_desc::colsum_fx) or NULL
-    int fx_rows, fx_reps;                   // rows per batch element (a multiple of 96), replicas
+    int fx_rows, fx_reps;                   // rows per batch element (a multiple of 16, at least 96), replicas
     float* colsum_tiles;                    // [M / 96][FF_C][2] fp32 per-tile column sums (seer_gemm_desc::colsum) or NULL
 };
 
@@ -164,7 +164,8 @@ __global__ void __launch_bounds__(256, 1) seer_ff_fused_c320_kernel(const FfArgs
 #pragma unroll
         for (int i = 0; i < 15; ++i) {
             const int q = wave * 15 + i, pnl = q / 12, rg = q - pnl * 12;
-            const bf16* s = src + (int64_t)(m0 + rg * 8 + drow) * ld + pnl * 64 + dchunk;
+            const int m = min(m0 + rg * 8 + drow, p.M - 1);            // (a ragged last tile reads its last row again)
+            const bf16* s = src + (int64_t)m * ld + pnl * 64 + dchunk;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
                                              (__attribute__((address_space(3))) void*)(T + pnl * FF_PANEL + rg * 1024), 16, 0, 0);
         }
@@ -480,7 +481,7 @@ __global__ void __launch_bounds__(256, 1) seer_ff_fused_c320_kernel(const FfArgs
     for (int i = 0; i < 15; ++i) {
         const int q = wave * 15 + i, pnl = q / 12, rg = q - pnl * 12;
         const u32x4 v = *reinterpret_cast<const u32x4*>(T + pnl * FF_PANEL + rg * 1024 + lane * 16);
-        store16_out(p.y + (int64_t)(m0 + rg * 8 + drow) * p.ldy + pnl * 64 + dchunk, v);
+        if (m0 + rg * 8 + drow < p.M) store16_out(p.y + (int64_t)(m0 + rg * 8 + drow) * p.ldy + pnl * 64 + dchunk, v);
     }
     FF_STAMP();                             // 66: rows stored
     if (p.colsum_fx || p.colsum_tiles) {
@@ -493,7 +494,8 @@ __global__ void __launch_bounds__(256, 1) seer_ff_fused_c320_kernel(const FfArgs
 #pragma unroll
             for (int e = 0; e < 8; ++e) sm[e] = sq[e] = 0.f;
             const int pnl = cc >> 3, ch = cc & 7;
-            for (int r = 0; r < 16; ++r) {
+            const int valid = min(16, p.M - m0 - 16 * s6);   // rows of this segment inside the tensor (a ragged last tile)
+            for (int r = 0; r < valid; ++r) {
                 const int row = 16 * s6 + r;
                 const u32x4 v = *reinterpret_cast<const u32x4*>(T + pnl * FF_PANEL + row * 128 + ((ch ^ (row & 7)) * 16));
                 float f[8];
@@ -508,14 +510,24 @@ __global__ void __launch_bounds__(256, 1) seer_ff_fused_c320_kernel(const FfArgs
             }
         }
         __syncthreads();
+        // a tile may straddle two batch elements (their boundary is a multiple of 16 rows: between two segments): the segments of the
+        // first go to its slot, the rest to the next one's
         const int nb = p.colsum_fx ? p.M / p.fx_rows : 1;
-        int64_t* dst = p.colsum_fx ? p.colsum_fx + (int64_t)((((int)blockIdx.x % p.fx_reps) * nb + m0 / p.fx_rows) * 2) * FF_C : nullptr;
+        const int b0 = p.colsum_fx ? m0 / p.fx_rows : 0;
+        const int s_split = p.colsum_fx ? min(6, ((b0 + 1) * p.fx_rows - m0) / 16) : 6;      // segments [0, s_split) belong to b0
+        int64_t* dst = p.colsum_fx ? p.colsum_fx + (int64_t)((((int)blockIdx.x % p.fx_reps) * nb + b0) * 2) * FF_C : nullptr;
         for (int i = tid; i < 2 * FF_C; i += 256) {         // i = plane * 320 + column
             const int col = i < FF_C ? i : i - FF_C, pl = i < FF_C ? 0 : 1;
-            float t = 0.f;
+            float t = 0.f, t1 = 0.f;
 #pragma unroll
-            for (int s = 0; s < 6; ++s) t += part[(s * FF_C + col) * 2 + pl];
-            if (dst) fx_add(dst + i, t);
+            for (int s = 0; s < 6; ++s) {
+                const float v = part[(s * FF_C + col) * 2 + pl];
+                if (s < s_split) t += v; else t1 += v;
+            }
+            if (dst) {
+                fx_add(dst + i, t);
+                if (s_split < 6 && b0 + 1 < nb) fx_add(dst + 2 * FF_C + i, t1);
+            }
             if (p.colsum_tiles) p.colsum_tiles[((int64_t)blockIdx.x * FF_C + col) * 2 + pl] = t;
         }
     }
@@ -568,11 +580,12 @@ extern "C" int seer_ff_fused_c320(const void* h, int32_t ldh, const void* x, int
                                   const float* bcat, int64_t* colsum_fx, int64_t fx_rows, int32_t fx_reps, float* colsum_tiles,
                                   void* stream) {
     if (!h || !x || !y || !gamma || !beta || !w1f || !b1 || !wcf || !bcat) return SEER_EINVAL;
-    if (M <= 0 || M % FF_BM || ldh % 8 || ldx % 8 || ldy % 8 || ldh < FF_C || ldx < FF_C || ldy < FF_C) return SEER_EINVAL;
+    if (M <= 0 || M >= ((int64_t)1 << 31) - FF_BM || ldh % 8 || ldx % 8 || ldy % 8 || ldh < FF_C || ldx < FF_C || ldy < FF_C) return SEER_EINVAL;
     if ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(w1f) |
          reinterpret_cast<uintptr_t>(wcf) | reinterpret_cast<uintptr_t>(b1) | reinterpret_cast<uintptr_t>(bcat) |
          reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) return SEER_EINVAL;
-    if (colsum_fx && (fx_rows <= 0 || fx_rows % FF_BM || M % fx_rows || fx_reps <= 0)) return SEER_EINVAL;
+    if (colsum_fx && (fx_rows < FF_BM || fx_rows % 16 || M % fx_rows || fx_reps <= 0)) return SEER_EINVAL;
+    if (colsum_tiles && M % FF_BM) return SEER_EINVAL;
     std::call_once(g_ff_once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_ff_fused_c320_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
     });
@@ -582,7 +595,7 @@ extern "C" int seer_ff_fused_c320(const void* h, int32_t ldh, const void* x, int
     a.gamma = gamma; a.beta = beta; a.eps = eps;
     a.w1f = reinterpret_cast<const unsigned char*>(w1f); a.b1 = b1; a.wcf = reinterpret_cast<const unsigned char*>(wcf); a.bcat = bcat;
     a.colsum_fx = colsum_fx; a.fx_rows = (int)fx_rows; a.fx_reps = fx_reps; a.colsum_tiles = colsum_tiles;
-    hipLaunchKernelGGL(seer_ff_fused_c320_kernel, dim3((unsigned)(M / FF_BM)), dim3(256), FF_LDS, reinterpret_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(seer_ff_fused_c320_kernel, dim3((unsigned)((M + FF_BM - 1) / FF_BM)), dim3(256), FF_LDS, reinterpret_cast<hipStream_t>(stream), a);
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }

@@ -594,11 +594,20 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
 
 
 FF_FUSED_C, FF_FUSED_ROWS = 320, 96
-# the engine takes the fused launch from this many rows up: a workgroup owns 96 rows for the whole launch, so the launch takes as long
-# at 64 workgroups as at 256 (74 us) -- from 192 workgroups (three quarters of the CUs) up it is ahead of the launches it replaces
-# (102 us at 24 576 rows, ~55 us at 12 288: a CFG half per rank keeps those).  Below, a CFG pair evaluated as one batch or as two calls
-# also runs the SAME kernels at every level (ddim_video.py:205-207's two branches stay bit-equal per row).
+# The engine takes the fused launch where its workgroups fill the chip: a workgroup owns 96 rows for the whole launch, so a launch
+# takes rounds x 74 us, rounds = ceil(workgroups / CUs), whatever the last round holds -- from three quarters of the slots up it is
+# ahead of the launches it replaces (scripts/lab_ff_fused.py: 24 576 rows 89 against 103 us, 18 432 rows 80 / 86, 12 288 rows 73 / 66,
+# 36 864 rows 151 / 149, 98 304 rows 303 / 399).  A CFG half per rank (12 288 rows) keeps the three launches, and a CFG pair
+# evaluated as one batch or as two calls runs the SAME kernels at every level (ddim_video.py:205-207's two branches).
 FF_FUSED_MIN_ROWS = 18432
+FF_FUSED_MIN_FILL = 0.74
+
+
+def ff_fused_pays(rows: int, n_cu: int = 256) -> bool:
+    if rows < FF_FUSED_MIN_ROWS:
+        return False
+    wgs = -(-rows // FF_FUSED_ROWS)
+    return wgs / (n_cu * -(-wgs // n_cu)) >= FF_FUSED_MIN_FILL
 
 
 def ff_fused_pack(w1: torch.Tensor, wcat: torch.Tensor):
@@ -618,9 +627,10 @@ def ff_fused(h: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, beta: torch.
     """y = x + [Wp | Wp W2] [h | GEGLU(LayerNorm(h) W1^T + b1)] + bcat as ONE launch (seer_ff_fused_c320): the feed-forward of a
     transformer block and the transformer's proj_out with both residual adds, at the 320-channel level.  w1f, wcf from
     ff_fused_pack; b1 in the interleaved GEGLU row order, bcat = Wp b2 + bp.  colsum_batch as in gemm(): (B, arena) -> out.colsums =
-    the ColSumsFx of y, B -> the per-tile ColSums (96-row tiles).  Returns None (nothing launched) when the shape is not the kernel's: C = 320, rows a multiple of 96."""
+    the ColSumsFx of y, B -> the per-tile ColSums (96-row tiles; only where no tile straddles two batch elements).  Returns None
+    (nothing launched) when the shape is not the kernel's: C = 320."""
     M, Cc = h.shape
-    if Cc != FF_FUSED_C or M % FF_FUSED_ROWS or M == 0:
+    if Cc != FF_FUSED_C or M == 0:
         return None
     _req(h, bf16, "h"); _req(x, bf16, "x"); _req(w1f, bf16, "w1f"); _req(wcf, bf16, "wcf")
     assert x.shape == h.shape and h.stride(1) == 1 and x.stride(1) == 1
@@ -631,12 +641,12 @@ def ff_fused(h: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, beta: torch.
         out = torch.empty((M, Cc), device=h.device, dtype=bf16)
     fx, fx_rows, cs, tiles = None, 0, None, None
     B, arena = colsum_batch if isinstance(colsum_batch, tuple) else (colsum_batch, None)
-    if B > 0 and M % B == 0 and (M // B) % FF_FUSED_ROWS == 0:
-        if arena is not None:
+    if B > 0 and M % B == 0:
+        if arena is not None and (M // B) % 16 == 0 and M // B >= FF_FUSED_ROWS:
             fx = arena.take(8, B, Cc)
         if fx is not None:
             fx_rows, cs = M // B, ColSumsFx(fx, Cc)
-        else:
+        elif (M // B) % FF_FUSED_ROWS == 0:
             tiles = torch.empty((1, M // FF_FUSED_ROWS, Cc, 2), device=h.device, dtype=torch.float32)
             cs = ColSums(tiles, Cc, 1, M // FF_FUSED_ROWS)
     check(_lib.load().seer_ff_fused_c320(_p(h), h.stride(0), _p(x), x.stride(0), _p(out), out.stride(0), M, _p(gamma), _p(beta),

@@ -469,8 +469,7 @@ class _Engine:
 
     def _ff_fused_rows(self, p, h):
         """will _ff_proj_out run transformer `p`'s feed-forward over the rows of h as the fused launch?"""
-        M = h.shape[0]
-        return (p + ".ff_fused.w1f") in self.w and M % self.ops.FF_FUSED_ROWS == 0 and M >= self.ops.FF_FUSED_MIN_ROWS
+        return (p + ".ff_fused.w1f") in self.w and self.ops.ff_fused_pays(h.shape[0])
 
     def _ff_proj_out(self, p, tb, h, x, cb):
         """the feed-forward of block `tb` and the transformer's proj_out + residual x: folded into one two-source GEMM when the

@@ -48,13 +48,18 @@ def gemm(a, w, *, bias=None, residual=None, rowvec=None, rows_per_batch=0, a2=No
 FF_FUSED_C, FF_FUSED_ROWS, FF_FUSED_MIN_ROWS = 320, 96, 18432
 
 
+def ff_fused_pays(rows, n_cu=256):
+    wgs = -(-rows // FF_FUSED_ROWS)
+    return rows >= FF_FUSED_MIN_ROWS and wgs / (n_cu * -(-wgs // n_cu)) >= 0.74
+
+
 def ff_fused_pack(w1, wcat):
     return torch.empty_like(w1), torch.empty_like(wcat)
 
 
 def ff_fused(h, x, gamma, beta, w1f, b1, wcf, bcat, *, eps=1e-5, out=None, colsum_batch=0):
     M, Cc = h.shape
-    if Cc != FF_FUSED_C or M % FF_FUSED_ROWS or M == 0:
+    if Cc != FF_FUSED_C or M == 0:
         return None
     out = torch.empty((M, Cc), dtype=bf16, device=h.device)
     out.colsums = None

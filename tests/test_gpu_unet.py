@@ -581,9 +581,9 @@ def test_fused_feed_forward_switch(device, monkeypatch):
     """320-channel transformer blocks with enough rows run norm3 -> ff.net.0 -> ff.net.2 -> proj_out (+ both residuals) as ONE
     launch (ops.ff_fused; attention.py:231-248, 308-327, 742-747, 126, 141-145); model.ff_fused = False runs the launches it replaces.
     Both land on the oracle, next to each other; smaller levels keep the unfused launches.  (The row threshold is lowered here so
-    that the small test network takes the fused launch at its finest level; the full-size tests take it at ops.FF_FUSED_MIN_ROWS.)"""
+    that the small test network takes the fused launch at its finest level; the full-size tests take it by ops.ff_fused_pays.)"""
     from seervideoldm_amd import ops
-    monkeypatch.setattr(ops, "FF_FUSED_MIN_ROWS", 6144)
+    monkeypatch.setattr(ops, "ff_fused_pays", lambda rows, n_cu=256: rows >= 6144)
     cfg, sd, m = _model("mini", device)
     x, ctx, t = _randn((2, 4, 3, 32, 32), 15), _randn((2, 3, 77, cfg["cross_attention_dim"]), 16), torch.tensor([500, 500])
     ref = O.unet_forward(sd, cfg, x, t, ctx, cond_frame=0)
