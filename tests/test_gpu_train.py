@@ -1,11 +1,18 @@
-"""The training step on a real MI355X: seervideoldm_amd.trainer.SeerTrainer over libseer_hip.so against autograd of the CPU
-oracle (oracle/seer_oracle.py::train_loss_and_grads, itself pinned to the reference's step by tests/golden/train_tiny.npz)
-on the same seeded weights and inputs.  Tolerances are relative L2 over all trainable tensors: bf16 activations and bf16
-P / dS inside the attention backward give 1-3e-2."""
+"""The training step on a real MI355X: seervideoldm_amd.trainer.SeerTrainer over libseer_hip.so against the step of the REAL
+reference (torch autograd over its SeerUNet / FSTextTransformer, run once in the build container: oracle/make_goldens_train.py ->
+tests/golden/train_*.npz: loss, prediction, and a sketch of every gradient tensor) on the same seeded weights and inputs.  (The
+case at the real widths with one layer per block is not a configuration the reference can build; its fixture comes from the CPU
+restatement, which tests/test_oracle_golden.py checks against the reference-made cases.)  No fp32 autograd runs on the GPU box's
+host.  Tolerances are relative L2 over all trainable tensors: bf16 activations and bf16 P / dS inside the attention backward
+give 1-3e-2."""
+from pathlib import Path
+
+import numpy as np
 import pytest
 import torch
 
 from oracle import seer_oracle as O
+from oracle.sketch import sketch_errors
 from seervideoldm_amd import FSTextTransformer, SeerUNet, synth
 from seervideoldm_amd.trainer import SeerTrainer
 
@@ -22,47 +29,57 @@ def _randn(shape, seed):
 
 
 def _models(cfg, device):
-    usd = synth.synth_state_dict(synth.unet_param_shapes(cfg))
-    fsd = synth.synth_state_dict(synth.fstext_param_shapes(**FS))
-    unet = SeerUNet(**cfg)
+    """(the closed-form weights are a function of the parameter name: synthesised ON the device -- 0.86 G parameters at the real
+    widths took the GPU box's host cores 25 s)"""
+    usd = synth.synth_state_dict(synth.unet_param_shapes(cfg), device=device)
+    fsd = synth.synth_state_dict(synth.fstext_param_shapes(**FS), device=device)
+    unet = SeerUNet(**cfg).to(device)
     unet.load_state_dict(usd, strict=True)
     fst = FSTextTransformer(num_frames=FS["num_frames"], in_channels=192, out_channels=192, n_heads=2, num_layers=1,
-                            cross_attention_dim=192)
+                            cross_attention_dim=192).to(device)
     fst.load_state_dict(fsd, strict=True)
-    return usd, fsd, unet.to(device), fst.to(device)
+    return usd, fsd, unet, fst
 
 
-def _compare(tr, gu, gf, tol, worst_tol):
+GOLDEN = Path(__file__).parent / "golden"
+
+
+def _compare(tr, fx, tol, worst_tol):
+    """gradients against the fixture's sketches (oracle/sketch.py): the relative L2 error over all tensors, estimated to +-5 % from
+    4 seeded projections per tensor, and the worst tensor's (estimated to a factor ~2: its bound is that much looser than the
+    0.12 the full comparison used to assert)"""
     got = tr.trainable_state_dict_of(tr.pu.g, tr.pf.g)
-    for name, ref, mine in (("unet", gu, got["unet"]), ("fstext", gf, got["fstext"])):
-        assert set(ref) == set(mine)
-        mine = {k: v.cpu() for k, v in mine.items()}
-        num = sum(((mine[k].reshape(ref[k].shape) - ref[k]) ** 2).sum() for k in ref) ** 0.5
-        den = sum((ref[k] ** 2).sum() for k in ref) ** 0.5
-        assert torch.isfinite(num) and num / den < tol, (name, float(num / den))
-        w = max(float((mine[k].reshape(ref[k].shape) - ref[k]).norm() / (ref[k].norm() + 1e-3 * den)) for k in ref)
-        assert w < worst_tol, (name, w)
+    for name in ("unet", "fstext"):
+        keys = [str(k) for k in fx[name + "_keys"]]
+        assert set(keys) == set(got[name])
+        mine = {k: v.float().cpu() for k, v in got[name].items()}
+        assert all(torch.isfinite(v).all() for v in mine.values())
+        num2, den2, worst = sketch_errors(name + ":", keys, fx[name + "_sketch"], mine)
+        assert (num2 / den2) ** 0.5 < tol, (name, (num2 / den2) ** 0.5)
+        assert worst < worst_tol, (name, worst)
 
 
 # (width 320 at a 32x32 latent = the ws = 8 window regime at d = 40; the real widths -- head dims 40 / 80 / 160 -- at 16x16: the fp32
 #  autograd of the oracle at the real widths AND 32x32 cost 64 s of host time per run; the full-size step has its own properties test)
 @pytest.mark.parametrize("cfg,B,Fr,cond,H", [(CFG_MINI, 1, 3, 1, 16), (CFG_MINI, 2, 4, 2, 8), (CFG_MINI, 1, 3, 1, 32), (CFG_WIDE, 1, 4, 2, 16)])
-def test_train_step_matches_oracle(device, cfg, B, Fr, cond, H):
+def test_train_step_matches_the_reference(device, cfg, B, Fr, cond, H):
+    fx = np.load(GOLDEN / f"train_{'mini' if cfg is CFG_MINI else 'wide'}_{B}_{Fr}_{cond}_{H}.npz")
     usd, fsd, unet, fst = _models(cfg, device)
     fst.set_numframe(Fr)
     tr = SeerTrainer(unet, fst, **HP)
     x, noise = _randn((B, 4, Fr, H, H), 1), _randn((B, 4, Fr - cond, H, H), 2)
     text, t = _randn((B, 77, 192), 3), torch.tensor([417, 93, 800, 5][:B])
     loss = tr.forward_backward(x.to(device), noise.to(device), t.to(device), text.to(device), cond)
-    ref_loss, gu, gf, pred = O.train_loss_and_grads(usd, {**O.DEFAULT_CFG, **cfg}, fsd, x, noise, t, text, cond, fstext_heads=2)
-    assert abs(float(loss) - float(ref_loss)) < 2e-2 * float(ref_loss), (float(loss), float(ref_loss))
+    ref_loss, pred = float(fx["loss"]), torch.from_numpy(fx["pred"])
+    assert abs(float(loss) - ref_loss) < 2e-2 * ref_loss, (float(loss), ref_loss)
     assert (tr.last_pred.cpu() - pred).norm() / pred.norm() < 3e-2
-    _compare(tr, gu, gf, 4e-2, 0.12)
+    _compare(tr, fx, 4e-2, 0.25)
+    gu, gf = [str(k) for k in fx["unet_keys"]], [str(k) for k in fx["fstext_keys"]]
     # clip + AdamW: the oracle's update applied to OUR gradients must give OUR new parameters (kernel arithmetic), and the
     # clip coefficient must come from the UNet gradients only
     mine_g = {n: {k: v.cpu() for k, v in d.items()} for n, d in tr.trainable_state_dict_of(tr.pu.g, tr.pf.g).items()}
-    pu = {k: usd[k].clone().float() for k in gu}
-    pf = {k: fsd[k].clone().float() for k in gf}
+    pu = {k: usd[k].clone().float().cpu() for k in gu}
+    pf = {k: fsd[k].clone().float().cpu() for k in gf}
     z = lambda d: {k: torch.zeros_like(v) for k, v in d.items()}
     O.clip_and_adamw(pu, {k: mine_g["unet"][k].reshape(pu[k].shape) for k in pu}, z(pu), z(pu), 1, HP["lr"], HP["betas"],
                      HP["eps"], HP["weight_decay"], HP["max_grad_norm"])

@@ -100,11 +100,23 @@ def _model(cfg_name, device):
     # (BASELINE config 4's regimes -- 64x64 latent -- are pinned to the reference itself: test_config4_regimes_against_the_reference)
 ])
 def test_unet_forward_matches_oracle(device, cfg_name, B, Fr, H, cond_frame):
-    cfg, sd, m = _model(cfg_name, device)
+    fixture = Path(__file__).parent / "golden" / f"unet_{cfg_name}_{B}_{Fr}_{H}_{cond_frame}.npz"
+    if fixture.exists():
+        # the oracle's output for this case, made in the build container (oracle/make_goldens_train.py::gen_unet_wide): neither the
+        # fp32 forward nor the closed-form weights of 0.86 G parameters are computed on the GPU box's host cores (the weights are a
+        # function of the parameter name: synthesised on the device)
+        cfg = dict(CFG_MINI if cfg_name == "mini" else CFG_WIDE)
+        m = SeerUNet(**cfg).to(device)
+        m.load_state_dict(synth.synth_state_dict(synth.unet_param_shapes(cfg), device=device), strict=True)
+        m, sd = m.eval(), None
+        ref = torch.from_numpy(np.load(fixture)["out"])
+    else:
+        cfg, sd, m = _model(cfg_name, device)
     x = _randn((B, 4, Fr, H, H), 1)
     ctx = _randn((B, Fr, 77, cfg["cross_attention_dim"]), 2)
     t = torch.tensor([501] * B)
-    ref = O.unet_forward(sd, cfg, x, t, ctx, cond_frame=cond_frame)
+    if sd is not None:
+        ref = O.unet_forward(sd, cfg, x, t, ctx, cond_frame=cond_frame)
     got = m(x.to(device), t.to(device), ctx.to(device), cond_frame=cond_frame)
     _check(got, ref, f"unet {cfg_name} B{B} F{Fr} {H}x{H} cond{cond_frame}")
     # python-number timestep and hipGraph replay give the same answer as the eager tensor-timestep call
