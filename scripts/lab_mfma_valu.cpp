@@ -9,9 +9,10 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
-enum { PK_FMA, FMA, EXP, PK_MUL, PK_ADD, CVT_PK_BF16, MAX, MUL, ADD_U32, PERM, MOV_DPP, NOPS };
+enum { PK_FMA, FMA, EXP, PK_MUL, PK_ADD, CVT_PK_BF16, MAX, MUL, ADD_U32, PERM, MOV_DPP, MAX_E64, MUL_E64, SUB_E64, MAX3, SUB, NOPS };
 static const char* NAMES[] = {"v_pk_fma_f32", "v_fma_f32", "v_exp_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_cvt_pk_bf16_f32", "v_max_f32",
-                              "v_mul_f32", "v_add_u32", "v_perm_b32", "v_mov_b32 dpp row_shr:1"};
+                              "v_mul_f32", "v_add_u32", "v_perm_b32", "v_mov_b32 dpp row_shr:1", "v_max_f32_e64", "v_mul_f32_e64", "v_sub_f32_e64", "v_max3_f32",
+                              "v_sub_f32"};
 
 template <int OP> __device__ __forceinline__ void valu(f32x2& v, float m, float c) {
     if (OP == PK_FMA) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(v) : "v"(f32x2{m, m}), "v"(f32x2{c, c}));
@@ -24,6 +25,11 @@ template <int OP> __device__ __forceinline__ void valu(f32x2& v, float m, float 
     if (OP == MUL) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(v[0]) : "v"(m));
     if (OP == ADD_U32) asm volatile("v_add_u32 %0, %0, %1" : "+v"(v[0]) : "v"(c));
     if (OP == PERM) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(v[0]) : "v"(m), "v"(c));
+    if (OP == MAX_E64) asm volatile("v_max_f32_e64 %0, %0, %1" : "+v"(v[0]) : "v"(c));
+    if (OP == MUL_E64) asm volatile("v_mul_f32_e64 %0, %0, %1" : "+v"(v[0]) : "v"(m));
+    if (OP == SUB_E64) asm volatile("v_sub_f32_e64 %0, %0, %1" : "+v"(v[0]) : "v"(c));
+    if (OP == MAX3) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(v[0]) : "v"(c), "v"(m));
+    if (OP == SUB) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(v[0]) : "v"(c));
     if (OP == MOV_DPP) asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v[0]) : "v"(v[1]));
 }
 
@@ -81,6 +87,7 @@ template <int THREADS> void table(float* out) {
     row<PK_FMA, THREADS>(out, tm); row<FMA, THREADS>(out, tm); row<EXP, THREADS>(out, tm); row<PK_MUL, THREADS>(out, tm);
     row<PK_ADD, THREADS>(out, tm); row<CVT_PK_BF16, THREADS>(out, tm); row<MAX, THREADS>(out, tm); row<MUL, THREADS>(out, tm);
     row<ADD_U32, THREADS>(out, tm); row<PERM, THREADS>(out, tm); row<MOV_DPP, THREADS>(out, tm);
+    row<SUB, THREADS>(out, tm); row<MAX_E64, THREADS>(out, tm); row<MUL_E64, THREADS>(out, tm); row<SUB_E64, THREADS>(out, tm); row<MAX3, THREADS>(out, tm);
 }
 
 int main() {
