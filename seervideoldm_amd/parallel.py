@@ -49,6 +49,7 @@ class FrameShard:
         self.G = self.P = None
         self.total_frames = self.frame_offset = self.local_frames = 0
         self.debug_boundaries = False   # tests: hit every sync point (with a no-op exchange) even when P == 1
+        self.force_exact_stats = False  # tests: the exact-statistics form of every GroupNorm even when P == 1 (see exact_stats)
         # RCCL collectives can be captured into the step's hipGraph (scripts/exp_nccl_capture.py: capture + replay of
         # all_reduce / all_gather_into_tensor verified on torch 2.10 + RCCL 2.26): the whole sharded step then replays as
         # ONE graph instead of ~94 segments with an eager exchange and a host round trip between each pair.  gloo (CPU tests,
@@ -64,6 +65,14 @@ class FrameShard:
                     self.capture_collectives = dist.get_backend() == "nccl"
             except Exception:       # noqa: BLE001  (no default group yet)
                 pass
+
+    @property
+    def exact_stats(self) -> bool:
+        """does every GroupNorm of this engine need exact integer statistics (unet._Engine._gn)?  Only frame shards exchange
+        anything: with batch groups alone (a CFG half per rank, P == 1) the engine keeps the single-process forms -- no extra
+        pass over the activations, nothing to add up across ranks.  The one-rank references of the bit-identity tests ask for the
+        sharded arithmetic explicitly."""
+        return (self.P or 1) > 1 or self.debug_boundaries or self.force_exact_stats
 
     # ---- geometry --------------------------------------------------------------------------------------------
     def plan(self, B: int, F: int):
@@ -179,7 +188,9 @@ class FrameShard:
         # exchange buffers: one set per (site shape) for the life of the partition -- no allocation per call outside a capture
         # (inside one the graph's pool owns them anyway, and buffers of an eager run must not be baked into a graph)
         capturing = x.is_cuda and torch.cuda.is_current_stream_capturing()
-        key = (self.G, self.P, B, rows_per_frame, C, x.dtype, x.device)
+        # (the frame geometry is part of the key: plan() runs on every forward, and a second clip length at the same latent size --
+        # 12 then 14 frames -- must not inherit buffers sized for the first)
+        key = (self.G, self.P, self.total_frames, tuple(self.frame_counts), B, rows_per_frame, C, x.dtype, x.device)
         bufs = None if capturing else self._xbuf.get(key)
         if bufs is None:
             out = torch.empty((B * self.total_frames * rows_per_frame, C), device=x.device, dtype=x.dtype)

@@ -138,14 +138,15 @@ class TimedOps:
         return sorted(rows, key=lambda x: -x[2])
 
     @staticmethod
-    def _family(cls: str, tag) -> str:
-        """the ~15 kernel families of a denoising step (bench.py roofline.rows)"""
+    def _family(cls: str, tag, levels=None) -> str:
+        """the ~15 kernel families of a denoising step (bench.py roofline.rows); `levels` = rows -> level name of the shape at hand
+        (default: BASELINE config 2)"""
         if tag is None:
             return cls
         t = tag.split()
         if t[0] == "gemm":
             M, N, K = int(t[1][1:]), int(t[2][1:]), int(t[3][1:])
-            lvl = {24576: "L0", 6144: "L1", 1536: "L2", 384: "L3/mid"}.get(M, f"M{M}")
+            lvl = (levels or {24576: "L0", 6144: "L1", 1536: "L2", 384: "L3/mid"}).get(M, f"M{M}")
             if "geglu" in t:
                 return f"ff.net.0 GEGLU {lvl}"
             if "+res" in t and K == 4 * N:
@@ -156,7 +157,7 @@ class TimedOps:
                 return f"q|k|v projection {lvl}"
             return f"projections / 1x1 {lvl}"
         if t[0] == "ff_fused":
-            lvl = {24576: "L0"}.get(int(t[1][1:]), t[1])
+            lvl = (levels or {24576: "L0"}).get(int(t[1][1:]), t[1])
             return f"fused feed-forward (norm3, ff.net.0 GEGLU, ff.net.2 | proj_out +res) {lvl}"
         if t[0] == "conv":
             return f"conv3x3 {t[2]}"

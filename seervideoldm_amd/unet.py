@@ -369,8 +369,8 @@ class _Engine:
         cs2 = getattr(x2, "colsums", None) if x2 is not None else None
         C = x1.shape[1] + (0 if x2 is None else x2.shape[1])
         FX = getattr(ops, "ColSumsFx", ())
-        if self.shard is not None and self._fx is not None and hasattr(ops, "groupnorm_stats_fx"):
-            # frame shards: EVERY GroupNorm normalises with exact integer statistics -- a source whose producer left no
+        if self.shard is not None and self.shard.exact_stats and self._fx is not None and hasattr(ops, "groupnorm_stats_fx"):
+            # frame shards (P > 1; batch groups alone exchange nothing and keep the forms below): EVERY GroupNorm normalises with exact integer statistics -- a source whose producer left no
             # accumulated sums (conv_in's output, tensors above the producers' row limit) gets them from one pass over its rows;
             # the sums stay with the tensor (a skip connection feeds a second GroupNorm with the totals already exchanged)
             if not isinstance(cs1, FX):

@@ -61,7 +61,7 @@ def _worker(rank, world, port, batch_groups, B, Fr, H, cond_frame, out_path):
         ref = ref1 = None
         if rank == 0:
             ref = m(x, t, ctx, cond_frame=cond_frame)          # the plain single-process engine
-            parallel.attach(m, 1, 0)                           # the sharded engine's code path on ONE rank: no exchange at all
+            parallel.attach(m, 1, 0).force_exact_stats = world // batch_groups > 1   # the sharded engine's code path on ONE rank: no exchange at all
             ref1 = m(x, t, ctx, cond_frame=cond_frame)
         shard = parallel.attach(m, world, rank, batch_groups=batch_groups)
         got = m(x, t, ctx, cond_frame=cond_frame)
@@ -92,6 +92,48 @@ def test_sharded_step_matches_unsharded(tmp_path, batch_groups, B, Fr, cond_fram
     # statistics' rounding, which ~100 bf16 layers amplify to the 1-2e-2 two bf16 runs of this network sit apart
     rel = ((r["ref1"] - r["ref"]).norm() / r["ref"].norm()).item()
     assert rel < 3e-2, rel
+
+
+def _two_lengths_worker(rank, world, port, out_path):
+    """one attached model, two clip lengths at the same latent size (BASELINE configs 2 and its 14-frame reading): the static
+    K|V exchange buffers of the first length must not serve the second"""
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from seervideoldm_amd import SeerUNet, parallel, synth
+        from tests import torch_ops_backend as tob
+        m = SeerUNet(**CFG_MINI)
+        m.load_state_dict(synth.synth_state_dict(synth.unet_param_shapes(CFG_MINI)), strict=True)
+        m._ops_backend = tob
+        tob.EXACT = True
+        res = {}
+        g = torch.Generator().manual_seed(11)
+        ins = {Fr: (torch.randn((1, 4, Fr, 8, 8), generator=g), torch.randn((1, Fr, 77, 256), generator=g)) for Fr in (4, 6, 5)}
+        t = torch.tensor([501])
+        if rank == 0:
+            parallel.attach(m, 1, 0).force_exact_stats = True
+            for Fr, (x, ctx) in ins.items():
+                res[f"ref{Fr}"] = m(x, t, ctx, cond_frame=0)
+        shard = parallel.attach(m, world, rank, batch_groups=1)
+        for Fr in (4, 6, 5, 4):                                # even, even (longer), uneven, and back
+            x, ctx = ins[Fr]
+            res[f"got{Fr}"] = m(x, t, ctx, cond_frame=0)
+        res["n_buffer_sets"] = len(shard._xbuf)
+        if rank == 0:
+            torch.save(res, out_path)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_clip_length_changes_on_an_attached_model(tmp_path):
+    out = tmp_path / "res.pt"
+    _spawn(_two_lengths_worker, 2, str(out))
+    r = torch.load(out)
+    for Fr in (4, 6, 5):
+        assert torch.equal(r[f"got{Fr}"], r[f"ref{Fr}"]), Fr
+    assert r["n_buffer_sets"] >= 3          # a set per frame geometry (and site shape), none shared across lengths
 
 
 def test_shard_geometry():
