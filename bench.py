@@ -59,7 +59,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
-    ap.add_argument("--cpu-budget-s", type=float, default=25.0)
+    ap.add_argument("--cpu-budget-s", type=float, default=45.0,
+                    help="CPU baseline: three timed full steps run when they fit this budget, else fewer frames scaled linearly")
     ap.add_argument("--no-train", action="store_true", help="skip the extra fine-tuning step measurement (config 5)")
     ap.add_argument("--collective-timeout-s", type=float, default=300.0,
                     help="N > 1: a phase with collectives (the partitioned step, the data-parallel fine-tuning step) that has not "
@@ -167,14 +168,19 @@ def cpu_baseline(sd_cpu, cfg, budget_s):
             O.unet_forward(sd_cpu, cfg, x, torch.tensor([981, 981]), c, 0)
         return time.perf_counter() - t0
 
-    t1 = one(1)                                   # warm-up (1 warm-up + >= 3 timed)
-    F = int(max(1, min(w["frames"], budget_s / 3.0 / max(t1, 1e-3))))
+    # 1 warm-up + >= 3 timed.  The warm-up IS a full step (GroupNorm couples the frames and temporal attention is
+    # quadratic in them: a short clip scaled linearly is not the step), and so are the timed runs whenever three of them fit the
+    # budget (default: they do, ~9 s each on the GPU boxes' hosts); only a host too slow for that falls back to fewer frames, scaled.
+    Fw = w["frames"] if budget_s >= 20.0 else 1          # (a test-sized budget warms up on one frame)
+    t_w = one(Fw) * w["frames"] / Fw
+    F = w["frames"] if 3.0 * t_w <= budget_s else int(max(1, w["frames"] * budget_s / (3.0 * t_w)))
     ts = sorted(one(F) for _ in range(3))
     tF = ts[1]                                    # median of 3
     est_full = tF * w["frames"] / F
+    how = "the full step, nothing scaled" if F == w["frames"] else "scaled linearly in F to the full step"
     return dict(value=1.0 / est_full, unit="steps/s", cores=ncores, kind="port",
-                sample=f"CFG-batched UNet forward (B=2, 32x32 latent, fp32) at F={F} of {w['frames']} frames: 1 warm-up + 3 timed "
-                       f"({ts[0]:.1f} / {ts[1]:.1f} / {ts[2]:.1f} s, median used), scaled linearly in F to the full step")
+                sample=f"CFG-batched UNet forward (B=2, 32x32 latent, fp32) at F={F} of {w['frames']} frames: 1 warm-up at F={Fw} "
+                       f"({t_w * Fw / w['frames']:.1f} s) + 3 timed ({ts[0]:.1f} / {ts[1]:.1f} / {ts[2]:.1f} s, median used), {how}")
 
 
 class Watchdog:
@@ -221,14 +227,35 @@ class Watchdog:
                 self._ev = None
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` WITHOUT a launcher: start the N ranks ourselves (the driver's own launch line: one process per GPU
+    under torch.distributed.run, rendezvous on 127.0.0.1) as a CHILD process and hand back its exit status.  Nothing in this
+    process has touched the GPU yet (device_count() does not initialise it), so the box's rule against replacing or forking an
+    initialised process is not in play.  Fewer than N devices is an error, never a silent single-GPU line filed under N."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("SEER_BENCH_SAME_DEVICE") != "1":
+        print(f"bench.py: --gpus {n} but this node shows {have} GPU(s); refusing to print a line for {n}", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    return subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")).returncode
+
+
 def main():
     args = parse()
     WORKLOAD.update({k: v for k, v in WORKLOADS[args.workload].items() if k != "name"})
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))          # before any GPU call in this process
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line must be measured on the GPUs it names")
     assert torch.cuda.is_available(), "bench.py needs a ROCm device"
     # flow-check knobs (tests on a 1-GPU box): all ranks on cuda:0 over gloo -- RCCL refuses two ranks on one device
     if os.environ.get("SEER_BENCH_SAME_DEVICE") == "1":
@@ -394,7 +421,7 @@ def main():
         # scripts/pmc_summary.py; PMC cannot be collected from inside this process)
         # (scripts/pmc_step.py -> scripts/pmc_summary.py; PMC cannot be collected from inside this process).  The file carries
         # the digest of the library build it was taken on: a stale file is refused, not quoted.
-        traffic, traffic_note, ff_traffic = None, None, None
+        traffic, traffic_note, ff_traffic, traffic_families = None, None, None, None
         try:
             if args.workload != "sthv2":
                 raise OSError("the PMC passes were taken on the default workload")
@@ -403,7 +430,11 @@ def main():
             if pmc.get("build_sha256") != built:
                 raise ValueError(f"{PMC_TRAFFIC_FILE} was taken on library build {str(pmc.get('build_sha256'))[:12]}, this is "
                                  f"{built[:12]}")
-            traffic = round(pmc["kernels"]["seer_gemm_kernel"]["hbm_bytes_per_launch"])
+            # like for like with `achieved` / `algorithmic_bytes_per_launch`: the launch-weighted mean over EVERY kernel family of the
+            # class (the tile kernels, the 256 x 320 tile, the weight-stationary pair, the fused feed-forward), not the tile kernels alone
+            fams = {k: v for k, v in pmc["kernels"].items() if k.startswith(("seer_gemm", "seer_ff_fused", "seer_conv_ws"))}
+            traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in fams.values()) / sum(v["launches"] for v in fams.values()))
+            traffic_families = sorted(fams)
             ff_traffic = pmc["kernels"].get("seer_ff_fused_c320_kernel", {}).get("hbm_bytes_per_launch")
         except (OSError, KeyError, ValueError) as e:
             traffic_note = str(e)[:200]
@@ -419,7 +450,8 @@ def main():
                                              "ten seer_ff_fused_c320_kernel launches, accounted with the MACs of the two GEMMs each contains)",
                         achieved=round(gm["tflops"], 2), peak=MFMA_BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=round(gm["tflops"] / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), traffic=traffic,
-                        traffic_unit="bytes beyond L2 per launch (2*FETCH_SIZE + WRITE_SIZE, PMC)",
+                        traffic_unit="bytes beyond L2 per launch (2*FETCH_SIZE + WRITE_SIZE, PMC), launch-weighted over the class's kernel families",
+                        traffic_families=traffic_families,
                         algorithmic_bytes_per_launch=round(gm["bytes"] / gm["launches"]),
                         launches_per_step=gm["launches"] // reps, avg_launch_us=round(avg_launch_ms * 1e3, 2),
                         algorithmic_gflop_per_launch=round(per_launch_flops / 1e9, 3),

@@ -64,6 +64,25 @@ def check_pk_src1_hi(lines: Iterable[str], fname: str = "") -> List[str]:
     return out
 
 
+_PK_F32_ARITH = re.compile(r"^\s*(v_pk_(?:fma|mul|add)_f32)\b")
+
+
+def check_no_packed_fp32(lines: Iterable[str], fname: str = "") -> List[str]:
+    """build.py::NO_PACKED_FP32 switches the packed fp32 arithmetic off for the device code (it serialises with MFMAs,
+    profiles/r05_lab_mfma_valu.log).  The switch is a cc1 target feature the driver does not know: a toolchain that drops it would
+    bring the instructions back without a word, so the emitted assembly is the check."""
+    out, kern = [], "?"
+    for ln, line in enumerate(lines, 1):
+        lab = _LABEL.match(line)
+        if lab and not lab.group(1).startswith(".L"):
+            kern = lab.group(1)
+        m = _PK_F32_ARITH.match(line)
+        if m:
+            out.append(f"{fname}:{ln}: [{kern}] packed fp32 arithmetic in device code ({m.group(1)}): NO_PACKED_FP32 did not reach "
+                       f"the device compilation")
+    return out
+
+
 def _asm_start(line: str) -> bool:
     t = line.strip()
     return t.startswith(";;#ASMSTART") or t.startswith(";APP")
@@ -290,6 +309,7 @@ def check_directory(objdir: Path, sources: Iterable[str] = ()) -> List[str]:
     for f in files:
         lines = f.read_text().splitlines(keepends=True)
         problems += check_pk_src1_hi(lines, f.name)
+        problems += check_no_packed_fp32(lines, f.name)[:5]
         if f.name.startswith("attention40"):
             v, p = check_attn40_vregs(lines, f.name)
             problems += v

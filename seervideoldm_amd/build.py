@@ -38,7 +38,10 @@ EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
 # shadow of MFMAs -- a loop of MFMAs with v_pk_fma_f32 between them takes the SUM of the two loops' times (plain v_fma_f32: 0.7 of
 # the shorter one hidden), also across the waves of a SIMD, so a wave in its epilogue stalls its neighbour's MFMAs; and with two
 # waves per SIMD a packed instruction costs 3.9 ns against 2.3 ns for a plain one (profiles/r05_lab_mfma_valu.log).  hipcc's SLP
-# vectoriser forms them freely from scalar code; this turns the feature off for the device code.
+# vectoriser forms them freely from scalar code; this turns the feature off for the device code.  It is a cc1 target feature (the
+# driver has no -m flag for it and -Xarch_device cannot forward an -Xclang pair), so the host pass of a .hip file sees it too and
+# ignores it as unknown to x86; asm_check.py::check_no_packed_fp32 fails the build if the instructions are in the device assembly
+# anyway (a toolchain that stops honouring the feature must not bring them back silently).
 NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 

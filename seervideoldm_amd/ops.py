@@ -597,15 +597,29 @@ FF_FUSED_C, FF_FUSED_ROWS = 320, 96
 # The engine takes the fused launch where its workgroups fill the chip: a workgroup owns 96 rows for the whole launch, so a launch
 # takes rounds x 74 us, rounds = ceil(workgroups / CUs), whatever the last round holds -- from three quarters of the slots up it is
 # ahead of the launches it replaces (scripts/lab_ff_fused.py: 24 576 rows 89 against 103 us, 18 432 rows 80 / 86, 12 288 rows 73 / 66,
-# 36 864 rows 151 / 149, 98 304 rows 303 / 399).  A CFG half per rank (12 288 rows) keeps the three launches, and a CFG pair
-# evaluated as one batch or as two calls runs the SAME kernels at every level (ddim_video.py:205-207's two branches).
+# 36 864 rows 151 / 149, 98 304 rows 303 / 399).  The choice is made per CALL, on the rows the call holds: a CFG pair evaluated as
+# one batch (24 576 rows) takes the fused launch at the 320-channel level, the same pair evaluated as two calls
+# (ddim_video.py:205-207's other branch; a CFG half per rank: 12 288 rows each) takes layernorm + the two GEMMs -- the two branches
+# run different kernels there and agree to the bf16 tolerance, not bit for bit (tests/test_gpu_unet.py::test_unbatched_cfg_branch).
 FF_FUSED_MIN_ROWS = 18432
 FF_FUSED_MIN_FILL = 0.74
+_n_cu: dict = {}
 
 
-def ff_fused_pays(rows: int, n_cu: int = 256) -> bool:
+def device_cus(device=None) -> int:
+    """compute units of the device the launch goes to (256 on MI355X); cached per device"""
+    idx = torch.cuda.current_device() if device is None or device.index is None else device.index
+    n = _n_cu.get(idx)
+    if n is None:
+        n = _n_cu[idx] = int(torch.cuda.get_device_properties(idx).multi_processor_count)
+    return n
+
+
+def ff_fused_pays(rows: int, n_cu: Optional[int] = None) -> bool:
     if rows < FF_FUSED_MIN_ROWS:
         return False
+    if n_cu is None:
+        n_cu = device_cus()
     wgs = -(-rows // FF_FUSED_ROWS)
     return wgs / (n_cu * -(-wgs // n_cu)) >= FF_FUSED_MIN_FILL
 

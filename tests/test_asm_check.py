@@ -40,3 +40,12 @@ def test_library_assembly_in_tree_is_clean():
     if not list(objdir.glob("*gfx950.s")):
         pytest.skip("no kept device assembly (run __graft_entry__.build())")
     assert asm_check.check_directory(objdir) == []
+
+
+def test_packed_fp32_arithmetic_is_refused_in_device_assembly():
+    """build.py::NO_PACKED_FP32 must have reached the device compilation: any v_pk_{fma,mul,add}_f32 fails the build"""
+    from seervideoldm_amd.asm_check import check_no_packed_fp32
+    arith = [l for l in GOOD + BAD if "v_pk_mov" not in l]
+    assert len(check_no_packed_fp32(["k:\n"] + GOOD + BAD, "x.s")) == len(arith) == 12
+    assert check_no_packed_fp32(["k:\n", "\tv_pk_mov_b32 v[2:3], v[4:5], v[6:7]\n", "\tv_fma_f32 v1, v2, v3, v4\n",
+                                 "\tv_pk_mul_f16 v1, v2, v3\n"], "x.s") == []

@@ -41,3 +41,17 @@ def test_bench_multi_rank_contract(world, partition):
     assert ws["scaling"] == "weak" and ws["value"] > 0 and abs(ws["value"] - world * 1e3 / ws["ms_per_step"]) < 1e-2 * ws["value"]
     assert j["vs_baseline"] is None and j["dtype"] == "bf16" and j["data"] == "synthetic"
 
+
+
+def test_bench_spawns_its_own_ranks_without_a_launcher():
+    """plain `python bench.py --gpus 2` (no torchrun, WORLD_SIZE unset): bench.py starts the two ranks itself and the line says
+    n_gpus == 2 -- it never files a one-GPU measurement under N"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SEER_BENCH_SAME_DEVICE="1", SEER_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-train"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["parallelism"].startswith("batch_groups2xframe_shards1")

@@ -22,3 +22,24 @@ def test_watchdog_prints_the_fallback_line_and_exits_nonzero():
         lines = [l for l in r.stdout.splitlines() if l.strip()]
         assert "never" not in r.stdout
         assert (json.loads(lines[-1]) == want and len(lines) == 1) if want is not None else lines == []
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """`python bench.py --gpus N` without a launcher spawns its N ranks itself (tests/test_bench_multi.py, GPU); with fewer devices
+    than N -- here: none -- it exits non-zero before touching a device and prints NO line: a one-GPU number is never filed under N"""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SEER_BENCH_SAME_DEVICE")}
+    env["HIP_VISIBLE_DEVICES"] = env["CUDA_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=str(root))
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "--gpus 8" in r.stderr
+    # ... and under a launcher whose world size disagrees with --gpus it refuses as well
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
+                       timeout=300, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=str(root))
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
