@@ -154,6 +154,20 @@ def save_checkpoint(tr: SeerTrainer, output_dir: str, global_step: int, epoch: i
     return save_path, side
 
 
+def _load_model_file(load_path: str, index: int) -> Dict[str, torch.Tensor]:
+    """the `index`-th prepared model of accelerator.save_state: `pytorch_model[_i].bin` (the accelerate the reference pins, and
+    `safe_serialization=False` today) or `model[_i].safetensors` (accelerate >= 0.22's default)"""
+    suffix = "" if index == 0 else f"_{index}"
+    fp = os.path.join(load_path, f"pytorch_model{suffix}.bin")
+    if os.path.exists(fp):
+        return torch.load(fp, map_location="cpu")
+    fs = os.path.join(load_path, f"model{suffix}.safetensors")
+    if os.path.exists(fs):
+        from safetensors.torch import load_file
+        return load_file(fs, device="cpu")
+    raise FileNotFoundError(f"neither {fp} nor {fs}: not an accelerator.save_state directory")
+
+
 def load_checkpoint(tr: SeerTrainer, output_dir: str, saved_global_step: int, lr_meter: RunningAverageMeter,
                     losses_train: RunningAverageMeter, restore_rng: bool = True) -> Optional[Dict]:
     """train.py:268-280: load `learned_sdunet-steps-{saved_global_step}` and its sidecar if they exist.  Returns
@@ -162,8 +176,8 @@ def load_checkpoint(tr: SeerTrainer, output_dir: str, saved_global_step: int, lr
     side = load_path + ".pt"
     out = None
     if os.path.exists(load_path):
-        tr.unet.load_state_dict(torch.load(os.path.join(load_path, "pytorch_model.bin"), map_location="cpu"), strict=True)
-        tr.fstext.load_state_dict(torch.load(os.path.join(load_path, "pytorch_model_1.bin"), map_location="cpu"), strict=True)
+        tr.unet.load_state_dict(_load_model_file(load_path, 0), strict=True)
+        tr.fstext.load_state_dict(_load_model_file(load_path, 1), strict=True)
         tr.reload_from_modules()
         load_optimizer_state_dict(tr, torch.load(os.path.join(load_path, "optimizer.bin"), map_location="cpu", weights_only=False))
         rp = os.path.join(load_path, f"random_states_{_rank()}.pkl")

@@ -106,13 +106,13 @@ def validation_grid(x_samples_ddim: torch.Tensor, video_recon: torch.Tensor, vid
     flat = lambda t: t.permute(0, 1, 3, 2, 4).reshape(t.shape[0], t.shape[1], t.shape[3], t.shape[2] * t.shape[4])  # b c h (f w)
     pred, recon = flat(padf(x_samples_ddim)), flat(padf(video_recon))
     ori, cond = flat(padf(video[:, :, f0:])), flat(padf(video[:, :, :f0]))
-    reali_pre = torch.cat([ori, recon, pred], dim=-2)
-    cond_expand = cond.repeat(1, 1, 3, 1)
-    n, c, h = reali_pre.shape[:3]
+    rows3 = torch.cat([ori, recon, pred], dim=-2)
+    cond3 = cond.repeat(1, 1, 3, 1)
+    n, c, h = rows3.shape[:3]
     red, green = torch.ones(n, c, h, 4), torch.ones(n, c, h, 4)
     red[:, [1, 2]] = 0
     green[:, [0, 2]] = 0
-    return _make_grid_rows(torch.cat([cond_expand, green, reali_pre, red], dim=-1))
+    return _make_grid_rows(torch.cat([cond3, green, rows3, red], dim=-1))
 
 
 def save_visualization(vae, x_samples_ddim: torch.Tensor, video_latent: torch.Tensor, video: torch.Tensor,
