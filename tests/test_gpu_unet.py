@@ -429,6 +429,52 @@ def test_full_size_step_matches_the_reference(device, cond):
     _check(got, torch.from_numpy(g[f"y_cond{cond}"]), f"config 2 full size (B2 F12 32x32, cond {cond}) vs the reference")
 
 
+def test_config1_end_to_end_against_the_reference(device):
+    """BASELINE config 1 end to end, one hop from the reference: the REAL `ddim_sample` (utils/ddim_sampling_utils.py:21-42 ->
+    ldm/models/diffusion/ddim_video.py:71-238) over the full-width UNet -- b = 1, 2 conditioning + 10 predicted frames, 32x32 latent,
+    S = 4 (timesteps 751 / 501 / 251 / 1), scale 7.5, CFG pair batched -- then 1 / 0.18215, the vendored full-size SD-VAE decoder and
+    the clamp (tests/golden/e2e_config1.npz, oracle/make_goldens_full.py::gen_e2e).  The product runs the same call chain: sampler
+    graph per step, fused CFG + DDIM update, fp16-storage VAE.
+    Tolerances: four dependent CFG steps at scale 7.5 amplify each step's eps error (the one-step bound is REL_L2 = 1.65 x the
+    reference's own bf16-autocast error): 8e-2 relative L2 on the final latent, as the small-network sampler test states; on the
+    decoded frames in [0, 1]: mean |pixel error| <= 2 / 255 and per-frame mean brightness within 1 / 255."""
+    g = np.load(_G / "e2e_config1.npz")
+    b, f1, Fp, h = 1, 2, 10, 32
+    x0_emb = _randn((b, 4, f1, h, h), 61) * 0.9
+    c = _randn((b, f1 + Fp, 77, 768), 62)
+    uc1 = _randn((b, 1, 77, 768), 63)
+    noise = _randn((b, 4, Fp, h, h), 64)
+    for t_, k in ((x0_emb, "x0_emb_fp"), (c, "c_fp"), (uc1, "uc_fp"), (noise, "noise_fp")):
+        assert np.array_equal(_fp(t_), g[k]), f"{k}: the seeded inputs drawn here are not the ones the reference ran on"
+    uc = uc1.expand(-1, f1 + Fp, -1, -1).contiguous()
+    m = _full_model(device)
+    vae = AutoencoderKL()
+    vae.load_state_dict(ldm_to_diffusers_vae(synth.synth_state_dict(synth.vae_param_shapes()), 4), strict=True)
+    vae = vae.to(device)
+    m.use_graph = True
+    try:
+        sampler = DDIMSampler(device)
+        lat, _ = sampler.sample(unet=m, S=4, conditioning=c.to(device), batch_size=b, shape=(4, Fp, h, h), x0_emb=x0_emb.to(device),
+                                verbose=False, unconditional_guidance_scale=7.5, unconditional_conditioning=uc.to(device), eta=0.0,
+                                x_T=noise.to(device), is_3d=True)
+        assert sampler.ddim_timesteps.tolist() == [1, 251, 501, 751]
+        clip = ddim_sample(sampler, m, vae, (b, 4, Fp, h, h), c.to(device), noise.to(device), x0_emb.to(device), ddim_steps=4,
+                           scale=7.5, uc=uc.to(device))
+    finally:
+        m.use_graph = False
+    ref_lat = torch.from_numpy(g["latent"])
+    rel = _rel(lat, ref_lat)
+    assert clip.shape == (b, 3, Fp, 8 * h, 8 * h) and clip.min() >= 0 and clip.max() <= 1
+    frames = [int(i) for i in g["clip_frames"]]
+    ref_clip = torch.from_numpy(g["clip"]).float()
+    px = (clip[:, :, frames].float().cpu() - ref_clip).abs()
+    dmean = (clip.float().mean(dim=(0, 1, 3, 4)).cpu() - torch.from_numpy(g["clip_frame_mean"])).abs().max().item()
+    print(f"[parity] config 1 end to end vs the reference: latent rel_l2 {rel:.4g}; frames {frames}: mean |pixel error| "
+          f"{px.mean().item() * 255:.3f}/255, max {px.max().item() * 255:.1f}/255; frame-mean brightness off by {dmean * 255:.3f}/255")
+    assert rel <= 8e-2, rel
+    assert px.mean().item() * 255 <= 2.0 and dmean * 255 <= 1.0, (px.mean().item() * 255, dmean * 255)
+
+
 def test_bridge_config_single_gpu(device):
     """BASELINE config 3 on one GPU: CFG batch 8 (4 samples x [uc, c]) x 16 frames (1 conditioning) x 32^2, full-width UNet.
     (0) against the REAL reference's output at this size; (a) finite, right shape; (b) a sample's result does not depend on its batch slot or on its neighbours: rows 0 and 4 of
