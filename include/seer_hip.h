@@ -256,6 +256,10 @@ typedef struct seer_attn_desc {
  * exp2 of the raw dot products and ignores `scale`.  Without the flag the d = 40 kernel multiplies Q itself (one more
  * bf16 rounding of q) and the generic kernel scales the fp32 scores. */
 #define SEER_ATTN_Q_PRESCALED 1u
+/* Q, K, V and O hold IEEE half (fp16) instead of bf16 -- the UNet engine under fp16 autocast (every reference yaml ships
+ * mixed_precision: "fp16").  fp32 scores, statistics and accumulation as always; P is rounded to fp16 for the PV product.  Runs the
+ * generic kernel at every head dim (variant 0 or 1; no lse: inference only). */
+#define SEER_ATTN_F16 2u
 
 int seer_attn_fwd(const seer_attn_desc* desc /* host */, void* stream);
 
@@ -328,6 +332,16 @@ int seer_groupnorm_apply_fx(const void* x1, int32_t C1, const void* x2, int32_t 
  * for GroupNorm sources without accumulated producer sums (resnet.py:179,197, attention.py:133 normalise over all frames). */
 int seer_groupnorm_stats_fx(const void* x, int32_t C, int32_t batch, int64_t rows_per_batch, int64_t* fx, int32_t dtype,
                             void* stream);
+/* seer_groupnorm_apply_from_colsums / seer_groupnorm_apply_fx with the storage type of x1 / x2 / y chosen by `dtype` (SEER_DT_*):
+ * the UNet engine on fp16 storage */
+int seer_groupnorm_apply_from_colsums_dt(const void* x1, int32_t C1, const void* x2, int32_t C2, const float* cs1, int32_t phases1,
+                                         int32_t tiles1, const float* cs2, int32_t phases2, int32_t tiles2, int32_t batch,
+                                         int64_t rows_per_batch, int32_t groups, double count, float eps, const float* gamma,
+                                         const float* beta, int32_t silu, void* y, int32_t dtype, void* stream);
+int seer_groupnorm_apply_fx_dt(const void* x1, int32_t C1, const void* x2, int32_t C2, const int64_t* fx1, int32_t reps1,
+                               const int64_t* fx2, int32_t reps2, int32_t batch, int64_t rows_per_batch, int32_t groups, double count,
+                               float eps, const float* gamma, const float* beta, int32_t silu, void* y, float* stats_out, int32_t dtype,
+                               void* stream);
 /* The feed-forward of a transformer block at the 320-channel level and the transformer's proj_out, ONE launch (csrc/ff_fused.hip):
  *     y = x + [Wp | Wp W2] [h | g] + bcat,   g = GEGLU(LayerNorm(h; gamma, beta, eps) W1^T + b1)
  * i.e. norm3 -> ff.net.0 -> ff.net.2 + residual -> proj_out + residual (seer/models/attention.py:231-248, 308-327, 742-747,
@@ -358,6 +372,9 @@ int seer_groupnorm_apply_dt(const void* x1, int32_t C1, const void* x2, int32_t 
 /* nn.LayerNorm(C) per token row (attention.py:198-200,275-277), eps 1e-5; bf16 in/out, fp32 statistics. */
 int seer_layernorm(const void* x, int64_t rows, int32_t C, int32_t ldx, const float* gamma, const float* beta,
                    float eps, void* y, int32_t ldy, void* stream);
+/* ... with x and y in the storage type `dtype` (SEER_DT_*) */
+int seer_layernorm_dt(const void* x, int64_t rows, int32_t C, int32_t ldx, const float* gamma, const float* beta,
+                      float eps, void* y, int32_t ldy, int32_t dtype, void* stream);
 
 /* y = softmax(scale * x) over rows of a [rows, n] matrix, x bf16 or fp32, y bf16 (VAE mid attention,
  * ldm/modules/diffusionmodules/model.py:186-197) */
@@ -377,6 +394,9 @@ int seer_timestep_embedding(const int64_t* t, int32_t B, int32_t dim, int32_t fl
  * y fp32.  Used for time_embedding (unet_3d_condition.py:308) and all 22 time_emb_proj at once (resnet.py:192). */
 int seer_linear_smallm(const float* x, int32_t B, int32_t K, const void* W, const float* bias, int32_t N,
                        int32_t silu_in, int32_t silu_out, float* y, void* stream);
+/* ... with W in the storage type `dtype` (SEER_DT_*) */
+int seer_linear_smallm_dt(const float* x, int32_t B, int32_t K, const void* W, const float* bias, int32_t N,
+                          int32_t silu_in, int32_t silu_out, float* y, int32_t dtype, void* stream);
 
 /* conv_in: InflatedConv3d(4->C0, 3x3, pad 1) reading the reference layout [B, Cin, F, H, W] fp32 and writing
  * channels-last bf16 [B*F, H*W, C0] (unet_3d_condition.py:94,311).  W fp32 repacked to [3][3][Cin][C0]. */
@@ -400,6 +420,8 @@ int seer_conv1x1_nchw_f32(const float* x, int32_t N, int32_t Cin, int32_t Cout, 
 
 /* layout / dtype conversion: fp32 [rows, C] -> bf16 (context, weights) */
 int seer_cast_f32_bf16(const float* x, int64_t n, void* y, void* stream);
+/* ... to the 16-bit storage type `dtype` (SEER_DT_*) */
+int seer_cast_f32_dt(const float* x, int64_t n, void* y, int32_t dtype, void* stream);
 /* NHWC bf16 -> NCHW fp32 and back (VAE boundary) */
 int seer_nchw_f32_to_nhwc_bf16(const float* x, int32_t N, int32_t C, int32_t HW, void* y, void* stream);
 int seer_nhwc_bf16_to_nchw_f32(const void* x, int32_t N, int32_t C, int32_t HW, float* y, void* stream);

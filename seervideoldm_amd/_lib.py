@@ -13,7 +13,7 @@ _PKG = Path(__file__).resolve().parent
 _LIB_PATH = _PKG / "lib" / "libseer_hip.so"
 _lib = None
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 SEER_GEMM_PLAIN = 0
 SEER_GEMM_CONV3X3 = 1
@@ -27,6 +27,7 @@ SEER_EPI_F16 = 64
 SEER_ENOSYS = -38
 SEER_DT_BF16, SEER_DT_F16 = 0, 1
 SEER_ATTN_Q_PRESCALED = 1
+SEER_ATTN_F16 = 2
 SEER_TILE_AUTO, SEER_TILE_128x128, SEER_TILE_64x64, SEER_TILE_128x64 = 0, 1, 2, 3
 
 
@@ -106,6 +107,10 @@ SIGNATURES = {
                                            _i32, _vp, _vp], C.c_int),
     "seer_groupnorm_apply_fx": ([_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i64, _i32, _f64, _f32, _vp, _vp, _i32, _vp, _vp, _vp], C.c_int),
     "seer_groupnorm_stats_fx": ([_vp, _i32, _i32, _i64, _vp, _i32, _vp], C.c_int),
+    "seer_groupnorm_apply_from_colsums_dt": ([_vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i64, _i32, _f64, _f32, _vp, _vp,
+                                              _i32, _vp, _i32, _vp], C.c_int),
+    "seer_groupnorm_apply_fx_dt": ([_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i64, _i32, _f64, _f32, _vp, _vp, _i32, _vp, _vp, _i32,
+                                    _vp], C.c_int),
     "seer_ff_fused_c320": ([_vp, _i32, _vp, _i32, _vp, _i32, _i64, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp], C.c_int),
     "seer_ff_fused_pack_w1": ([_vp, _vp, _vp], C.c_int),
     "seer_ff_fused_pack_wcat": ([_vp, _vp, _vp], C.c_int),
@@ -116,13 +121,16 @@ SIGNATURES = {
     "seer_conv_in_dt": ([_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp], C.c_int),
     "seer_conv_out_dt": ([_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp], C.c_int),
     "seer_layernorm": ([_vp, _i64, _i32, _i32, _vp, _vp, _f32, _vp, _i32, _vp], C.c_int),
+    "seer_layernorm_dt": ([_vp, _i64, _i32, _i32, _vp, _vp, _f32, _vp, _i32, _i32, _vp], C.c_int),
     "seer_softmax_rows": ([_vp, _i32, _i64, _i32, _i32, _f32, _vp, _i32, _vp], C.c_int),
     "seer_conv1x1_nchw_f32": ([_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp], C.c_int),
     "seer_timestep_embedding": ([_vp, _i32, _i32, _i32, _f32, _vp, _vp], C.c_int),
     "seer_linear_smallm": ([_vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp], C.c_int),
+    "seer_linear_smallm_dt": ([_vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp], C.c_int),
     "seer_conv_in": ([_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp], C.c_int),
     "seer_conv_out": ([_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp], C.c_int),
     "seer_cast_f32_bf16": ([_vp, _i64, _vp, _vp], C.c_int),
+    "seer_cast_f32_dt": ([_vp, _i64, _vp, _i32, _vp], C.c_int),
     "seer_nchw_f32_to_nhwc_bf16": ([_vp, _i32, _i32, _i32, _vp, _vp], C.c_int),
     "seer_nhwc_bf16_to_nchw_f32": ([_vp, _i32, _i32, _i32, _vp, _vp], C.c_int),
     "seer_cfg_ddim_step": ([_vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i32, _vp, _vp, _vp, _vp, _vp], C.c_int),

@@ -85,7 +85,22 @@ struct TokMap {
 // defer_thr: the running max of a query is only raised when a tile's max exceeds it by more than defer_thr (log2 units), so
 //            p <= 2^defer_thr instead of <= 1 and the O rescale (skipped when no lane moved its max) becomes rare; bf16 P keeps
 //            its relative precision at any magnitude and l/O accumulate in fp32, so the result is unchanged to rounding.
-template <int D, bool DBUF>
+// F16 (SEER_ATTN_F16): Q, K, V and O hold IEEE half instead of bf16 -- the same 16-bit loads, LDS images and transposed reads (the
+// bf16 vector types below are containers of bits); only the MFMA opcode, the constant 1.0 of the denominator column, the conversion
+// of P and the output pack differ.  P <= 2^defer_thr = 16 is far inside the half range; probabilities below 6e-8 flush to zero.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+template <bool F16>
+__device__ __forceinline__ f32x16 mma32(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ bf16 to16(float v) {      // the 16-bit storage value of v, in a bf16-typed container
+    if constexpr (F16) return __builtin_bit_cast(bf16, (_Float16)v);
+    else return (bf16)v;
+}
+
+template <int D, bool DBUF, bool F16 = false>
 __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, const int ws_log2, const float defer_thr) {
     using C = AttnCfg<D>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -138,7 +153,7 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
     // ---- V pad column D = 1.0 (never overwritten: the tile commits only write columns < D)
     if constexpr (LSUM_MFMA) {
         for (int r = tid; r < (DBUF ? 2 : 1) * KT; r += 256)
-            lds[(r / KT) * C::BUF + KT * C::KRS + (r % KT) * C::VRS + D] = (bf16)1.0f;
+            lds[(r / KT) * C::BUF + KT * C::KRS + (r % KT) * C::VRS + D] = to16<F16>(1.0f);
     }
 
     // ---- Q fragments (B operand: col = query, k = 8h + j inside each 16-wide step)
@@ -252,7 +267,7 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
                 for (int r = 0; r < 8; ++r) sacc[r] += (float)kf[s][r] + (float)qf[s][r];
 #else
 #pragma unroll
-            for (int s = 0; s < C::KSTEPS; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], sacc, 0, 0, 0);
+            for (int s = 0; s < C::KSTEPS; ++s) sacc = mma32<F16>(kf[s], qf[s], sacc);
 #endif
 
             return sacc;
@@ -315,7 +330,7 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pf[s2][j] = (bf16)sacc[8 * s2 + j];
+                for (int j = 0; j < 8; ++j) pf[s2][j] = to16<F16>(sacc[8 * s2 + j]);
 
             // ---- O^T += V^T P^T ; V^T fragments by transposed LDS reads
             // lane group of 16: i = lane & 15 -> (q = i >> 2: key row of the 4x16 block, pcol = i & 3: 4-column group)
@@ -338,7 +353,7 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
 #if SEER_ATTN_PROBE & 2
                     oacc[tt][s2] += (float)vf[0] + (float)pf[s2][tt];
 #else
-                    oacc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], oacc[tt], 0, 0, 0);
+                    oacc[tt] = mma32<F16>(vf, pf[s2], oacc[tt]);
 #endif
                 }
             }
@@ -377,8 +392,13 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
                 const int d0 = 32 * tt + 8 * g + 4 * lh;
                 if (d0 < D) {
                     u32x2 o;
-                    o[0] = pack2(oacc[tt][4 * g + 0] * inv, oacc[tt][4 * g + 1] * inv);
-                    o[1] = pack2(oacc[tt][4 * g + 2] * inv, oacc[tt][4 * g + 3] * inv);
+                    if constexpr (F16) {
+                        o[0] = pack2h(oacc[tt][4 * g + 0] * inv, oacc[tt][4 * g + 1] * inv);
+                        o[1] = pack2h(oacc[tt][4 * g + 2] * inv, oacc[tt][4 * g + 3] * inv);
+                    } else {
+                        o[0] = pack2(oacc[tt][4 * g + 0] * inv, oacc[tt][4 * g + 1] * inv);
+                        o[1] = pack2(oacc[tt][4 * g + 2] * inv, oacc[tt][4 * g + 3] * inv);
+                    }
                     *reinterpret_cast<u32x2*>(orow + d0) = o;
                 }
             }
@@ -386,14 +406,14 @@ __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, 
     }
 }
 
-template <int D, bool DBUF>
+template <int D, bool DBUF, bool F16 = false>
 int launch_attn2(const seer_attn_desc& d, int ws_log2, float thr, hipStream_t st) {
     int nbatch = d.batch;
     if (ws_log2 >= 0) nbatch *= (d.H >> ws_log2) * (d.W >> ws_log2);
     dim3 grid((d.Sq + 127) / 128, nbatch * d.heads, 1);
     constexpr size_t lds = AttnCfg<D>::LDS_BYTES / (DBUF ? 1 : 2);
     static_assert(lds <= 64 * 1024, "above the default dynamic-LDS limit: would need a hipFuncSetAttribute opt-in");
-    hipLaunchKernelGGL((seer_attn_kernel<D, DBUF>), grid, dim3(256), lds, st, d, ws_log2, thr);
+    hipLaunchKernelGGL((seer_attn_kernel<D, DBUF, F16>), grid, dim3(256), lds, st, d, ws_log2, thr);
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }
@@ -403,6 +423,7 @@ int launch_attn2(const seer_attn_desc& d, int ws_log2, float thr, hipStream_t st
 template <int D>
 int launch_attn(const seer_attn_desc& d, int ws_log2, hipStream_t st) {
     constexpr float thr = 4.0f;
+    if (d.flags & SEER_ATTN_F16) return launch_attn2<D, false, true>(d, ws_log2, thr, st);      // IEEE-half operands: the generic kernel
     if constexpr (AttnCfg<D>::LDS_BYTES <= 64 * 1024) {
         if (d.variant == 6) return launch_attn2<D, true>(d, ws_log2, thr, st);
     }
@@ -430,8 +451,10 @@ extern "C" int seer_attn_fwd(const seer_attn_desc* desc, void* stream) {
     if (d.variant < 0 || d.variant > 7 || d.variant == 4) return SEER_EINVAL;
     if ((d.variant == 2 || d.variant == 3 || d.variant == 5 || d.variant == 7) && d.head_dim != 40) return SEER_EINVAL;
     if (d.causal_offset < 0 || (d.causal && d.Sq + d.causal_offset > d.Sk)) return SEER_EINVAL;
+    if ((d.flags & SEER_ATTN_F16) && (d.lse || (d.variant != 0 && d.variant != 1))) return SEER_EINVAL;      // inference, generic kernel
     switch (d.head_dim) {
         case 40:
+            if (d.flags & SEER_ATTN_F16) return launch_attn<40>(d, ws_log2, st);          // (the d = 40 kernel is bf16 only)
             // the d = 40 kernel pays ~3 us of set-up (constant region, LDS-DMA plan, reference pre-pass) that short key
             // sequences do not earn back (text cross-attention, Sk = 77: 18.7 vs 16.6 us, profiles/r02_attn40_variants.log)
             if (d.variant == 1 || d.variant == 6 || (d.variant == 0 && d.Sk < 256)) return launch_attn<40>(d, ws_log2, st);

@@ -70,7 +70,7 @@ __global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, int B, 
 // ---- small-M linear (time-embedding MLP, B <= 8 rows): act(x) staged once per block in LDS, each wave owns ROWS
 // consecutive output features so ROWS independent 16-B weight loads per lane are in flight per K pass (the 51 MB
 // time_emb_proj stack is a pure HBM stream) -----------------------------------------------------------------------
-template <int MAXB, int ROWS>
+template <int MAXB, int ROWS, bool F16 = false>
 __global__ void __launch_bounds__(256) linear_smallm_kernel(const float* __restrict__ x, int B, int K,
                                                             const bf16* __restrict__ W, const float* __restrict__ bias,
                                                             int N, int silu_in, int silu_out, float* __restrict__ y) {
@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(256) linear_smallm_kernel(const float* __restr
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             float w[8];
-            unpack8(wv[r], w);
+            unpack8t<F16>(wv[r], w);
 #pragma unroll
             for (int b = 0; b < MAXB; ++b)
 #pragma unroll
@@ -240,16 +240,25 @@ __global__ void __launch_bounds__(256) conv_out_kernel(const bf16* __restrict__ 
     }
 }
 
+template <bool F16>
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ x, int64_t n, bf16* __restrict__ y) {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i + 3 < n) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
         u32x2 o;
-        o[0] = pack2(v[0], v[1]);
-        o[1] = pack2(v[2], v[3]);
+        if constexpr (F16) {
+            o[0] = pack2h(v[0], v[1]);
+            o[1] = pack2h(v[2], v[3]);
+        } else {
+            o[0] = pack2(v[0], v[1]);
+            o[1] = pack2(v[2], v[3]);
+        }
         *reinterpret_cast<u32x2*>(y + i) = o;
     } else {
-        for (int64_t j = i; j < n; ++j) y[j] = (bf16)x[j];
+        for (int64_t j = i; j < n; ++j) {
+            if constexpr (F16) reinterpret_cast<_Float16*>(y)[j] = (_Float16)x[j];
+            else y[j] = (bf16)x[j];
+        }
     }
 }
 
@@ -460,22 +469,30 @@ int ensure_lds(K kernel, size_t bytes, std::atomic<bool>* done) {      // settin
 
 extern "C" int seer_linear_smallm(const float* x, int32_t B, int32_t K, const void* W, const float* bias, int32_t N,
                                   int32_t silu_in, int32_t silu_out, float* y, void* stream) {
+    return seer_linear_smallm_dt(x, B, K, W, bias, N, silu_in, silu_out, y, SEER_DT_BF16, stream);
+}
+extern "C" int seer_linear_smallm_dt(const float* x, int32_t B, int32_t K, const void* W, const float* bias, int32_t N,
+                                     int32_t silu_in, int32_t silu_out, float* y, int32_t dtype, void* stream) {
+    if (dtype != SEER_DT_BF16 && dtype != SEER_DT_F16) return SEER_EINVAL;
     if (!x || !W || !y || B <= 0 || B > 8 || K <= 0 || K % 8 || N <= 0) return SEER_EINVAL;
     const size_t lds = (size_t)B * K * sizeof(float);
     const bf16* Wb = reinterpret_cast<const bf16*>(W);
+    static std::atomic<bool> done[4] = {{false}, {false}, {false}, {false}};
+#define SEER_LSM(MB, R, H, GRID, FLAG)                                                                                              \
+    do {                                                                                                                            \
+        const int rc = ensure_lds(linear_smallm_kernel<MB, R, H>, lds, &done[FLAG]);                                                \
+        if (rc != SEER_OK) return rc;                                                                                               \
+        hipLaunchKernelGGL((linear_smallm_kernel<MB, R, H>), dim3(GRID), dim3(256), lds, S(stream), x, B, K, Wb, bias, N, silu_in,   \
+                           silu_out, y);                                                                                            \
+    } while (0)
     if (B <= 2) {
-        static std::atomic<bool> done{false};
-        const int rc = ensure_lds(linear_smallm_kernel<2, 4>, lds, &done);
-        if (rc != SEER_OK) return rc;
-        hipLaunchKernelGGL((linear_smallm_kernel<2, 4>), dim3((N + 15) / 16), dim3(256), lds, S(stream), x, B, K, Wb, bias, N,
-                           silu_in, silu_out, y);
+        if (dtype == SEER_DT_F16) SEER_LSM(2, 4, true, (N + 15) / 16, 0);
+        else SEER_LSM(2, 4, false, (N + 15) / 16, 1);
     } else {
-        static std::atomic<bool> done{false};
-        const int rc = ensure_lds(linear_smallm_kernel<8, 2>, lds, &done);
-        if (rc != SEER_OK) return rc;
-        hipLaunchKernelGGL((linear_smallm_kernel<8, 2>), dim3((N + 7) / 8), dim3(256), lds, S(stream), x, B, K, Wb, bias, N,
-                           silu_in, silu_out, y);
+        if (dtype == SEER_DT_F16) SEER_LSM(8, 2, true, (N + 7) / 8, 2);
+        else SEER_LSM(8, 2, false, (N + 7) / 8, 3);
     }
+#undef SEER_LSM
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }
@@ -545,11 +562,15 @@ extern "C" int seer_conv_out_dt(const void* x, int32_t B, int32_t C0, int32_t F,
     return SEER_OK;
 }
 
-extern "C" int seer_cast_f32_bf16(const float* x, int64_t n, void* y, void* stream) {
+extern "C" int seer_cast_f32_bf16(const float* x, int64_t n, void* y, void* stream) { return seer_cast_f32_dt(x, n, y, SEER_DT_BF16, stream); }
+extern "C" int seer_cast_f32_dt(const float* x, int64_t n, void* y, int32_t dtype, void* stream) {
+    if (dtype != SEER_DT_BF16 && dtype != SEER_DT_F16) return SEER_EINVAL;
     if (!x || !y || n <= 0) return SEER_EINVAL;
     const int64_t nt = (n + 3) / 4;
-    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, S(stream), x, n,
-                       reinterpret_cast<bf16*>(y));
+    if (dtype == SEER_DT_F16)
+        hipLaunchKernelGGL(cast_f32_bf16_kernel<true>, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, S(stream), x, n, reinterpret_cast<bf16*>(y));
+    else
+        hipLaunchKernelGGL(cast_f32_bf16_kernel<false>, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, S(stream), x, n, reinterpret_cast<bf16*>(y));
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }
@@ -632,7 +653,7 @@ extern "C" int seer_gaussian_sample(const float* moments, int32_t N, int32_t C, 
     return SEER_OK;
 }
 
-extern "C" int seer_abi_version(void) { return 21; }
+extern "C" int seer_abi_version(void) { return 22; }
 extern "C" const char* seer_build_arch(void) { return "gfx950"; }
 extern "C" const char* seer_strerror(int code) {
     switch (code) {

@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
     // and keeps the raw pair through the K loop; the epilogue converts it and hands (mean * rstd, rstd) to the lanes that own the
     // row through LDS.  (Converting here put a wait for the load -- an L2 round trip -- in front of the first LDS-DMA of every
     // tile: +3 us on the GEGLU projections with their 7.5 tiles per CU, profiles/r04_ln_fold_overheads.md.)
-    constexpr bool LN_OK = !SPLIT && !F16 && tile_ln_ok<BM, BN, NS, WM, WN>();
+    constexpr bool LN_OK = !SPLIT && tile_ln_ok<BM, BN, NS, WM, WN>();
     typedef __attribute__((ext_vector_type(2))) long long i64x2;
     i64x2 ln_raw = {0, 0};
     if constexpr (LN_OK) {
@@ -872,7 +872,7 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
     // the staging address is one XOR per fragment column plus an immediate offset per fragment row.
     // row statistics of the output (seer_gemm_desc::rowstat): each lane adds the fp32 values of its quads per fragment row, the
     // four lanes of a row meet by two lane exchanges, one atomic pair per (row, wave column)
-    constexpr bool RS_OK = !GEGLU && !SPLIT && !F16 && tile_ln_ok<BM, BN, NS, WM, WN>();
+    constexpr bool RS_OK = !GEGLU && !SPLIT && tile_ln_ok<BM, BN, NS, WM, WN>();
     bool do_rs = false;
     float rsum[TM], rsq[TM];
     if constexpr (RS_OK) {
@@ -1252,18 +1252,31 @@ __device__ __forceinline__ f32x4 splitk_reduce_quad(const seer_gemm_desc& p, int
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] *= p.col_scale;
     }
+    const bool h16 = (p.epilogue & SEER_EPI_F16) != 0;      // IEEE-half storage (the fp16 engine): same bytes, other conversions
     if (p.residual) {
         const u32x2 rv = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16*>(p.residual) + (int64_t)m * p.ldr + n);
-        v[0] += __builtin_bit_cast(float, rv[0] << 16);
-        v[1] += __builtin_bit_cast(float, rv[0] & 0xffff0000u);
-        v[2] += __builtin_bit_cast(float, rv[1] << 16);
-        v[3] += __builtin_bit_cast(float, rv[1] & 0xffff0000u);
+        if (h16) {
+            const f32x2 r01 = unpack2t<true>(rv[0]), r23 = unpack2t<true>(rv[1]);
+            v[0] += r01[0]; v[1] += r01[1]; v[2] += r23[0]; v[3] += r23[1];
+        } else {
+            v[0] += __builtin_bit_cast(float, rv[0] << 16);
+            v[1] += __builtin_bit_cast(float, rv[0] & 0xffff0000u);
+            v[2] += __builtin_bit_cast(float, rv[1] << 16);
+            v[3] += __builtin_bit_cast(float, rv[1] & 0xffff0000u);
+        }
     }
     if (p.epilogue & SEER_EPI_OUT_F32) {
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
         return f32x4{v[0], v[1], v[2], v[3]};
     }
     u32x2 o;
+    if (h16) {
+        o[0] = pack2h(v[0], v[1]);
+        o[1] = pack2h(v[2], v[3]);
+        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + n) = o;
+        const f32x2 s01 = unpack2t<true>(o[0]), s23 = unpack2t<true>(o[1]);
+        return f32x4{s01[0], s01[1], s23[0], s23[1]};
+    }
     o[0] = pack2(v[0], v[1]);
     o[1] = pack2(v[2], v[3]);
     *reinterpret_cast<u32x2*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + n) = o;
@@ -1366,10 +1379,11 @@ bool colsum_store_ok(const seer_gemm_desc& d) {
 
 // one flag per tile instantiation, at namespace scope (no function-local statics in the library): the dynamic-LDS opt-in of its
 // kernels has run
-template <int BM, int BN, int NS, int WM, int WN>
+template <int BM, int BN, int NS, int WM, int WN, bool F16>
 std::once_flag g_tile_lds_once;
 
-template <int BM, int BN, int NS, int WM = 2, int WN = 2>
+// F16: the IEEE-half instantiation of the same tile (SEER_EPI_F16: the VAE, and the UNet engine under fp16 autocast)
+template <int BM, int BN, int NS, int WM = 2, int WN = 2, bool F16 = false>
 int launch_tile(const seer_gemm_desc& d, hipStream_t st) {
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, 1, d.batch > 1 ? d.batch : 1);
@@ -1378,13 +1392,13 @@ int launch_tile(const seer_gemm_desc& d, hipStream_t st) {
     if (lds > 64 * 1024) {
         // above the default dynamic-LDS limit: opt in once per instantiation (160 KiB per CU on gfx950); std::call_once keeps
         // concurrent first calls from different host threads safe (the header promises thread safety)
-        std::call_once(g_tile_lds_once<BM, BN, NS, WM, WN>, [lds] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, true, false, false, NS, WM, WN>),
+        std::call_once(g_tile_lds_once<BM, BN, NS, WM, WN, F16>, [lds] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, true, false, false, NS, WM, WN, F16>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if constexpr (GEGLU_OK)
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, false, true, false, NS, WM, WN>),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, false, true, false, NS, WM, WN, F16>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, false, false, false, NS, WM, WN>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, false, false, false, NS, WM, WN, F16>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         });
     }
@@ -1394,53 +1408,28 @@ int launch_tile(const seer_gemm_desc& d, hipStream_t st) {
     if ((d.colsum || d.colsum_fx) && (geglu || !tile_colsum_ok<BM, BN, NS, WM, WN>() || !colsum_store_ok(d))) return SEER_EINVAL;
     if ((d.rowstat || d.ln_rowstat) && !tile_ln_ok<BM, BN, NS, WM, WN>()) return SEER_EINVAL;
     if (conv) {
-        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, true, false, false, NS, WM, WN>), grid, dim3(64 * WM * WN), lds, st, d);
+        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, true, false, false, NS, WM, WN, F16>), grid, dim3(64 * WM * WN), lds, st, d);
     } else if (geglu) {
         if constexpr (GEGLU_OK)
-            hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, true, false, NS, WM, WN>), grid, dim3(64 * WM * WN), lds, st, d);
+            hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, true, false, NS, WM, WN, F16>), grid, dim3(64 * WM * WN), lds, st, d);
         else
             return SEER_EINVAL;
     } else {
-        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, false, false, NS, WM, WN>), grid, dim3(64 * WM * WN), lds, st, d);
+        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, false, false, NS, WM, WN, F16>), grid, dim3(64 * WM * WN), lds, st, d);
     }
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }
 
-template <int BM, int BN, int NS>
-std::once_flag g_tile_f16_lds_once;
-
-// SEER_EPI_F16 launches (the VAE): plain and conv, unsplit, the tiles AUTO reaches on the VAE's shapes
-template <int BM, int BN, int NS>
-int launch_tile_f16(const seer_gemm_desc& d, hipStream_t st) {
-    const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
-    dim3 grid(tiles_m * tiles_n, 1, d.batch > 1 ? d.batch : 1);
-    const size_t lds = (size_t)(NS == 0 ? 2 : NS) * (BM + BN) * BK * sizeof(bf16);
-    if (lds > 64 * 1024) {
-        std::call_once(g_tile_f16_lds_once<BM, BN, NS>, [lds] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, true, false, false, NS, 2, 2, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_kernel<BM, BN, false, false, false, NS, 2, 2, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        });
-    }
-    if (d.mode == SEER_GEMM_CONV3X3)
-        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, true, false, false, NS, 2, 2, true>), grid, dim3(256), lds, st, d);
-    else
-        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, false, false, NS, 2, 2, true>), grid, dim3(256), lds, st, d);
-    SEER_LAUNCH_CHECK();
-    return SEER_OK;
-}
-
-template <int BM, int BN, int NS>
+template <int BM, int BN, int NS, bool F16 = false>
 int launch_split_tile(const seer_gemm_desc& d, hipStream_t st) {
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, 1, d.splits);
     const size_t lds = (size_t)(NS == 0 ? 2 : NS) * (BM + BN) * BK * sizeof(bf16);
     if (d.mode == SEER_GEMM_CONV3X3)
-        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, true, false, true, NS>), grid, dim3(256), lds, st, d);
+        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, true, false, true, NS, 2, 2, F16>), grid, dim3(256), lds, st, d);
     else
-        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, false, true, NS>), grid, dim3(256), lds, st, d);
+        hipLaunchKernelGGL((seer_gemm_kernel<BM, BN, false, false, true, NS, 2, 2, F16>), grid, dim3(256), lds, st, d);
     SEER_LAUNCH_CHECK();
     if (d.colsum_fx) {
         if (d.epilogue & (SEER_EPI_OUT_F32 | SEER_EPI_TRANS_OUT | SEER_EPI_GEGLU)) return SEER_EINVAL;
@@ -1463,13 +1452,17 @@ int launch_split_tile(const seer_gemm_desc& d, hipStream_t st) {
     return SEER_OK;
 }
 
-int launch_split(const seer_gemm_desc& d, hipStream_t st) {
-    if (d.tile == SEER_TILE_64x64) return launch_split_tile<64, 64, 0>(d, st);        // register-staged (A/B testing)
-    if (d.tile == SEER_TILE_G64x64_3) return launch_split_tile<64, 64, 3>(d, st);
-    if (d.tile == SEER_TILE_G128x128_2) return launch_split_tile<128, 128, 2>(d, st);
-    if (d.tile == SEER_TILE_G96x160_2) return launch_split_tile<96, 160, 2>(d, st);
+template <bool F16>
+int launch_split_t(const seer_gemm_desc& d, hipStream_t st) {
+    if (d.tile == SEER_TILE_64x64) return launch_split_tile<64, 64, 0, F16>(d, st);        // register-staged (A/B testing)
+    if (d.tile == SEER_TILE_G64x64_3) return launch_split_tile<64, 64, 3, F16>(d, st);
+    if (d.tile == SEER_TILE_G128x128_2) return launch_split_tile<128, 128, 2, F16>(d, st);
+    if (d.tile == SEER_TILE_G96x160_2) return launch_split_tile<96, 160, 2, F16>(d, st);
     // auto: prepare() already wrote its tile choice into d.tile; anything else keeps the 64x64 ring
-    return launch_split_tile<64, 64, 3>(d, st);
+    return launch_split_tile<64, 64, 3, F16>(d, st);
+}
+int launch_split(const seer_gemm_desc& d, hipStream_t st) {
+    return (d.epilogue & SEER_EPI_F16) ? launch_split_t<true>(d, st) : launch_split_t<false>(d, st);
 }
 
 // validate + normalise a descriptor; returns SEER_OK and the number of K slices the call will use in *splits
@@ -1518,7 +1511,7 @@ int prepare(seer_gemm_desc& d, int* splits) {
 
     // split-K decision: few output tiles and a long K loop (deep-level convs / linears, M = 384 .. 1536)
     int s = 1;
-    const bool can_split = d.batch == 1 && !geglu && !(d.epilogue & (SEER_EPI_TRANS_OUT | SEER_EPI_ROTARY | SEER_EPI_F16)) &&
+    const bool can_split = d.batch == 1 && !geglu && !(d.epilogue & (SEER_EPI_TRANS_OUT | SEER_EPI_ROTARY)) &&
                            (d.tile == SEER_TILE_AUTO || d.tile == SEER_TILE_64x64 || d.tile == SEER_TILE_G64x64_3 ||
                             d.tile == SEER_TILE_G128x128_2 || d.tile == SEER_TILE_G96x160_2) &&
                            d.splits != 1;
@@ -1770,7 +1763,7 @@ extern "C" int32_t seer_gemm_colsum_rows(const seer_gemm_desc* desc) {
 int ln_resolve(const seer_gemm_desc& in) {
     seer_gemm_desc d = in;
     const bool geglu = (d.epilogue & SEER_EPI_GEGLU) != 0;
-    if (d.mode != SEER_GEMM_PLAIN || d.batch > 1 || (d.epilogue & (SEER_EPI_F16 | SEER_EPI_OUT_F32 | SEER_EPI_TRANS_OUT | SEER_EPI_SILU)))
+    if (d.mode != SEER_GEMM_PLAIN || d.batch > 1 || (d.epilogue & (SEER_EPI_OUT_F32 | SEER_EPI_TRANS_OUT | SEER_EPI_SILU)))
         return 0;
     if (d.ldc % 8 || d.N % (geglu ? 16 : 8) || (reinterpret_cast<uintptr_t>(d.C) & 15)) return 0;      // the kernel's `staged`
     if (d.rowstat && (geglu || d.colsum || d.colsum_fx)) return 0;
@@ -1865,16 +1858,11 @@ extern "C" int seer_gemm_bf16(const seer_gemm_desc* desc, void* stream) {
     if (requested == SEER_TILE_WS || requested == SEER_TILE_AUTO_TILED) d.tile = SEER_TILE_AUTO;   // the tile kernel picks its own
 
     const int tile = resolve_tile(d);
-    if (d.epilogue & SEER_EPI_F16) {
-        if (d.colsum || d.colsum_fx || (d.epilogue & (SEER_EPI_GEGLU | SEER_EPI_ROTARY))) return SEER_EINVAL;
-        switch (tile) {
-            case SEER_TILE_G128x128_2: return launch_tile_f16<128, 128, 2>(d, st);
-            case SEER_TILE_G128x64_3: return launch_tile_f16<128, 64, 3>(d, st);
-            case SEER_TILE_G64x64_5: return launch_tile_f16<64, 64, 5>(d, st);
-            case SEER_TILE_64x64: return launch_tile_f16<64, 64, 0>(d, st);
-            default: return d.K / BK >= 3 ? launch_tile_f16<64, 64, 3>(d, st) : launch_tile_f16<64, 64, 0>(d, st);
-        }
-    }
+    if (d.epilogue & SEER_EPI_F16)
+        return dispatch_tile(tile, [&](auto t) {
+            using T = decltype(t);
+            return launch_tile<T::BM, T::BN, T::NS, T::WM, T::WN, true>(d, st);
+        });
     return dispatch_tile(tile, [&](auto t) {
         using T = decltype(t);
         return launch_tile<T::BM, T::BN, T::NS, T::WM, T::WN>(d, st);

@@ -325,7 +325,7 @@ int ws_launch(const seer_gemm_desc& d, hipStream_t st) {
 bool seer_gemm_ws_eligible(const seer_gemm_desc& d) {
     if (d.mode != SEER_GEMM_PLAIN || d.batch > 1) return false;
     // (rotary: its table lookups are ordinary loads whose first use would drain the LDS-DMA ring -- the tile kernel keeps those)
-    if (d.epilogue & (SEER_EPI_OUT_F32 | SEER_EPI_SILU | SEER_EPI_TRANS_OUT | SEER_EPI_ROTARY)) return false;
+    if (d.epilogue & (SEER_EPI_OUT_F32 | SEER_EPI_SILU | SEER_EPI_TRANS_OUT | SEER_EPI_ROTARY | SEER_EPI_F16)) return false;      // (bf16 operands only)
     if (d.rowvec) return false;
     if (d.K != 320 && d.K != 640) return false;
     if (d.M < 1024) return false;                                   // too few rows to stream

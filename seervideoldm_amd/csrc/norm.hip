@@ -237,7 +237,7 @@ struct GnCsGeom {
     int nslice, nrowblk;
     int rpb;            // rows per row block
 };
-template <bool FX>
+template <bool FX, bool F16 = false>
 __global__ void __launch_bounds__(256) gn_apply_cs_kernel(const bf16* __restrict__ x1, const bf16* __restrict__ x2, GnColsumSrc s1,
                                                           GnColsumSrc s2, GnCsGeom g, int batch, int64_t rows_per_batch,
                                                           float inv_count, float eps, const float* __restrict__ gamma,
@@ -399,14 +399,14 @@ __global__ void __launch_bounds__(256) gn_apply_cs_kernel(const bf16* __restrict
         const int64_t row = (int64_t)b * rows_per_batch + r;
         const u32x4 v = *reinterpret_cast<const u32x4*>(src + row * ld);
         float f[8];
-        unpack8(v, f);
+        unpack8t<F16>(v, f);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float o = f[e] * sc[e] + sh[e];
             if (silu) o = silu_f(o);
             f[e] = o;
         }
-        store16_out(y + row * C + c0, pack8(f));
+        store16_out(y + row * C + c0, pack8t<F16>(f));
     }
 }
 
@@ -436,7 +436,7 @@ bool gn_cs_geom(int C1, int C2, int groups, int batch, int64_t rows_per_batch, G
 }
 
 // LayerNorm: one wave per row, the row lives in registers (<= 3 chunks of 8 per lane: C <= 1536), two-pass statistics.
-template <int MAXC>
+template <int MAXC, bool F16 = false>
 __global__ void __launch_bounds__(256) layernorm_kernel(const bf16* __restrict__ x, int64_t rows, int C, int ldx,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float eps, bf16* __restrict__ y, int ldy) {
@@ -462,7 +462,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const bf16* __restrict__
             const int ch = lane + 64 * i;
             if (ch < nch) {
                 const u32x4 v = *reinterpret_cast<const u32x4*>(x + r * ldx + ch * 8);
-                unpack8(v, f[i]);
+                unpack8t<F16>(v, f[i]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) s += f[i][e];
             }
@@ -485,7 +485,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const bf16* __restrict__
                 float o[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (f[i][e] - mean) * rstd * gm[i][e] + bt[i][e];
-                store16_out(y + r * ldy + ch * 8, pack8(o));
+                store16_out(y + r * ldy + ch * 8, pack8t<F16>(o));
             }
         }
     }
@@ -656,6 +656,15 @@ extern "C" int seer_groupnorm_apply_from_colsums(const void* x1, int32_t C1, con
                                                  int32_t tiles2, int32_t batch, int64_t rows_per_batch, int32_t groups,
                                                  double count, float eps, const float* gamma, const float* beta,
                                                  int32_t silu, void* y, void* stream) {
+    return seer_groupnorm_apply_from_colsums_dt(x1, C1, x2, C2, cs1, phases1, tiles1, cs2, phases2, tiles2, batch, rows_per_batch, groups,
+                                                count, eps, gamma, beta, silu, y, SEER_DT_BF16, stream);
+}
+extern "C" int seer_groupnorm_apply_from_colsums_dt(const void* x1, int32_t C1, const void* x2, int32_t C2, const float* cs1,
+                                                    int32_t phases1, int32_t tiles1, const float* cs2, int32_t phases2,
+                                                    int32_t tiles2, int32_t batch, int64_t rows_per_batch, int32_t groups,
+                                                    double count, float eps, const float* gamma, const float* beta,
+                                                    int32_t silu, void* y, int32_t dtype, void* stream) {
+    if (dtype != SEER_DT_BF16 && dtype != SEER_DT_F16) return SEER_EINVAL;
     if (!x1 || !cs1 || !gamma || !beta || !y || batch <= 0 || rows_per_batch <= 0 || count <= 0) return SEER_EINVAL;
     if (phases1 <= 0 || tiles1 <= 0 || tiles1 % batch) return SEER_EINVAL;
     if (!x2) C2 = 0;
@@ -672,9 +681,14 @@ extern "C" int seer_groupnorm_apply_from_colsums(const void* x1, int32_t C1, con
     }
     const GnColsumSrc s1{cs1, C1, phases1, tiles1}, s2{cs2, C2, C2 ? phases2 : 0, C2 ? tiles2 : 0};
     dim3 grid((unsigned)(g.nslice * g.nrowblk), batch);
-    hipLaunchKernelGGL(gn_apply_cs_kernel<false>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       reinterpret_cast<const bf16*>(x1), reinterpret_cast<const bf16*>(x2), s1, s2, g, batch, rows_per_batch,
-                       (float)(1.0 / count), eps, gamma, beta, silu, reinterpret_cast<bf16*>(y), (float*)nullptr);
+    if (dtype == SEER_DT_F16)
+        hipLaunchKernelGGL((gn_apply_cs_kernel<false, true>), grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           reinterpret_cast<const bf16*>(x1), reinterpret_cast<const bf16*>(x2), s1, s2, g, batch, rows_per_batch,
+                           (float)(1.0 / count), eps, gamma, beta, silu, reinterpret_cast<bf16*>(y), (float*)nullptr);
+    else
+        hipLaunchKernelGGL((gn_apply_cs_kernel<false, false>), grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           reinterpret_cast<const bf16*>(x1), reinterpret_cast<const bf16*>(x2), s1, s2, g, batch, rows_per_batch,
+                           (float)(1.0 / count), eps, gamma, beta, silu, reinterpret_cast<bf16*>(y), (float*)nullptr);
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }
@@ -683,6 +697,14 @@ extern "C" int seer_groupnorm_apply_fx(const void* x1, int32_t C1, const void* x
                                        const int64_t* fx2, int32_t reps2, int32_t batch, int64_t rows_per_batch, int32_t groups,
                                        double count, float eps, const float* gamma, const float* beta, int32_t silu, void* y,
                                        float* stats_out, void* stream) {
+    return seer_groupnorm_apply_fx_dt(x1, C1, x2, C2, fx1, reps1, fx2, reps2, batch, rows_per_batch, groups, count, eps, gamma, beta, silu,
+                                      y, stats_out, SEER_DT_BF16, stream);
+}
+extern "C" int seer_groupnorm_apply_fx_dt(const void* x1, int32_t C1, const void* x2, int32_t C2, const int64_t* fx1, int32_t reps1,
+                                          const int64_t* fx2, int32_t reps2, int32_t batch, int64_t rows_per_batch, int32_t groups,
+                                          double count, float eps, const float* gamma, const float* beta, int32_t silu, void* y,
+                                          float* stats_out, int32_t dtype, void* stream) {
+    if (dtype != SEER_DT_BF16 && dtype != SEER_DT_F16) return SEER_EINVAL;
     if (!x1 || !fx1 || reps1 < 1 || !gamma || !beta || !y || batch <= 0 || rows_per_batch <= 0 || count <= 0) return SEER_EINVAL;
     if (!x2) C2 = 0;
     if (C2 > 0 && (!fx2 || reps2 < 1)) return SEER_EINVAL;
@@ -690,9 +712,14 @@ extern "C" int seer_groupnorm_apply_fx(const void* x1, int32_t C1, const void* x
     if (!gn_cs_geom(C1, C2, groups, batch, rows_per_batch, &g, SEER_GN_FX_BLOCKS)) return SEER_ENOSYS;
     const GnColsumSrc s1{reinterpret_cast<const float*>(fx1), C1, reps1, batch}, s2{reinterpret_cast<const float*>(fx2), C2, C2 ? reps2 : 0, batch};
     dim3 grid((unsigned)(g.nslice * g.nrowblk), batch);
-    hipLaunchKernelGGL(gn_apply_cs_kernel<true>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       reinterpret_cast<const bf16*>(x1), reinterpret_cast<const bf16*>(x2), s1, s2, g, batch, rows_per_batch,
-                       (float)(1.0 / count), eps, gamma, beta, silu, reinterpret_cast<bf16*>(y), stats_out);
+    if (dtype == SEER_DT_F16)
+        hipLaunchKernelGGL((gn_apply_cs_kernel<true, true>), grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           reinterpret_cast<const bf16*>(x1), reinterpret_cast<const bf16*>(x2), s1, s2, g, batch, rows_per_batch,
+                           (float)(1.0 / count), eps, gamma, beta, silu, reinterpret_cast<bf16*>(y), stats_out);
+    else
+        hipLaunchKernelGGL((gn_apply_cs_kernel<true, false>), grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           reinterpret_cast<const bf16*>(x1), reinterpret_cast<const bf16*>(x2), s1, s2, g, batch, rows_per_batch,
+                           (float)(1.0 / count), eps, gamma, beta, silu, reinterpret_cast<bf16*>(y), stats_out);
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }
@@ -770,6 +797,11 @@ extern "C" int seer_groupnorm_stats_fx(const void* x, int32_t C, int32_t batch, 
 
 extern "C" int seer_layernorm(const void* x, int64_t rows, int32_t C, int32_t ldx, const float* gamma,
                               const float* beta, float eps, void* y, int32_t ldy, void* stream) {
+    return seer_layernorm_dt(x, rows, C, ldx, gamma, beta, eps, y, ldy, SEER_DT_BF16, stream);
+}
+extern "C" int seer_layernorm_dt(const void* x, int64_t rows, int32_t C, int32_t ldx, const float* gamma,
+                                 const float* beta, float eps, void* y, int32_t ldy, int32_t dtype, void* stream) {
+    if (dtype != SEER_DT_BF16 && dtype != SEER_DT_F16) return SEER_EINVAL;
     if (!x || !y || !gamma || !beta || rows <= 0 || C <= 0 || C % 8 || ldx % 8 || ldy % 8) return SEER_EINVAL;
     if (C > 64 * 8 * 3) return SEER_ENOSYS;
     int64_t blocks = (rows + 3) / 4;
@@ -777,9 +809,17 @@ extern "C" int seer_layernorm(const void* x, int64_t rows, int32_t C, int32_t ld
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bf16* xb = reinterpret_cast<const bf16*>(x);
     bf16* yb = reinterpret_cast<bf16*>(y);
-    if (C <= 512) hipLaunchKernelGGL(layernorm_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, xb, rows, C, ldx, gamma, beta, eps, yb, ldy);
-    else if (C <= 1024) hipLaunchKernelGGL(layernorm_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, xb, rows, C, ldx, gamma, beta, eps, yb, ldy);
-    else hipLaunchKernelGGL(layernorm_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, st, xb, rows, C, ldx, gamma, beta, eps, yb, ldy);
+#define SEER_LN_LAUNCH(MC, H) hipLaunchKernelGGL((layernorm_kernel<MC, H>), dim3((unsigned)blocks), dim3(256), 0, st, xb, rows, C, ldx, gamma, beta, eps, yb, ldy)
+    if (dtype == SEER_DT_F16) {
+        if (C <= 512) SEER_LN_LAUNCH(1, true);
+        else if (C <= 1024) SEER_LN_LAUNCH(2, true);
+        else SEER_LN_LAUNCH(3, true);
+    } else {
+        if (C <= 512) SEER_LN_LAUNCH(1, false);
+        else if (C <= 1024) SEER_LN_LAUNCH(2, false);
+        else SEER_LN_LAUNCH(3, false);
+    }
+#undef SEER_LN_LAUNCH
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }

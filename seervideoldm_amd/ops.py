@@ -92,12 +92,13 @@ class RowStats:
         return self.buf.to(torch.float64) / float(1 << 24)
 
 
-def fold_layernorm(w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, bias: Optional[torch.Tensor] = None):
+def fold_layernorm(w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, bias: Optional[torch.Tensor] = None, dtype=bf16):
     """LayerNorm(gamma, beta) followed by Linear(w [N, K], bias) as ONE GEMM over the un-normalised rows:
     LN(x) W^T + b = rstd * (x W'^T - mean * wsum) + b',  W' = bf16(gamma (.) W),  wsum = row sums of W' AS ROUNDED (the mean
-    cancels exactly),  b' = W beta + b (fp32).  Returns (W' bf16 [N, K], wsum fp32 [N], b' fp32 [N])."""
+    cancels exactly),  b' = W beta + b (fp32).  Returns (W' bf16 [N, K], wsum fp32 [N], b' fp32 [N]); `dtype` = the engine's 16-bit
+    storage type (torch.float16 under fp16 autocast)."""
     wf = w.float()
-    wp = (wf * gamma.float()[None, :]).to(bf16).contiguous()
+    wp = (wf * gamma.float()[None, :]).to(dtype).contiguous()
     wsum = wp.float().sum(dim=1).contiguous()
     bp = wf @ beta.float()
     if bias is not None:
@@ -357,7 +358,7 @@ def conv_up2x(x: torch.Tensor, w4: torch.Tensor, n_img: int, Hin: int, Win: int,
     """nearest-2x upsample + conv3x3 (Upsample3D, resnet.py:52-57) as four 2x2 phase convs in one launch.
     x: channels-last [n_img*Hin*Win, Cin] bf16; w4: [4, Cout, 4*Cin] from weights.pack_conv3x3_up_phases.
     Returns [n_img*2Hin*2Win, Cout]."""
-    _req(x, bf16, "x"); _req(w4, bf16, "w4")
+    dt = _req16(x, "x"); _req16(w4, "w4", x)
     assert x.is_contiguous() and w4.is_contiguous()
     Cin = x.shape[1]
     four, Cout, K = w4.shape
@@ -366,11 +367,12 @@ def conv_up2x(x: torch.Tensor, w4: torch.Tensor, n_img: int, Hin: int, Win: int,
     d.A, d.W = _p(x), _p(w4)
     d.M, d.N, d.K, d.K1 = n_img * Hin * Win, Cout, K, K
     if out is None:
-        out = torch.empty((n_img * 4 * Hin * Win, Cout), device=x.device, dtype=bf16)
+        out = torch.empty((n_img * 4 * Hin * Win, Cout), device=x.device, dtype=x.dtype)
     d.C, d.ldc = _p(out), out.stride(0)
     if bias is not None:
         _req(bias, torch.float32, "bias"); d.bias = _p(bias)
     d.mode = _lib.SEER_GEMM_CONV3X3
+    d.epilogue = _lib.SEER_EPI_F16 if dt else 0
     d.Hin, d.Win, d.Cin, d.Hout, d.Wout, d.stride, d.upsample = Hin, Win, Cin, 2 * Hin, 2 * Win, 1, 2
     d.batch = 4
     d.tile = tile
@@ -397,8 +399,10 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     [batch * heads * tokens, head_dim] (seer_attn_desc::q_hs / k_hs / v_hs); `out` is always token-major.
     q_prescaled: q already holds q * scale * log2(e) (gemm(..., col_scale=(qk_prescale(head_dim), cols))).
     variant: kernel selection for A/B runs (include/seer_hip.h, seer_attn_desc.variant); 0 = auto."""
-    for t, n in ((q, "q"), (k, "k"), (v, "v"), (out, "out")):
-        _req(t, bf16, n)
+    dt = _req16(q, "q")
+    for t, n in ((k, "k"), (v, "v"), (out, "out")):
+        _req16(t, n, q)
+    for t in (q, k, v, out):
         assert t.dim() == 2 and t.stride(1) == 1
     d = AttnDesc()
     d.Q, d.K, d.V, d.O = _p(q), _p(k), _p(v), _p(out)
@@ -429,7 +433,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     d.batch, d.heads, d.head_dim, d.Sq, d.Sk = batch, heads, head_dim, Sq, Sk
     d.causal = int(causal)
     d.scale = float(scale if scale is not None else head_dim ** -0.5)
-    d.flags = _lib.SEER_ATTN_Q_PRESCALED if q_prescaled else 0
+    d.flags = (_lib.SEER_ATTN_Q_PRESCALED if q_prescaled else 0) | (_lib.SEER_ATTN_F16 if dt else 0)
     d.variant = variant
     if lse is not None:         # training: keep the softmax statistics for seer_attn_bwd
         _req(lse, torch.float32, "lse")
@@ -519,16 +523,18 @@ def groupnorm_apply_from_colsums(x1: torch.Tensor, x2: Optional[torch.Tensor], c
                                  out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """groupnorm_stats_from_colsums + groupnorm_apply as one launch (single-process engines).  Returns None when this channel
     layout has to stay on the two calls (SEER_ENOSYS)."""
-    _req(x1, bf16, "x1")
+    dt = _req16(x1, "x1")
+    if x2 is not None:
+        _req16(x2, "x2", x1)
     rows = x1.shape[0] // batch
     C2 = 0 if x2 is None else x2.shape[1]
     if out is None:
-        out = torch.empty((x1.shape[0], x1.shape[1] + C2), device=x1.device, dtype=bf16)
+        out = torch.empty((x1.shape[0], x1.shape[1] + C2), device=x1.device, dtype=x1.dtype)
     _req(gamma, torch.float32, "gamma"); _req(beta, torch.float32, "beta")
-    rc = _lib.load().seer_groupnorm_apply_from_colsums(
+    rc = _lib.load().seer_groupnorm_apply_from_colsums_dt(
         _p(x1), x1.shape[1], _p(x2), C2, _p(cs1.buf), cs1.phases, cs1.tiles, _p(cs2.buf) if cs2 is not None else None,
         cs2.phases if cs2 is not None else 0, cs2.tiles if cs2 is not None else 0, batch, rows, groups, float(count), float(eps),
-        _p(gamma), _p(beta), int(silu), _p(out), _stream())
+        _p(gamma), _p(beta), int(silu), _p(out), dt, _stream())
     if rc == _lib.SEER_ENOSYS:
         return None
     check(rc, "seer_groupnorm_apply_from_colsums")
@@ -541,20 +547,22 @@ def groupnorm_apply_fx(x1: torch.Tensor, x2: Optional[torch.Tensor], fx1: ColSum
     """GroupNorm (+ SiLU) from the producers' accumulated fixed-point column sums: ONE launch, no statistics pass.  Returns None
     when the channel layout does not slice into whole groups (SEER_ENOSYS).  stats_out [batch, groups, 2] fp32: also receives
     (sum, sum of squares) per (batch element, group) for the backward pass."""
-    _req(x1, bf16, "x1")
+    dt = _req16(x1, "x1")
+    if x2 is not None:
+        _req16(x2, "x2", x1)
     rows = x1.shape[0] // batch
     C2 = 0 if x2 is None else x2.shape[1]
     assert fx1.C == x1.shape[1] and fx1.buf.shape[1] == batch and (x2 is None or (fx2.C == C2 and fx2.buf.shape[1] == batch))
     if out is None:
-        out = torch.empty((x1.shape[0], x1.shape[1] + C2), device=x1.device, dtype=bf16)
+        out = torch.empty((x1.shape[0], x1.shape[1] + C2), device=x1.device, dtype=x1.dtype)
     _req(gamma, torch.float32, "gamma"); _req(beta, torch.float32, "beta")
     if stats_out is not None:
         _req(stats_out, torch.float32, "stats_out")
         assert stats_out.shape == (batch, groups, 2) and stats_out.is_contiguous()
-    rc = _lib.load().seer_groupnorm_apply_fx(_p(x1), x1.shape[1], _p(x2), C2, _p(fx1.buf), fx1.reps,
-                                             _p(fx2.buf) if x2 is not None else None, fx2.reps if x2 is not None else 0, batch, rows,
-                                             groups, float(count), float(eps), _p(gamma), _p(beta), int(silu), _p(out),
-                                             _p(stats_out), _stream())
+    rc = _lib.load().seer_groupnorm_apply_fx_dt(_p(x1), x1.shape[1], _p(x2), C2, _p(fx1.buf), fx1.reps,
+                                                _p(fx2.buf) if x2 is not None else None, fx2.reps if x2 is not None else 0, batch, rows,
+                                                groups, float(count), float(eps), _p(gamma), _p(beta), int(silu), _p(out),
+                                                _p(stats_out), dt, _stream())
     if rc == _lib.SEER_ENOSYS:
         return None
     check(rc, "seer_groupnorm_apply_fx")
@@ -584,12 +592,13 @@ def groupnorm_stats_from_fx(fx1: ColSumsFx, fx2: Optional[ColSumsFx], batch: int
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    _req(x, bf16, "x")
+    dt = _req16(x, "x")
     assert x.dim() == 2 and x.stride(1) == 1
     if out is None:
-        out = torch.empty((x.shape[0], x.shape[1]), device=x.device, dtype=bf16)
-    check(_lib.load().seer_layernorm(_p(x), x.shape[0], x.shape[1], x.stride(0), _p(gamma), _p(beta), float(eps),
-                                     _p(out), out.stride(0), _stream()), "seer_layernorm")
+        out = torch.empty((x.shape[0], x.shape[1]), device=x.device, dtype=x.dtype)
+    _req16(out, "out", x)
+    check(_lib.load().seer_layernorm_dt(_p(x), x.shape[0], x.shape[1], x.stride(0), _p(gamma), _p(beta), float(eps),
+                                        _p(out), out.stride(0), dt, _stream()), "seer_layernorm")
     return out
 
 
@@ -644,7 +653,7 @@ def ff_fused(h: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, beta: torch.
     the ColSumsFx of y, B -> the per-tile ColSums (96-row tiles; only where no tile straddles two batch elements).  Returns None
     (nothing launched) when the shape is not the kernel's: C = 320."""
     M, Cc = h.shape
-    if Cc != FF_FUSED_C or M == 0:
+    if Cc != FF_FUSED_C or M == 0 or h.dtype != bf16:         # (the kernel is bf16 only: an fp16 engine keeps the three launches)
         return None
     _req(h, bf16, "h"); _req(x, bf16, "x"); _req(w1f, bf16, "w1f"); _req(wcf, bf16, "wcf")
     assert x.shape == h.shape and h.stride(1) == 1 and x.stride(1) == 1
@@ -711,13 +720,14 @@ def timestep_embedding(t: torch.Tensor, dim: int, flip_sin_to_cos: bool, freq_sh
 
 def linear_smallm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, silu_in=False,
                   silu_out=False) -> torch.Tensor:
-    _req(x, torch.float32, "x"); _req(w, bf16, "w")
+    _req(x, torch.float32, "x")
+    dt = _req16(w, "w")
     assert x.is_contiguous() and w.is_contiguous()
     B, K = x.shape
     N = w.shape[0]
     y = torch.empty((B, N), device=x.device, dtype=torch.float32)
-    check(_lib.load().seer_linear_smallm(_p(x), B, K, _p(w), _p(bias), N, int(silu_in), int(silu_out), _p(y),
-                                         _stream()), "seer_linear_smallm")
+    check(_lib.load().seer_linear_smallm_dt(_p(x), B, K, _p(w), _p(bias), N, int(silu_in), int(silu_out), _p(y), dt,
+                                            _stream()), "seer_linear_smallm")
     return y
 
 
@@ -765,11 +775,12 @@ def conv_out(x: torch.Tensor, w_ohwc: torch.Tensor, bias: torch.Tensor, B: int, 
     return y
 
 
-def cast_bf16(x: torch.Tensor) -> torch.Tensor:
+def cast_bf16(x: torch.Tensor, dtype=bf16) -> torch.Tensor:
+    """fp32 -> bf16 (or, dtype=torch.float16, IEEE half: the fp16 engine's context)"""
     _req(x, torch.float32, "x")
     x = x.contiguous()
-    y = torch.empty(x.shape, device=x.device, dtype=bf16)
-    check(_lib.load().seer_cast_f32_bf16(_p(x), x.numel(), _p(y), _stream()), "seer_cast_f32_bf16")
+    y = torch.empty(x.shape, device=x.device, dtype=dtype)
+    check(_lib.load().seer_cast_f32_dt(_p(x), x.numel(), _p(y), _req16(y, "y"), _stream()), "seer_cast_f32_dt")
     return y
 
 

@@ -62,7 +62,7 @@ class SeerUNet(nn.Module):
                  up_block_types=("UpBlock3D", "CrossAttnUpBlock3D", "CrossAttnUpBlock3D", "CrossAttnUpBlock3D"),
                  block_out_channels=(320, 640, 1280, 1280), layers_per_block=2, downsample_padding=1,
                  mid_block_scale_factor=1, act_fn="silu", norm_num_groups=32, norm_eps=1e-5,
-                 cross_attention_dim=1280, attention_head_dim=8):
+                 cross_attention_dim=1280, attention_head_dim=8, compute_dtype=None):
         super().__init__()
         # the reference overwrites the block types / downsample padding with constants (unet_3d_condition.py:90-92)
         if len(block_out_channels) != 4:
@@ -87,6 +87,13 @@ class SeerUNet(nn.Module):
         self.gn_colsums = True          # GroupNorm statistics from the producing GEMM's column sums (read by prepare())
         self._ops_backend = hip_ops     # tests may inject tests/torch_ops_backend.py to exercise the host logic on CPU
         self._ctx_slice = None
+        # 16-bit storage type of activations and weights (fp32 accumulation and statistics either way): bf16 = the reference under
+        # `mixed_precision: "bf16"` (BASELINE config 2), torch.float16 = under "fp16" (what every shipped yaml says:
+        # configs/inference_base.yaml:16, eval.yaml:22, train.yaml:33).  Set here, by `unet.compute_dtype = ...`, or -- None --
+        # taken from the autocast state of the call (accelerate's prepare() wraps forward in torch.autocast with the configured type).
+        if compute_dtype not in (None, torch.bfloat16, torch.float16):
+            raise ValueError(f"compute_dtype {compute_dtype!r}: torch.bfloat16 or torch.float16 (fp32 accumulation either way)")
+        self.compute_dtype = compute_dtype
 
     # ---- construction / weights -------------------------------------------------------------------------------
     @classmethod
@@ -122,9 +129,20 @@ class SeerUNet(nn.Module):
         self._engine = None
         return super()._apply(fn, *a, **k)
 
-    def prepare(self):
+    def _dtype_of_call(self):
+        """the 16-bit storage type this forward runs in: compute_dtype, else the autocast type when the caller wrapped the call in
+        torch.autocast (accelerate.prepare under mixed_precision fp16 / bf16), else bf16"""
+        if self.compute_dtype is not None:
+            return self.compute_dtype
+        if torch.is_autocast_enabled():
+            dt = torch.get_autocast_gpu_dtype()
+            if dt in (torch.bfloat16, torch.float16):
+                return dt
+        return torch.bfloat16
+
+    def prepare(self, dtype=None):
         """(re)build the packed device weights from the current parameters; call after editing parameters in place."""
-        self._engine = _Engine(self, ops=self._ops_backend, shard=self._shard)
+        self._engine = _Engine(self, ops=self._ops_backend, shard=self._shard, dtype=dtype or self._dtype_of_call())
         return self
 
     # ---- toggles of the reference surface (SURVEY 8(b)) ---------------------------------------------------------
@@ -152,8 +170,9 @@ class SeerUNet(nn.Module):
                 cond_frame: int = 0, return_attn: bool = False) -> torch.Tensor:
         if not sample.is_cuda and self._ops_backend is hip_ops:
             raise hip_ops._lib.SeerHipError("SeerUNet.forward needs ROCm tensors: the HIP kernels are the only compute path")
-        if self._engine is None or self._engine.device != sample.device:
-            self.prepare()
+        dt = self._dtype_of_call()
+        if self._engine is None or self._engine.device != sample.device or self._engine.dt != dt:
+            self.prepare(dt)
         if self.config.center_input_sample:
             sample = 2 * sample - 1.0
         t = timestep
@@ -196,8 +215,9 @@ FX_MAX_ROWS_PB = int(os.environ.get("SEER_FX_MAX_ROWS_PB", "4096"))        # row
 class _Engine:
     """packed weights + the kernel schedule of one SeerUNet forward."""
 
-    def __init__(self, model: SeerUNet, ops=hip_ops, shard=None, fold_ln=True):
+    def __init__(self, model: SeerUNet, ops=hip_ops, shard=None, fold_ln=True, dtype=bf16):
         self.ops = ops
+        self.dt = dtype                 # 16-bit storage type of activations and packed weights (bf16, or IEEE half under fp16 autocast)
         self.cfg = model.config
         self.shard = shard              # parallel.FrameShard or None
         p0 = next(model.parameters())
@@ -230,7 +250,7 @@ class _Engine:
         # ff.net.2 and proj_out as one two-source GEMM (model.ff_fold = False / SEER_FF_FOLD=0: two launches; see _pack)
         self.ff_fold = bool(getattr(model, "ff_fold", os.environ.get("SEER_FF_FOLD", "1") != "0"))
         # ... and, at 320 channels, the whole feed-forward with it as ONE launch (model.ff_fused = False / SEER_FF_FUSED=0: off)
-        self.ff_fused = self.ff_fold and bool(getattr(model, "ff_fused", os.environ.get("SEER_FF_FUSED", "1") != "0"))
+        self.ff_fused = self.ff_fold and self.dt == bf16 and bool(getattr(model, "ff_fused", os.environ.get("SEER_FF_FUSED", "1") != "0"))      # (the fused kernel is bf16 only)
         self.gn_from_colsums = 0
         self.w: Dict[str, torch.Tensor] = {}
         self._pack(sd)
@@ -264,7 +284,7 @@ class _Engine:
         w = self.w
         dev = self.device
         f32 = lambda t: t.to(dev, torch.float32).contiguous()
-        b16 = lambda t: t.to(dev, torch.float32).to(bf16).contiguous()
+        b16 = lambda t: t.to(dev, torch.float32).to(self.dt).contiguous()
         self.resnets: List[str] = []
         self.temb_slices: Dict[str, Tuple[int, int]] = {}
         temb_w, temb_b, off = [], [], 0
@@ -331,7 +351,7 @@ class _Engine:
                     continue
                 wp = pack_conv1x1(sd[k]).to(dev, torch.float32)
                 w2, b2 = f32(sd[tb + ".ff.net.2.weight"]), f32(sd[tb + ".ff.net.2.bias"])
-                w[pth + ".ffproj.w"] = torch.cat([wp, wp @ w2], dim=1).to(bf16).contiguous()           # [C, C + 4C]
+                w[pth + ".ffproj.w"] = torch.cat([wp, wp @ w2], dim=1).to(self.dt).contiguous()           # [C, C + 4C]
                 w[pth + ".ffproj.b"] = (wp @ b2 + f32(sd[pth + ".proj_out.bias"])).contiguous()
                 # 320 channels: norm3, ff.net.0, GEGLU and this GEMM run as ONE launch (ops.ff_fused, csrc/ff_fused.hip), which reads
                 # both matrices in its own fragment order
@@ -342,7 +362,7 @@ class _Engine:
         # sums and beta W^T + b, next to the plain weights (a launch that cannot fold runs layernorm + the plain ones)
         self.wln: Dict[str, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = {}
         if self.ln_fold:
-            fold = self.ops.fold_layernorm
+            fold = self.ops.fold_layernorm if self.dt == bf16 else (lambda *a: self.ops.fold_layernorm(*a, dtype=self.dt))
             for k in sd:
                 if not k.endswith(".norm1.weight") or ".transformer_blocks." not in k:
                     continue
@@ -526,8 +546,8 @@ class _Engine:
         it): the scores are one batched MFMA GEMM over the head-split, zero-padded operands with 1 / log2(e) in its epilogue."""
         HW, Bt = H * W, B * Fr * heads
         dp, Lp = (d + 63) // 64 * 64, (L + 3) // 4 * 4
-        qh = torch.zeros((Bt, HW, dp), device=q.device, dtype=bf16)
-        kh = torch.zeros((Bt, Lp, dp), device=q.device, dtype=bf16)
+        qh = torch.zeros((Bt, HW, dp), device=q.device, dtype=q.dtype)
+        kh = torch.zeros((Bt, Lp, dp), device=q.device, dtype=q.dtype)
         qh[:, :, :d] = q.reshape(B * Fr, HW, heads, d).permute(0, 2, 1, 3).reshape(Bt, HW, d)
         kh[:, :L, :d] = k.reshape(B * Fr, L, heads, d).permute(0, 2, 1, 3).reshape(Bt, L, d)
         s = self.ops.gemm_batched(qh, kh, out_f32=True, col_scale=(1.0 / self.ops.LOG2E, Lp))
@@ -630,7 +650,8 @@ class _Engine:
         emb = ops.linear_smallm(emb, w["time_embedding.linear_2.weight"], w["time_embedding.linear_2.bias"])
         self._temb = ops.linear_smallm(emb, w["temb_all.w"], w["temb_all.b"], silu_in=True)
 
-        x = ops.conv_in(sample, w["conv_in.weight"], w["conv_in.bias"])
+        x = ops.conv_in(sample, w["conv_in.weight"], w["conv_in.bias"]) if self.dt == bf16 else \
+            ops.conv_in(sample, w["conv_in.weight"], w["conv_in.bias"], dtype=self.dt)
         skips = [x]
         geo = (B, Fr, H, W)
         for i in range(n):
@@ -678,9 +699,9 @@ class _Engine:
         same shape is written into them in place, so the captured hipGraphs -- which read them by address -- stay valid and a
         new prompt costs 1 + 16 small launches, not a re-capture."""
         key = (context.data_ptr(), context._version, tuple(context.shape), context.dtype)
-        if key != self._kv_key:
+        if key != self._kv_key:     # (an engine is built per storage type: the cached K|V never mix types)
             c = context.reshape(-1, context.shape[-1])
-            new = self.ops.cast_bf16(c.float()) if c.dtype != bf16 else c
+            new = (self.ops.cast_bf16(c.float()) if self.dt == bf16 else self.ops.cast_bf16(c.float(), self.dt)) if c.dtype != self.dt else c
             old = getattr(self, "_ctx_bf16", None)
             if old is not None and old.shape == new.shape and self._kv_cache:
                 old.copy_(new)

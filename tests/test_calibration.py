@@ -28,3 +28,19 @@ def test_bf16_autocast_error_of_the_oracle_matches_the_committed_calibration():
     rel = ((y16 - y32).norm() / y32.norm()).item()
     print(f"oracle bf16 autocast vs fp32: rel_l2 {rel:.4g}; committed (reference): {calib['rel_l2']:.4g}")
     assert 0.5 * calib["rel_l2"] < rel < 2.0 * calib["rel_l2"]
+
+
+def test_fp16_autocast_error_of_the_oracle_matches_the_committed_calibration():
+    """the same for fp16 autocast (every shipped yaml: mixed_precision "fp16"): tests/golden/calibration_fp16.json sets the
+    tolerance of the fp16-storage engine (tests/test_gpu_unet.py::test_full_size_step_fp16_storage_matches_the_reference)"""
+    calib = json.loads((GOLD / "calibration_fp16.json").read_text())["unet_w320_fp16_autocast_vs_fp32"]
+    g = {k: torch.from_numpy(v) for k, v in np.load(GOLD / "unet_w320_real.npz").items()}
+    sd = synth.synth_state_dict(synth.unet_param_shapes(W320_UNET))
+    y32 = O.unet_forward(sd, W320_UNET, g["sample"], g["timestep"], g["context"], cond_frame=0)
+    with torch.autocast("cpu", dtype=torch.float16):
+        y16 = O.unet_forward(sd, W320_UNET, g["sample"], g["timestep"], g["context"], cond_frame=0).float()
+    rel = ((y16 - y32).norm() / y32.norm()).item()
+    print(f"oracle fp16 autocast vs fp32: rel_l2 {rel:.4g}; committed (reference): {calib['rel_l2']:.4g}")
+    assert 0.5 * calib["rel_l2"] < rel < 2.0 * calib["rel_l2"]
+    bf = json.loads((GOLD / "calibration_bf16.json").read_text())["unet_w320_bf16_autocast_vs_fp32"]
+    assert calib["rel_l2"] < bf["rel_l2"] / 4          # three more significand bits
