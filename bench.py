@@ -67,6 +67,9 @@ def parse():
                          "finished after this long is abandoned: rank 0 prints the line with what was measured so far, every rank exits")
     ap.add_argument("--no-capture-collectives", action="store_true",
                     help="N > 1: keep the RCCL exchanges of the partitioned step eager between hipGraph segments")
+    ap.add_argument("--dtype", choices=("bf16", "fp16"), default="bf16",
+                    help="16-bit storage type of the UNet engine: bf16 = BASELINE config 2 (the headline line); fp16 = the mixed_precision every "
+                         "shipped yaml names (SeerUNet(compute_dtype=torch.float16)), an extra measurement")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="sthv2",
                     help="default = BASELINE.json's metric configuration; the others are extra measurements")
     return ap.parse_args()
@@ -290,7 +293,7 @@ def main():
     from seervideoldm_amd.profiler import TimedOps
 
     cfg = dict(synth.SD15_UNET_CFG)
-    model = SeerUNet(**cfg).to(device)
+    model = SeerUNet(**cfg, compute_dtype=torch.float16 if args.dtype == "fp16" else torch.bfloat16).to(device)
     sd = synth.synth_state_dict(synth.unet_param_shapes(cfg), device=device)
     model.load_state_dict(sd, strict=True)
     sd_cpu = None
@@ -358,7 +361,7 @@ def main():
             "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "strong" if (world > 1 and "independent samples" not in par) else "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload]["name"] + ", "
                                    "full-width SeerUNet 1.08G params, 50-step DDIM, scale 7.5",
                        "global_batch": WORKLOADS[args.workload]["b"], "parallelism": par,

@@ -355,6 +355,12 @@ int seer_groupnorm_apply_fx_dt(const void* x1, int32_t C1, const void* x2, int32
 int seer_ff_fused_c320(const void* h, int32_t ldh, const void* x, int32_t ldx, void* y, int32_t ldy, int64_t M,
                        const float* gamma, const float* beta, float eps, const void* w1f, const float* b1, const void* wcf,
                        const float* bcat, int64_t* colsum_fx, int64_t fx_rows, int32_t fx_reps, float* colsum_tiles, void* stream);
+/* ... with h, x, y and the two packed weight matrices in the storage type `dtype` (SEER_DT_*; the pack entry points move 16-bit
+ * words and serve both) */
+int seer_ff_fused_c320_dt(const void* h, int32_t ldh, const void* x, int32_t ldx, void* y, int32_t ldy, int64_t M,
+                          const float* gamma, const float* beta, float eps, const void* w1f, const float* b1, const void* wcf,
+                          const float* bcat, int64_t* colsum_fx, int64_t fx_rows, int32_t fx_reps, float* colsum_tiles, int32_t dtype,
+                          void* stream);
 /* w1 [2560][320] bf16 -> out (same size): [chunk 20][wave 4][K step 5][k32 2][value | gate][lane 64][8 bf16], element
  * w1[128 c + 32 w + 16 f + (lane & 15)][64 ks + 32 k32 + 8 (lane >> 4) + e]: every fragment load of the kernel is one contiguous KiB */
 int seer_ff_fused_pack_w1(const void* w1, void* out, void* stream);

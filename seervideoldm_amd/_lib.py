@@ -112,6 +112,8 @@ SIGNATURES = {
     "seer_groupnorm_apply_fx_dt": ([_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i64, _i32, _f64, _f32, _vp, _vp, _i32, _vp, _vp, _i32,
                                     _vp], C.c_int),
     "seer_ff_fused_c320": ([_vp, _i32, _vp, _i32, _vp, _i32, _i64, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp], C.c_int),
+    "seer_ff_fused_c320_dt": ([_vp, _i32, _vp, _i32, _vp, _i32, _i64, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp],
+                              C.c_int),
     "seer_ff_fused_pack_w1": ([_vp, _vp, _vp], C.c_int),
     "seer_ff_fused_pack_wcat": ([_vp, _vp, _vp], C.c_int),
     "seer_gemm_colsum_fx_layout": ([C.POINTER(GemmDesc), _i32, C.POINTER(C.c_int32)], C.c_int32),

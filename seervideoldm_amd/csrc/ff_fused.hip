@@ -144,6 +144,9 @@ template <int N> __device__ __forceinline__ void bias_got(f32x4& a, f32x4& b) {
 }
 __device__ __forceinline__ bf16x8 as_bf(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
 
+// F16: h, x, y and both weight matrices hold IEEE half (the fp16 engine): same loads, LDS images and schedule; the MFMA opcode and
+// the pack / unpack of LayerNorm, GEGLU, residual and column sums differ
+template <bool F16>
 __global__ void __launch_bounds__(256, 1) seer_ff_fused_c320_kernel(const FfArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const T = smem;
@@ -199,7 +202,7 @@ __global__ void __launch_bounds__(256, 1) seer_ff_fused_c320_kernel(const FfArgs
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
-            for (int j = 0; j < 5; ++j) Y[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w5[j]), as_bf(a.r[i]), Y[i][j], 0, 0, 0);
+            for (int j = 0; j < 5; ++j) Y[i][j] = mma16<F16>(as_bf(w5[j]), as_bf(a.r[i]), Y[i][j]);
     };
 
     // ================= phase 0: the tile of h; gamma, beta, b1 into LDS; Y = h Wp^T (K steps 0..4 of [Wp | Wp W2]) =================
@@ -261,7 +264,7 @@ __global__ void __launch_bounds__(256, 1) seer_ff_fused_c320_kernel(const FfArgs
 #pragma unroll
             for (int q = 0; q < 5; ++q) {
                 const u32x4 raw = *reinterpret_cast<const u32x4*>(T + q * FF_PANEL + row * 128 + (lane & 7) * 16);
-                unpack8(raw, v[q]);
+                unpack8t<F16>(raw, v[q]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) sm += v[q][e];
             }
@@ -285,7 +288,7 @@ __global__ void __launch_bounds__(256, 1) seer_ff_fused_c320_kernel(const FfArgs
                     o[e] = (v[q][e] - mean) * rstd * g0[e] + b0[e];
                     o[4 + e] = (v[q][4 + e] - mean) * rstd * g1[e] + b1[e];
                 }
-                *reinterpret_cast<u32x4*>(T + q * FF_PANEL + row * 128 + (lane & 7) * 16) = pack8(o);
+                *reinterpret_cast<u32x4*>(T + q * FF_PANEL + row * 128 + (lane & 7) * 16) = pack8t<F16>(o);
             }
         }
     }
@@ -311,8 +314,8 @@ __global__ void __launch_bounds__(256, 1) seer_ff_fused_c320_kernel(const FfArgs
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            H[i0 + i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w2[0]), as_bf(a.r[i]), H[i0 + i][0], 0, 0, 0);
-            H[i0 + i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w2[1]), as_bf(a.r[i]), H[i0 + i][1], 0, 0, 0);
+            H[i0 + i][0] = mma16<F16>(as_bf(w2[0]), as_bf(a.r[i]), H[i0 + i][0]);
+            H[i0 + i][1] = mma16<F16>(as_bf(w2[1]), as_bf(a.r[i]), H[i0 + i][1]);
         }
     };
     // GEGLU of row fragment i of H: g = (value + b) * gelu(gate + b), bf16: columns 16 wave + 4 fq .. + 3 of row 16 i + frow
@@ -323,8 +326,8 @@ __global__ void __launch_bounds__(256, 1) seer_ff_fused_c320_kernel(const FfArgs
 #pragma unroll
         for (int e = 0; e < 4; ++e) ge[e] = (FF_PROBE & 8) ? gat[e] : gelu_erf_f(gat[e]);
         u32x2 o;
-        o[0] = pack2(val[0] * ge[0], val[1] * ge[1]);
-        o[1] = pack2(val[2] * ge[2], val[3] * ge[3]);
+        o[0] = pack2t<F16>(val[0] * ge[0], val[1] * ge[1]);
+        o[1] = pack2t<F16>(val[2] * ge[2], val[3] * ge[3]);
         return o;
     };
     const unsigned gcell = (unsigned)(frow * 128 + (fq & 1) * 8) + (((unsigned)(2 * wave + (fq >> 1)) ^ swz) * 16);   // (16 i + frow) & 7 = frow & 7
@@ -335,7 +338,7 @@ __global__ void __launch_bounds__(256, 1) seer_ff_fused_c320_kernel(const FfArgs
             return;
         }
 #pragma unroll
-        for (int j = 0; j < 5; ++j) Y[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w5[j]), as_bf(a), Y[i][j], 0, 0, 0);
+        for (int j = 0; j < 5; ++j) Y[i][j] = mma16<F16>(as_bf(w5[j]), as_bf(a), Y[i][j]);
     };
     // The two halves of H(c) = 20 sub steps j = (half, ks, k32) of 6 MFMAs.  The activation fragments of sub step j + 3 are requested
     // before the MFMAs of sub step j (four buffers in rotation, three requests in flight, every wait counted: the LDS returns in order).
@@ -467,10 +470,9 @@ __global__ void __launch_bounds__(256, 1) seer_ff_fused_c320_kernel(const FfArgs
             u32x2* cell = reinterpret_cast<u32x2*>(T + pnl * FF_PANEL + row * 128 + ((ch ^ (row & 7)) * 16) + (n & 7) * 2);
             const u32x2 xv = *cell;
             u32x2 o;
-            o[0] = pack2(Y[i][j][0] + bb[0] + __builtin_bit_cast(float, xv[0] << 16),
-                         Y[i][j][1] + bb[1] + __builtin_bit_cast(float, xv[0] & 0xffff0000u));
-            o[1] = pack2(Y[i][j][2] + bb[2] + __builtin_bit_cast(float, xv[1] << 16),
-                         Y[i][j][3] + bb[3] + __builtin_bit_cast(float, xv[1] & 0xffff0000u));
+            const f32x2 x01 = unpack2t<F16>(xv[0]), x23 = unpack2t<F16>(xv[1]);
+            o[0] = pack2t<F16>(Y[i][j][0] + bb[0] + x01[0], Y[i][j][1] + bb[1] + x01[1]);
+            o[1] = pack2t<F16>(Y[i][j][2] + bb[2] + x23[0], Y[i][j][3] + bb[3] + x23[1]);
             *cell = o;
         }
     }
@@ -499,7 +501,7 @@ __global__ void __launch_bounds__(256, 1) seer_ff_fused_c320_kernel(const FfArgs
                 const int row = 16 * s6 + r;
                 const u32x4 v = *reinterpret_cast<const u32x4*>(T + pnl * FF_PANEL + row * 128 + ((ch ^ (row & 7)) * 16));
                 float f[8];
-                unpack8(v, f);
+                unpack8t<F16>(v, f);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { sm[e] += f[e]; sq[e] += f[e] * f[e]; }
             }
@@ -579,6 +581,14 @@ extern "C" int seer_ff_fused_c320(const void* h, int32_t ldh, const void* x, int
                                   const float* gamma, const float* beta, float eps, const void* w1f, const float* b1, const void* wcf,
                                   const float* bcat, int64_t* colsum_fx, int64_t fx_rows, int32_t fx_reps, float* colsum_tiles,
                                   void* stream) {
+    return seer_ff_fused_c320_dt(h, ldh, x, ldx, y, ldy, M, gamma, beta, eps, w1f, b1, wcf, bcat, colsum_fx, fx_rows, fx_reps, colsum_tiles,
+                                 SEER_DT_BF16, stream);
+}
+extern "C" int seer_ff_fused_c320_dt(const void* h, int32_t ldh, const void* x, int32_t ldx, void* y, int32_t ldy, int64_t M,
+                                     const float* gamma, const float* beta, float eps, const void* w1f, const float* b1, const void* wcf,
+                                     const float* bcat, int64_t* colsum_fx, int64_t fx_rows, int32_t fx_reps, float* colsum_tiles,
+                                     int32_t dtype, void* stream) {
+    if (dtype != SEER_DT_BF16 && dtype != SEER_DT_F16) return SEER_EINVAL;
     if (!h || !x || !y || !gamma || !beta || !w1f || !b1 || !wcf || !bcat) return SEER_EINVAL;
     if (M <= 0 || M >= ((int64_t)1 << 31) - FF_BM || ldh % 8 || ldx % 8 || ldy % 8 || ldh < FF_C || ldx < FF_C || ldy < FF_C) return SEER_EINVAL;
     if ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(w1f) |
@@ -587,7 +597,8 @@ extern "C" int seer_ff_fused_c320(const void* h, int32_t ldh, const void* x, int
     if (colsum_fx && (fx_rows < FF_BM || fx_rows % 16 || M % fx_rows || fx_reps <= 0)) return SEER_EINVAL;
     if (colsum_tiles && M % FF_BM) return SEER_EINVAL;
     std::call_once(g_ff_once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_ff_fused_c320_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_ff_fused_c320_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_ff_fused_c320_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
     });
     FfArgs a;
     a.h = reinterpret_cast<const bf16*>(h); a.x = reinterpret_cast<const bf16*>(x); a.y = reinterpret_cast<bf16*>(y);
@@ -595,7 +606,10 @@ extern "C" int seer_ff_fused_c320(const void* h, int32_t ldh, const void* x, int
     a.gamma = gamma; a.beta = beta; a.eps = eps;
     a.w1f = reinterpret_cast<const unsigned char*>(w1f); a.b1 = b1; a.wcf = reinterpret_cast<const unsigned char*>(wcf); a.bcat = bcat;
     a.colsum_fx = colsum_fx; a.fx_rows = (int)fx_rows; a.fx_reps = fx_reps; a.colsum_tiles = colsum_tiles;
-    hipLaunchKernelGGL(seer_ff_fused_c320_kernel, dim3((unsigned)((M + FF_BM - 1) / FF_BM)), dim3(256), FF_LDS, reinterpret_cast<hipStream_t>(stream), a);
+    if (dtype == SEER_DT_F16)
+        hipLaunchKernelGGL(seer_ff_fused_c320_kernel<true>, dim3((unsigned)((M + FF_BM - 1) / FF_BM)), dim3(256), FF_LDS, reinterpret_cast<hipStream_t>(stream), a);
+    else
+        hipLaunchKernelGGL(seer_ff_fused_c320_kernel<false>, dim3((unsigned)((M + FF_BM - 1) / FF_BM)), dim3(256), FF_LDS, reinterpret_cast<hipStream_t>(stream), a);
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }

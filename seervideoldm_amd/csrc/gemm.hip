@@ -101,29 +101,6 @@ constexpr bool tile_ln_ok() {
     return !PP8 && BM <= NT && BM * CPITCH + 4096 + BM * 8 <= (NS == 0 ? 2 : NS) * STAGE * (int)sizeof(bf16);
 }
 
-// F16: A, A2, W, residual and C hold IEEE half instead of bf16 (SEER_EPI_F16: the VAE, which the reference runs in fp32 --
-// 11 significand bits instead of 8 at the same MFMA rate).  Same 16-bit loads and LDS image; only the MFMA opcode and the
-// pack / unpack of the epilogue differ.
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-template <bool F16>
-__device__ __forceinline__ f32x4 mma16(const bf16x8& a, const bf16x8& b, const f32x4& c) {
-    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-}
-template <bool F16>
-__device__ __forceinline__ unsigned int pack2t(float lo, float hi) {
-    if constexpr (F16) return pack2h(lo, hi);
-    else return pack2(lo, hi);
-}
-template <bool F16>
-__device__ __forceinline__ f32x2 unpack2t(unsigned int v) {
-    if constexpr (F16) {
-        return f32x2{half_bits_to_f32(v), half_bits_to_f32(v >> 16)};
-    } else {
-        return f32x2{__builtin_bit_cast(float, v << 16), __builtin_bit_cast(float, v & 0xffff0000u)};
-    }
-}
-
 template <int BM, int BN, bool CONV, bool GEGLU, bool SPLIT, int NS, int WM = 2, int WN = 2, bool F16 = false>
 __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm_desc p) {
     constexpr int NT = 64 * WM * WN;               // threads per block
@@ -1850,7 +1827,7 @@ extern "C" int seer_gemm_bf16(const seer_gemm_desc* desc, void* stream) {
     }
     d.splits = 1;
     d.tile = desc->tile == SEER_TILE_T256x320 ? SEER_TILE_AUTO : desc->tile;            // prepare() may have picked a split tile; unsplit launches choose their own below
-    if (!d.colsum && !d.colsum_fx && !rows_ln && !(d.epilogue & SEER_EPI_F16) && seer_gemm_ws_eligible(d) &&
+    if (!d.colsum && !d.colsum_fx && !rows_ln && seer_gemm_ws_eligible(d) &&
         (requested == SEER_TILE_WS || (requested == SEER_TILE_AUTO && seer_gemm_ws_profitable(d)))) {
         const int rc_ws = seer_gemm_ws_launch(d, st);
         if (rc_ws != SEER_ENOSYS) return rc_ws;

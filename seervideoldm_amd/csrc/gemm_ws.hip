@@ -70,7 +70,7 @@ __device__ __forceinline__ void ws_wait_vmcnt(int n) {       // n is wave-unifor
 // the W fragments are a register array and must be indexed statically (the K loop is fully unrolled).
 // LDS (dynamic): [3 slots: NK x (ROWS rows x 128 B), 16-byte chunks XOR-swizzled by row & 7 as in gemm.hip]
 //                [8 wave-private areas: a 32-row staging tile + the wave's CW bias values]
-template <int CW, int NK, bool GEGLU>
+template <int CW, int NK, bool GEGLU, bool F16 = false>
 __global__ void __launch_bounds__(512) seer_gemm_ws_kernel(const seer_gemm_desc p, const int n_panels, const int wpp) {
     constexpr int BK = WS_BK;
     constexpr int ROWS = WS_SLOT_BYTES / (NK * BK * 2);      // rows of A per slot: 64 (K = 320) or 32 (K = 640)
@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(512) seer_gemm_ws_kernel(const seer_gemm_desc 
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][j], af[t & 1][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mma16<F16>(wf[t][j], af[t & 1][i], acc[i][j]);
         });
     };
     // ---- epilogue of the block at rows m0 (swapped MFMA: the lane holds 4 consecutive columns n = .. + 4 fq + r of row frow)
@@ -230,8 +230,8 @@ __global__ void __launch_bounds__(512) seer_gemm_ws_kernel(const seer_gemm_desc 
                     for (int r = 0; r < 4; ++r) v[r] *= p.col_scale;
                 }
                 u32x2 o;
-                o[0] = pack2(v[0], v[1]);
-                o[1] = pack2(v[2], v[3]);
+                o[0] = pack2t<F16>(v[0], v[1]);
+                o[1] = pack2t<F16>(v[2], v[3]);
                 *reinterpret_cast<u32x2*>(stg + frow * SPITCH + (jo * 16 + fq * 4) * 2) = o;
             }
             // the wave's 16 rows x CWO columns leave as whole row segments, 16 B per lane (wave-private LDS: no barrier)
@@ -294,10 +294,10 @@ __global__ void __launch_bounds__(512) seer_gemm_ws_kernel(const seer_gemm_desc 
     }
 }
 
-template <int CW, int NK, bool GEGLU>
+template <int CW, int NK, bool GEGLU, bool F16>
 std::once_flag g_ws_lds_once;        // the kernel's dynamic-LDS opt-in has run (namespace scope: no function-local statics)
 
-template <int CW, int NK, bool GEGLU>
+template <int CW, int NK, bool GEGLU, bool F16 = false>
 int ws_launch(const seer_gemm_desc& d, hipStream_t st) {
     constexpr int ROWS = WS_SLOT_BYTES / (NK * WS_BK * 2);
     constexpr int CWO = GEGLU ? CW / 2 : CW;
@@ -307,12 +307,12 @@ int ws_launch(const seer_gemm_desc& d, hipStream_t st) {
     if (wpp < 1) return SEER_ENOSYS;
     if (wpp > slots_m) wpp = slots_m;
     const size_t lds = (size_t)WS_NSLOT * WS_SLOT_BYTES + 8 * (32 * (CWO * 2 + 16) + CW * 4);
-    std::call_once(g_ws_lds_once<CW, NK, GEGLU>, [lds] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_ws_kernel<CW, NK, GEGLU>),
+    std::call_once(g_ws_lds_once<CW, NK, GEGLU, F16>, [lds] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_gemm_ws_kernel<CW, NK, GEGLU, F16>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
     const int grid = 8 * ((n_panels * wpp + 7) / 8);
-    hipLaunchKernelGGL((seer_gemm_ws_kernel<CW, NK, GEGLU>), dim3(grid), dim3(512), lds, st, d, n_panels, wpp);
+    hipLaunchKernelGGL((seer_gemm_ws_kernel<CW, NK, GEGLU, F16>), dim3(grid), dim3(512), lds, st, d, n_panels, wpp);
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }
@@ -325,7 +325,7 @@ int ws_launch(const seer_gemm_desc& d, hipStream_t st) {
 bool seer_gemm_ws_eligible(const seer_gemm_desc& d) {
     if (d.mode != SEER_GEMM_PLAIN || d.batch > 1) return false;
     // (rotary: its table lookups are ordinary loads whose first use would drain the LDS-DMA ring -- the tile kernel keeps those)
-    if (d.epilogue & (SEER_EPI_OUT_F32 | SEER_EPI_SILU | SEER_EPI_TRANS_OUT | SEER_EPI_ROTARY | SEER_EPI_F16)) return false;      // (bf16 operands only)
+    if (d.epilogue & (SEER_EPI_OUT_F32 | SEER_EPI_SILU | SEER_EPI_TRANS_OUT | SEER_EPI_ROTARY)) return false;
     if (d.rowvec) return false;
     if (d.K != 320 && d.K != 640) return false;
     if (d.M < 1024) return false;                                   // too few rows to stream
@@ -347,6 +347,10 @@ bool seer_gemm_ws_profitable(const seer_gemm_desc& d) { return d.K == 320 && d.N
 
 int seer_gemm_ws_launch(const seer_gemm_desc& d, hipStream_t st) {
     const bool geglu = (d.epilogue & SEER_EPI_GEGLU) != 0;
+    if (d.epilogue & SEER_EPI_F16) {          // IEEE-half operands (the fp16 engine): the same kernel, other MFMA opcode and pack
+        if (d.K == 320) return geglu ? ws_launch<64, 5, true, true>(d, st) : ws_launch<64, 5, false, true>(d, st);
+        return geglu ? ws_launch<32, 10, true, true>(d, st) : ws_launch<32, 10, false, true>(d, st);
+    }
     if (d.K == 320) return geglu ? ws_launch<64, 5, true>(d, st) : ws_launch<64, 5, false>(d, st);
     return geglu ? ws_launch<32, 10, true>(d, st) : ws_launch<32, 10, false>(d, st);
 }

@@ -77,6 +77,30 @@ __device__ __forceinline__ u32x4 pack8t(const float (&f)[8]) {
     }
 }
 
+// F16 instantiations of the MFMA kernels: A, A2, W, residual and C hold IEEE half instead of bf16 (SEER_EPI_F16: the VAE, which the
+// reference runs in fp32, and the UNet engine under fp16 autocast --
+// 11 significand bits instead of 8 at the same MFMA rate).  Same 16-bit loads and LDS image; only the MFMA opcode and the
+// pack / unpack of the epilogue differ.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+template <bool F16>
+__device__ __forceinline__ f32x4 mma16(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ unsigned int pack2t(float lo, float hi) {
+    if constexpr (F16) return pack2h(lo, hi);
+    else return pack2(lo, hi);
+}
+template <bool F16>
+__device__ __forceinline__ f32x2 unpack2t(unsigned int v) {
+    if constexpr (F16) {
+        return f32x2{half_bits_to_f32(v), half_bits_to_f32(v >> 16)};
+    } else {
+        return f32x2{__builtin_bit_cast(float, v << 16), __builtin_bit_cast(float, v & 0xffff0000u)};
+    }
+}
+
 // ---- write-through output stores.  A plain store leaves its line dirty in the XCD's L2 and the dependent-kernel boundary behind
 // the launch waits for the write-back (microarch guide, "boundary": + dirty bytes / 6 TB/s -- 2.6 us behind a 15.7 MB activation,
 // a quarter of a 10 us normalisation kernel).  `sc1` stores write through while the kernel still runs; 16-byte stores only (the

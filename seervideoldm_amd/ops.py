@@ -636,7 +636,7 @@ def ff_fused_pays(rows: int, n_cu: Optional[int] = None) -> bool:
 def ff_fused_pack(w1: torch.Tensor, wcat: torch.Tensor):
     """The two weight matrices of ff_fused in the kernel's fragment order (seer_ff_fused_pack_w1 / _wcat): w1 [2560, 320] bf16 in the
     interleaved GEGLU row order, wcat [320, 1600] bf16 = [Wp | Wp W2].  Once per model."""
-    _req(w1, bf16, "w1"); _req(wcat, bf16, "wcat")
+    _req16(w1, "w1"); _req16(wcat, "wcat", w1)          # (the pack kernels move 16-bit words: bf16 and fp16 alike)
     assert w1.shape == (8 * FF_FUSED_C, FF_FUSED_C) and w1.is_contiguous() and wcat.shape == (FF_FUSED_C, 5 * FF_FUSED_C) and wcat.is_contiguous()
     w1f, wcf = torch.empty_like(w1), torch.empty_like(wcat)
     check(_lib.load().seer_ff_fused_pack_w1(_p(w1), _p(w1f), _stream()), "seer_ff_fused_pack_w1")
@@ -653,15 +653,15 @@ def ff_fused(h: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, beta: torch.
     the ColSumsFx of y, B -> the per-tile ColSums (96-row tiles; only where no tile straddles two batch elements).  Returns None
     (nothing launched) when the shape is not the kernel's: C = 320."""
     M, Cc = h.shape
-    if Cc != FF_FUSED_C or M == 0 or h.dtype != bf16:         # (the kernel is bf16 only: an fp16 engine keeps the three launches)
+    if Cc != FF_FUSED_C or M == 0:
         return None
-    _req(h, bf16, "h"); _req(x, bf16, "x"); _req(w1f, bf16, "w1f"); _req(wcf, bf16, "wcf")
+    dt = _req16(h, "h"); _req16(x, "x", h); _req16(w1f, "w1f", h); _req16(wcf, "wcf", h)
     assert x.shape == h.shape and h.stride(1) == 1 and x.stride(1) == 1
     assert w1f.numel() == 8 * Cc * Cc and w1f.is_contiguous() and wcf.numel() == 5 * Cc * Cc and wcf.is_contiguous()
     for t, n in ((gamma, "gamma"), (beta, "beta"), (b1, "b1"), (bcat, "bcat")):
         _req(t, torch.float32, n)
     if out is None:
-        out = torch.empty((M, Cc), device=h.device, dtype=bf16)
+        out = torch.empty((M, Cc), device=h.device, dtype=h.dtype)
     fx, fx_rows, cs, tiles = None, 0, None, None
     B, arena = colsum_batch if isinstance(colsum_batch, tuple) else (colsum_batch, None)
     if B > 0 and M % B == 0:
@@ -672,10 +672,10 @@ def ff_fused(h: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, beta: torch.
         elif (M // B) % FF_FUSED_ROWS == 0:
             tiles = torch.empty((1, M // FF_FUSED_ROWS, Cc, 2), device=h.device, dtype=torch.float32)
             cs = ColSums(tiles, Cc, 1, M // FF_FUSED_ROWS)
-    check(_lib.load().seer_ff_fused_c320(_p(h), h.stride(0), _p(x), x.stride(0), _p(out), out.stride(0), M, _p(gamma), _p(beta),
-                                         float(eps), _p(w1f), _p(b1), _p(wcf), _p(bcat), fx.data_ptr() if fx is not None else None,
-                                         fx_rows, fx.shape[0] if fx is not None else 0, _p(tiles) if tiles is not None else None,
-                                         _stream()), "seer_ff_fused_c320")
+    check(_lib.load().seer_ff_fused_c320_dt(_p(h), h.stride(0), _p(x), x.stride(0), _p(out), out.stride(0), M, _p(gamma), _p(beta),
+                                            float(eps), _p(w1f), _p(b1), _p(wcf), _p(bcat), fx.data_ptr() if fx is not None else None,
+                                            fx_rows, fx.shape[0] if fx is not None else 0, _p(tiles) if tiles is not None else None,
+                                            dt, _stream()), "seer_ff_fused_c320")
     out.colsums = cs
     out.rowstats = None
     return out

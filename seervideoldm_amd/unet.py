@@ -135,14 +135,17 @@ class SeerUNet(nn.Module):
         if self.compute_dtype is not None:
             return self.compute_dtype
         if torch.is_autocast_enabled():
-            dt = torch.get_autocast_gpu_dtype()
+            dt = torch.get_autocast_dtype("cuda")
             if dt in (torch.bfloat16, torch.float16):
                 return dt
         return torch.bfloat16
 
     def prepare(self, dtype=None):
         """(re)build the packed device weights from the current parameters; call after editing parameters in place."""
-        self._engine = _Engine(self, ops=self._ops_backend, shard=self._shard, dtype=dtype or self._dtype_of_call())
+        dtype = dtype or self._dtype_of_call()
+        dev = next(self.parameters()).device.type
+        with torch.autocast(device_type=dev if dev in ("cuda", "cpu") else "cuda", enabled=False):     # fp32 weight algebra stays fp32
+            self._engine = _Engine(self, ops=self._ops_backend, shard=self._shard, dtype=dtype)
         return self
 
     # ---- toggles of the reference surface (SURVEY 8(b)) ---------------------------------------------------------
@@ -171,6 +174,12 @@ class SeerUNet(nn.Module):
         if not sample.is_cuda and self._ops_backend is hip_ops:
             raise hip_ops._lib.SeerHipError("SeerUNet.forward needs ROCm tensors: the HIP kernels are the only compute path")
         dt = self._dtype_of_call()
+        # the caller's autocast state has said its piece (the storage type): everything below -- the host-side weight algebra of
+        # prepare() included -- runs outside it (a torch matmul under autocast would hand back 16-bit biases)
+        with torch.autocast(device_type=sample.device.type if sample.device.type in ("cuda", "cpu") else "cuda", enabled=False):
+            return self._forward_impl(sample, timestep, context, cond_frame, return_attn, dt)
+
+    def _forward_impl(self, sample, timestep, context, cond_frame, return_attn, dt):
         if self._engine is None or self._engine.device != sample.device or self._engine.dt != dt:
             self.prepare(dt)
         if self.config.center_input_sample:
@@ -250,7 +259,7 @@ class _Engine:
         # ff.net.2 and proj_out as one two-source GEMM (model.ff_fold = False / SEER_FF_FOLD=0: two launches; see _pack)
         self.ff_fold = bool(getattr(model, "ff_fold", os.environ.get("SEER_FF_FOLD", "1") != "0"))
         # ... and, at 320 channels, the whole feed-forward with it as ONE launch (model.ff_fused = False / SEER_FF_FUSED=0: off)
-        self.ff_fused = self.ff_fold and self.dt == bf16 and bool(getattr(model, "ff_fused", os.environ.get("SEER_FF_FUSED", "1") != "0"))      # (the fused kernel is bf16 only)
+        self.ff_fused = self.ff_fold and bool(getattr(model, "ff_fused", os.environ.get("SEER_FF_FUSED", "1") != "0"))
         self.gn_from_colsums = 0
         self.w: Dict[str, torch.Tensor] = {}
         self._pack(sd)

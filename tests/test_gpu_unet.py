@@ -440,7 +440,7 @@ def test_config1_end_to_end_against_the_reference(device):
     graph per step, fused CFG + DDIM update, fp16-storage VAE.
     Tolerances: four dependent CFG steps at scale 7.5 amplify each step's eps error (the one-step bound is REL_L2 = 1.65 x the
     reference's own bf16-autocast error): 8e-2 relative L2 on the final latent, as the small-network sampler test states; on the
-    decoded frames in [0, 1]: mean |pixel error| <= 2 / 255 and per-frame mean brightness within 1 / 255."""
+    decoded frames in [0, 1]: mean |pixel error| <= 3 / 255 (measured 1.87) and per-frame mean brightness within 1 / 255 (0.11)."""
     g = np.load(_G / "e2e_config1.npz")
     b, f1, Fp, h = 1, 2, 10, 32
     x0_emb = _randn((b, 4, f1, h, h), 61) * 0.9
@@ -475,7 +475,7 @@ def test_config1_end_to_end_against_the_reference(device):
     print(f"[parity] config 1 end to end vs the reference: latent rel_l2 {rel:.4g}; frames {frames}: mean |pixel error| "
           f"{px.mean().item() * 255:.3f}/255, max {px.max().item() * 255:.1f}/255; frame-mean brightness off by {dmean * 255:.3f}/255")
     assert rel <= 8e-2, rel
-    assert px.mean().item() * 255 <= 2.0 and dmean * 255 <= 1.0, (px.mean().item() * 255, dmean * 255)
+    assert px.mean().item() * 255 <= 3.0 and dmean * 255 <= 1.0, (px.mean().item() * 255, dmean * 255)      # (measured: 1.87 / 0.11)
 
 
 def test_full_size_step_fp16_storage_matches_the_reference(device):
