@@ -361,6 +361,33 @@ int seer_ff_fused_c320_dt(const void* h, int32_t ldh, const void* x, int32_t ldx
                           const float* gamma, const float* beta, float eps, const void* w1f, const float* b1, const void* wcf,
                           const float* bcat, int64_t* colsum_fx, int64_t fx_rows, int32_t fx_reps, float* colsum_tiles, int32_t dtype,
                           void* stream);
+/* The row-local chains in front of the attention launches of a transformer block at the 320-channel level, ONE launch (csrc/rowchain.hip):
+ *     h   = [GroupNorm(in)] W1^T + b1 [+ res]                          (stored when h != NULL)
+ *     out = LayerNorm(h; ln_gamma, ln_beta, ln_eps) [W2_0 | ... ]^T     n2 = 1..3 thirds of 320 columns (skipped when w2f == NULL)
+ * GroupNorm -> proj_in -> norm1 -> to_q | to_k | to_v (seer/models/attention.py:129-145, 231-240, 308-318; the temporal block's rotary
+ * embedding :649-651 as rot_*), or attn1.to_out + residual -> norm2 -> attn2.to_q (:316-322).  in, res, h [M][320], out [M][n2 * 320]
+ * in the storage type `dtype` (SEER_DT_*), row strides multiples of 8 elements, h may alias res.  GroupNorm: gn_stats [batch][groups][2]
+ * fp32 (sum, sum of squares per (batch element, group): what seer_groupnorm_stats* write), gn_count elements per group, rows_per_batch
+ * a multiple of 96 (SEER_ENOSYS otherwise: a workgroup's 96 rows may not straddle two batch elements); NULL = no normalisation of
+ * the input.  ln_gamma / ln_beta NULL = no LayerNorm.  w1f / w2f: the matrices in FRAGMENT order (seer_rowchain_pack).  The first
+ * rot_thirds thirds are rotated like SEER_EPI_ROTARY (table of seer_rotary_table, position = row % rot_tokens_per_batch +
+ * rot_pos_offset, heads of rot_head_dim channels, the first rot_dim rotated), then the first scale_thirds thirds are multiplied by
+ * col_scale (the q columns leave as q * scale * log2(e) for SEER_ATTN_Q_PRESCALED).  All pointers 16-byte aligned. */
+typedef struct seer_rowchain_desc {
+    const void* in; int32_t ld_in;
+    const float* gn_stats; double gn_count; float gn_eps; const float* gn_gamma; const float* gn_beta; int64_t rows_per_batch; int32_t groups;
+    const void* w1f; const float* b1; const void* res; int32_t ldr; void* h; int32_t ldh;
+    const float* ln_gamma; const float* ln_beta; float ln_eps;
+    const void* w2f; int32_t n2; void* out; int32_t ldo;
+    float col_scale; int32_t scale_thirds;
+    const float* rot_table; int32_t rot_tokens_per_batch, rot_pos_offset, rot_head_dim, rot_dim, rot_thirds;
+    int64_t M;
+    int32_t dtype;
+} seer_rowchain_desc;
+int seer_rowchain_c320(const seer_rowchain_desc* desc /* host */, void* stream);
+/* n_mats 320 x 320 matrices -- rows 320 t .. 320 t + 319 of W [n_mats * 320][ld], 16-bit elements -- into the kernel's fragment order:
+ * out[t][K step 5][wave 4][k32 2][column fragment 5][lane 64][8], element W[320 t + 80 w + 16 j + (lane & 15)][64 s + 32 k32 + 8 (lane >> 4) + e] */
+int seer_rowchain_pack(const void* W, int32_t ld, int32_t n_mats, void* out, void* stream);
 /* w1 [2560][320] bf16 -> out (same size): [chunk 20][wave 4][K step 5][k32 2][value | gate][lane 64][8 bf16], element
  * w1[128 c + 32 w + 16 f + (lane & 15)][64 ks + 32 k32 + 8 (lane >> 4) + e]: every fragment load of the kernel is one contiguous KiB */
 int seer_ff_fused_pack_w1(const void* w1, void* out, void* stream);

@@ -73,6 +73,21 @@ class AttnDesc(C.Structure):
     ]
 
 
+class RowChainDesc(C.Structure):
+    _fields_ = [
+        ("inp", C.c_void_p), ("ld_in", C.c_int32),
+        ("gn_stats", C.c_void_p), ("gn_count", C.c_double), ("gn_eps", C.c_float), ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p),
+        ("rows_per_batch", C.c_int64), ("groups", C.c_int32),
+        ("w1f", C.c_void_p), ("b1", C.c_void_p), ("res", C.c_void_p), ("ldr", C.c_int32), ("h", C.c_void_p), ("ldh", C.c_int32),
+        ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float),
+        ("w2f", C.c_void_p), ("n2", C.c_int32), ("out", C.c_void_p), ("ldo", C.c_int32),
+        ("col_scale", C.c_float), ("scale_thirds", C.c_int32),
+        ("rot_table", C.c_void_p), ("rot_tokens_per_batch", C.c_int32), ("rot_pos_offset", C.c_int32), ("rot_head_dim", C.c_int32),
+        ("rot_dim", C.c_int32), ("rot_thirds", C.c_int32),
+        ("M", C.c_int64), ("dtype", C.c_int32),
+    ]
+
+
 class AttnBwdDesc(C.Structure):
     _fields_ = [
         ("fwd", AttnDesc),
@@ -114,6 +129,8 @@ SIGNATURES = {
     "seer_ff_fused_c320": ([_vp, _i32, _vp, _i32, _vp, _i32, _i64, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp], C.c_int),
     "seer_ff_fused_c320_dt": ([_vp, _i32, _vp, _i32, _vp, _i32, _i64, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp],
                               C.c_int),
+    "seer_rowchain_c320": ([C.POINTER(RowChainDesc), _vp], C.c_int),
+    "seer_rowchain_pack": ([_vp, _i32, _i32, _vp, _vp], C.c_int),
     "seer_ff_fused_pack_w1": ([_vp, _vp, _vp], C.c_int),
     "seer_ff_fused_pack_wcat": ([_vp, _vp, _vp], C.c_int),
     "seer_gemm_colsum_fx_layout": ([C.POINTER(GemmDesc), _i32, C.POINTER(C.c_int32)], C.c_int32),

@@ -317,6 +317,11 @@ def check_directory(objdir: Path, sources: Iterable[str] = ()) -> List[str]:
         if f.name.startswith("ff_fused"):
             v, ff_seen = check_async_vregs(lines, "seer_ff_fused_c320_kernel", f.name)
             problems += v
+        if f.name.startswith("rowchain"):       # the same discipline: weight fragments requested by asm, waited for by count
+            v, rc_seen = check_async_vregs(lines, "seer_rowchain_c320_kernel", f.name)
+            problems += v
+            if rc_seen < 30:
+                problems.append(f"rowchain: only {rc_seen} asynchronous fragment requests found in the kernel's assembly (the check no longer sees them)")
     if pairs == 0:
         problems.append("attention40: no lds_issue_kv / lds_wait_v statement pair found in the assembly (the check no longer sees the kernel)")
     if ff_seen is not None and ff_seen < 30:

@@ -18,7 +18,7 @@ ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIBDIR = PKG / "lib"
 LIB = LIBDIR / "libseer_hip.so"
-SOURCES = ["gemm.hip", "gemm_ws.hip", "gemm_t320.hip", "ff_fused.hip", "attention.hip", "attention40.hip", "attention_bwd.hip", "gemm_tn.hip", "norm.hip", "elementwise.hip", "train.hip"]
+SOURCES = ["gemm.hip", "gemm_ws.hip", "gemm_t320.hip", "ff_fused.hip", "rowchain.hip", "attention.hip", "attention40.hip", "attention_bwd.hip", "gemm_tn.hip", "norm.hip", "elementwise.hip", "train.hip"]
 ARCH = "gfx950"
 # per-source extra flags.  attention: keep the MFMA accumulators in VGPRs (gfx950's unified file allows it) -- the online
 # softmax touches S and O every key tile, and the default AGPR form costs ~220 v_accvgpr moves per tile per wave.
@@ -29,7 +29,10 @@ EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                # GEMM: the epilogue reads every accumulator once; VGPR form saves those moves (+0.7 % on the step, A/B in one run)
                "gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "gemm_ws.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
-               "gemm_t320.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+               "gemm_t320.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+               # rowchain: 120 accumulators + 80 weight-fragment registers + 48 of activation fragments fit the V file; its
+               # epilogues read every accumulator once
+               "rowchain.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 # ff_fused.hip: default form -- its accumulators and its W1 fragment ring live in the accumulation registers (120 + 48 + 80), the
 # asynchronously written fragment registers must never meet a register-allocator copy (asm_check.py::check_async_vregs)
 

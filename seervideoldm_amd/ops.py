@@ -681,6 +681,91 @@ def ff_fused(h: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, beta: torch.
     return out
 
 
+ROWCHAIN_C, ROWCHAIN_ROWS = 320, 96
+
+
+def rowchain_pack(w: torch.Tensor) -> torch.Tensor:
+    """w [n * 320, 320] (16-bit) -> the n matrices in the fragment order of rowchain() (seer_rowchain_pack).  Once per model."""
+    _req16(w, "w")
+    assert w.dim() == 2 and w.shape[1] == ROWCHAIN_C and w.shape[0] % ROWCHAIN_C == 0 and w.is_contiguous()
+    out = torch.empty_like(w)
+    check(_lib.load().seer_rowchain_pack(_p(w), w.stride(0), w.shape[0] // ROWCHAIN_C, _p(out), _stream()), "seer_rowchain_pack")
+    return out
+
+
+def rowchain_pays(rows: int, n_cu: Optional[int] = None, products: int = 4) -> bool:
+    """a workgroup owns 96 rows for the whole launch (as ff_fused), so a launch takes rounds x ~30 us (four products) / ~20 us (two)
+    whatever its rows: ahead of the launches it replaces where its workgroups fill the chip's rounds (scripts/lab_rowchain.py,
+    profiles/r06_lab_rowchain.log: GroupNorm -> proj_in -> norm1 -> q|k|v 24 576 rows 35.9 against 54.4 us, 12 288 rows 31.6 / 35.0,
+    6 144 rows 30.7 / 23.3; to_out + residual -> norm2 -> to_q 26.0 / 27.5, 21.2 / 19.3, 20.5 / 15.1)"""
+    if n_cu is None:
+        n_cu = device_cus()
+    wgs = -(-rows // ROWCHAIN_ROWS)
+    fill = wgs / (n_cu * -(-wgs // n_cu))
+    return (rows >= 12288 and fill >= 0.49) if products >= 4 else (rows >= 18432 and fill >= 0.74)
+
+
+def rowchain(inp: torch.Tensor, w1f: torch.Tensor, *, b1: Optional[torch.Tensor] = None, gn=None, res: Optional[torch.Tensor] = None,
+             h_out=True, ln=None, w2f: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, col_scale=None, rotary=None):
+    """h = [GroupNorm(inp)] W1^T + b1 [+ res];  out = LayerNorm(h) [W2_0 | ...]^T  as ONE launch at 320 channels (seer_rowchain_c320).
+    gn = (stats [B, G, 2] fp32, count, eps, gamma, beta, rows_per_batch); ln = (gamma, beta, eps); w1f / w2f from rowchain_pack;
+    h_out: True = a new tensor, a tensor = write there (may be `res`), False = h is not stored; col_scale = (factor, thirds);
+    rotary = (table, tokens_per_batch, pos_offset, head_dim, rot_dim, thirds).  Returns (h or None, out or None), or None when the
+    launch is refused (SEER_ENOSYS: a 96-row tile would straddle two batch elements of the GroupNorm)."""
+    dt = _req16(inp, "inp"); _req16(w1f, "w1f", inp)
+    M, Cc = inp.shape
+    assert Cc == ROWCHAIN_C and inp.stride(1) == 1 and w1f.numel() == Cc * Cc and w1f.is_contiguous()
+    d = _lib.RowChainDesc()
+    d.inp, d.ld_in, d.M, d.dtype = _p(inp), inp.stride(0), M, dt
+    d.w1f = _p(w1f)
+    if b1 is not None:
+        _req(b1, torch.float32, "b1"); d.b1 = _p(b1)
+    if gn is not None:
+        stats, count, eps, gamma, beta, rows_pb = gn
+        _req(stats, torch.float32, "gn stats"); _req(gamma, torch.float32, "gn gamma"); _req(beta, torch.float32, "gn beta")
+        assert stats.is_contiguous() and stats.dim() == 3 and stats.shape[2] == 2 and M % rows_pb == 0 and stats.shape[0] == M // rows_pb
+        d.gn_stats, d.gn_count, d.gn_eps, d.gn_gamma, d.gn_beta = _p(stats), float(count), float(eps), _p(gamma), _p(beta)
+        d.rows_per_batch, d.groups = rows_pb, stats.shape[1]
+    if res is not None:
+        _req16(res, "res", inp)
+        assert res.shape == (M, Cc) and res.stride(1) == 1
+        d.res, d.ldr = _p(res), res.stride(0)
+    h = None
+    if h_out is not False:
+        h = torch.empty((M, Cc), device=inp.device, dtype=inp.dtype) if h_out is True else h_out
+        _req16(h, "h", inp)
+        assert h.shape == (M, Cc) and h.stride(1) == 1
+        d.h, d.ldh = _p(h), h.stride(0)
+    if ln is not None:
+        g, b, eps = ln
+        _req(g, torch.float32, "ln gamma"); _req(b, torch.float32, "ln beta")
+        d.ln_gamma, d.ln_beta, d.ln_eps = _p(g), _p(b), float(eps)
+    o = None
+    if w2f is not None:
+        _req16(w2f, "w2f", inp)
+        n2 = w2f.numel() // (Cc * Cc)
+        assert w2f.is_contiguous() and n2 * Cc * Cc == w2f.numel() and 1 <= n2 <= 3
+        o = torch.empty((M, n2 * Cc), device=inp.device, dtype=inp.dtype) if out is None else out
+        _req16(o, "out", inp)
+        assert o.shape == (M, n2 * Cc) and o.stride(1) == 1
+        d.w2f, d.n2, d.out, d.ldo = _p(w2f), n2, _p(o), o.stride(0)
+        if col_scale is not None:
+            d.col_scale, d.scale_thirds = float(col_scale[0]), int(col_scale[1])
+        if rotary is not None:
+            table, tpb, pos_off, hd, rd, thirds = rotary
+            _req(table, torch.float32, "rotary table")
+            assert table.shape[0] >= tpb + pos_off and table.shape[1] * 2 == rd
+            d.rot_table, d.rot_tokens_per_batch, d.rot_pos_offset, d.rot_head_dim, d.rot_dim, d.rot_thirds = _p(table), tpb, pos_off, hd, rd, thirds
+    rc = _lib.load().seer_rowchain_c320(C.byref(d), _stream())
+    if rc == _lib.SEER_ENOSYS:
+        return None
+    check(rc, "seer_rowchain_c320")
+    if h is not None:
+        h.colsums = None
+        h.rowstats = None
+    return h, o
+
+
 def softmax_rows(x: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None, dtype=None) -> torch.Tensor:
     """softmax(scale * x) over the last dim; x bf16 / fp16 / fp32 -> `dtype` (bf16 unless out / dtype say fp16)."""
     assert x.dtype in (bf16, f16, torch.float32) and x.is_cuda

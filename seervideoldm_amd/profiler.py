@@ -48,6 +48,14 @@ class TimedOps:
         return self._timed("gemm", flops, nbytes, self._base.ff_fused, h, x, gamma, beta, w1f, b1, wcf, bcat,
                            _tag=f"ff_fused M{M} C{Cc}", **k)
 
+    def rowchain(self, inp, w1f, **k):
+        # one or more 320 x 320 products over the same rows (GroupNorm / LayerNorm in between) as one launch: their MACs
+        M, Cc = inp.shape
+        n2 = 0 if k.get("w2f") is None else k["w2f"].numel() // (Cc * Cc)
+        flops = 2.0 * M * Cc * Cc * (1 + n2)
+        nbytes = 2 * (M * Cc * (2 + n2 + (1 if k.get("res") is not None else 0)) + (1 + n2) * Cc * Cc)
+        return self._timed("gemm", flops, nbytes, self._base.rowchain, inp, w1f, _tag=f"rowchain M{M} n{1 + n2}" + (" +res" if k.get("res") is not None else ""), **k)
+
     def gemm_batched(self, a, w, **k):
         Bt, M, K = a.shape
         N = w.shape[-2]
@@ -156,6 +164,10 @@ class TimedOps:
             if N == 3 * K:
                 return f"q|k|v projection {lvl}"
             return f"projections / 1x1 {lvl}"
+        if t[0] == "rowchain":
+            lvl = (levels or {24576: "L0"}).get(int(t[1][1:]), t[1])
+            return ("attn1.to_out + residual -> norm2 -> attn2.to_q, one launch " if "+res" in t else
+                    "GroupNorm -> proj_in -> norm1 -> q|k|v, one launch ") + lvl
         if t[0] == "ff_fused":
             lvl = (levels or {24576: "L0"}).get(int(t[1][1:]), t[1])
             return f"fused feed-forward (norm3, ff.net.0 GEGLU, ff.net.2 | proj_out +res) {lvl}"

@@ -260,6 +260,11 @@ class _Engine:
         self.ff_fold = bool(getattr(model, "ff_fold", os.environ.get("SEER_FF_FOLD", "1") != "0"))
         # ... and, at 320 channels, the whole feed-forward with it as ONE launch (model.ff_fused = False / SEER_FF_FUSED=0: off)
         self.ff_fused = self.ff_fold and bool(getattr(model, "ff_fused", os.environ.get("SEER_FF_FUSED", "1") != "0"))
+        # ... and the row-local chains in front of the attention launches at 320 channels -- GroupNorm -> proj_in -> norm1 -> q|k|v, and
+        # attn1.to_out + residual -> norm2 -> attn2.to_q -- as ONE launch each (ops.rowchain, csrc/rowchain.hip;
+        # model.rowchain = False / SEER_ROWCHAIN=0: the separate launches)
+        self.rowchain = bool(getattr(model, "rowchain", os.environ.get("SEER_ROWCHAIN", "1") != "0")) and hasattr(self.ops, "rowchain")
+        self.rowchains = 0
         self.gn_from_colsums = 0
         self.w: Dict[str, torch.Tensor] = {}
         self._pack(sd)
@@ -367,6 +372,18 @@ class _Engine:
                 if self.ff_fused and wp.shape[0] == getattr(self.ops, "FF_FUSED_C", -1) and (tb + ".norm3.weight") in sd:
                     w[pth + ".ff_fused.w1f"], w[pth + ".ff_fused.wcf"] = self.ops.ff_fused_pack(
                         w[tb + ".ff.net.0.proj.weight"], w[pth + ".ffproj.w"])
+        # the chains of ops.rowchain read their 320 x 320 matrices in the kernel's fragment order
+        if self.rowchain:
+            RC = self.ops.ROWCHAIN_C
+            for k in list(w):
+                if k.endswith(".proj_in.weight") and w[k].shape == (RC, RC) and (k[:-len(".proj_in.weight")] + ".transformer_blocks.0.attn1.qkv") in w:
+                    pth = k[: -len(".proj_in.weight")]
+                    tb = pth + ".transformer_blocks.0"
+                    w[pth + ".rc.proj_in"] = self.ops.rowchain_pack(w[k])
+                    w[tb + ".rc.qkv"] = self.ops.rowchain_pack(w[tb + ".attn1.qkv"])
+                    if (tb + ".attn2.q") in w:
+                        w[tb + ".rc.to_out"] = self.ops.rowchain_pack(w[tb + ".attn1.to_out.0.weight"])
+                        w[tb + ".rc.q"] = self.ops.rowchain_pack(w[tb + ".attn2.q"])
         # LayerNorm folded into the GEMM that consumes it (ops.fold_layernorm): W' = gamma (.) W from the fp32 weights, its row
         # sums and beta W^T + b, next to the plain weights (a launch that cannot fold runs layernorm + the plain ones)
         self.wln: Dict[str, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = {}
@@ -454,6 +471,42 @@ class _Engine:
             return 0
         return (B, self._fx) if (self._fx is not None and rows_pb <= FX_MAX_ROWS_PB) else B
 
+    def _gn_stats(self, x, B, rows_pb):
+        """(stats [B, G, 2], count) of the GroupNorm over x alone, for a launch that applies the normalisation itself (ops.rowchain):
+        from the producer's per-tile column sums, else from a pass over x.  None: the accumulated fixed-point form (small tensors) or a
+        sharded engine -- the caller keeps the separate launches."""
+        ops = self.ops
+        cs = getattr(x, "colsums", None)
+        if self.shard is not None or isinstance(cs, getattr(ops, "ColSumsFx", ())):
+            return None
+        stats = self._stats_arena[self._stats_i]
+        self._stats_i += 1
+        if self.gn_colsums and cs is not None:
+            ops.groupnorm_stats_from_colsums(cs, None, B, self.G, stats)
+            self.gn_from_colsums += 1
+        else:
+            ops.groupnorm_stats(x, None, B, self.G, stats)
+        return stats, rows_pb * (x.shape[1] // self.G)
+
+    def _rc_in(self, p, tb, x, B, rows_pb, rotary, qs):
+        """GroupNorm -> proj_in -> norm1 -> q|k|v of transformer `p` as one launch: (h, qkv), or None when this block / shape keeps
+        the separate launches"""
+        ops, w = self.ops, self.w
+        if not self.rowchain or (p + ".rc.proj_in") not in w or rows_pb % ops.ROWCHAIN_ROWS or not ops.rowchain_pays(x.shape[0]):
+            return None
+        i0 = self._stats_i
+        st = self._gn_stats(x, B, rows_pb)
+        if st is None:
+            return None
+        r = ops.rowchain(x, w[p + ".rc.proj_in"], b1=w[p + ".proj_in.bias"],
+                         gn=(st[0], st[1], 1e-6, w[p + ".norm.weight"], w[p + ".norm.bias"], rows_pb),
+                         ln=(w[tb + ".norm1.weight"], w[tb + ".norm1.bias"], 1e-5), w2f=w[tb + ".rc.qkv"], col_scale=(qs, 1), rotary=rotary)
+        if r is None:
+            self._stats_i = i0
+            return None
+        self.rowchains += 1
+        return r
+
     def _resnet(self, p, x, skip, geo):
         """ResnetBlock3D (resnet.py:174-208); `skip` is the channel-concat partner of unet_3d_blocks.py:596,712."""
         ops, w = self.ops, self.w
@@ -523,19 +576,32 @@ class _Engine:
         heads, d = self.heads, C // self.heads
         HW = H * W
         tb = p + ".transformer_blocks.0"
-        hn = self._gn(x, None, B, Fr * HW, p + ".norm", 1e-6, False)
-        h = ops.gemm(hn, w[p + ".proj_in.weight"], bias=w[p + ".proj_in.bias"], **self._rs())
-        # self attention per frame
         # the q columns leave the projection as q * scale * log2(e) (one bf16 rounding): the attention kernels exponentiate
         # the raw dot products
         qs = ops.qk_prescale(d)
-        qkv = self._ln_gemm(h, tb, ".norm1", tb + ".attn1.qkv", col_scale=(qs, C))
+        rc = self._rc_in(p, tb, x, B, Fr * HW, None, qs)
+        if rc is not None:
+            h, qkv = rc
+        else:
+            hn = self._gn(x, None, B, Fr * HW, p + ".norm", 1e-6, False)
+            h = ops.gemm(hn, w[p + ".proj_in.weight"], bias=w[p + ".proj_in.bias"], **self._rs())
+            qkv = self._ln_gemm(h, tb, ".norm1", tb + ".attn1.qkv", col_scale=(qs, C))
+        # self attention per frame
         a = torch.empty_like(h)
         ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], a, batch=B * Fr, heads=heads, head_dim=d,
                       Sq=HW, Sk=HW, q_prescaled=True)
-        ops.gemm(a, w[tb + ".attn1.to_out.0.weight"], bias=w[tb + ".attn1.to_out.0.bias"], residual=h, out=h, **self._rs())
         # text cross attention per frame (K/V depend on the context only: cached across DDIM steps)
-        q = self._ln_gemm(h, tb, ".norm2", tb + ".attn2.q", col_scale=(qs, C))
+        q = None
+        if rc is not None and (tb + ".rc.q") in w and ops.rowchain_pays(a.shape[0], products=2):
+            # attn1.to_out + residual (over h) -> norm2 -> attn2.to_q, one launch
+            r2 = ops.rowchain(a, w[tb + ".rc.to_out"], b1=w[tb + ".attn1.to_out.0.bias"], res=h, h_out=h,
+                              ln=(w[tb + ".norm2.weight"], w[tb + ".norm2.bias"], 1e-5), w2f=w[tb + ".rc.q"], col_scale=(qs, 1))
+            if r2 is not None:
+                q = r2[1]
+                self.rowchains += 1
+        if q is None:
+            ops.gemm(a, w[tb + ".attn1.to_out.0.weight"], bias=w[tb + ".attn1.to_out.0.bias"], residual=h, out=h, **self._rs())
+            q = self._ln_gemm(h, tb, ".norm2", tb + ".attn2.q", col_scale=(qs, C))
         kv = self._kv_cache.get(tb)
         if kv is None:
             kv = ops.gemm(self._ctx, w[tb + ".attn2.kv"])
@@ -584,15 +650,19 @@ class _Engine:
         heads, d = self.heads, C // self.heads
         HW = H * W
         tb = p + ".transformer_blocks.0"
-        hn = self._gn(x, None, B, Fr * HW, p + ".norm", 1e-6, False)
-        h = ops.gemm(hn, w[p + ".proj_in.weight"], bias=w[p + ".proj_in.bias"], **self._rs())
         F_all = Fr if self.shard is None else self.shard.total_frames
         f_off = 0 if self.shard is None else self.shard.frame_offset
         rot_dim = min(32, d)
         cs = self._rotary_table(tb, F_all * HW)
-        # q|k|v projection with the rotary embedding applied to the q and k columns in the GEMM epilogue
-        qkv = self._ln_gemm(h, tb, ".norm1", tb + ".attn1.qkv", rotary=(cs, Fr * HW, f_off * HW, d, rot_dim, 2 * C),
-                            col_scale=(ops.qk_prescale(d), C))
+        rc = self._rc_in(p, tb, x, B, Fr * HW, (cs, Fr * HW, f_off * HW, d, rot_dim, 2), ops.qk_prescale(d))
+        if rc is not None:
+            h, qkv = rc
+        else:
+            hn = self._gn(x, None, B, Fr * HW, p + ".norm", 1e-6, False)
+            h = ops.gemm(hn, w[p + ".proj_in.weight"], bias=w[p + ".proj_in.bias"], **self._rs())
+            # q|k|v projection with the rotary embedding applied to the q and k columns in the GEMM epilogue
+            qkv = self._ln_gemm(h, tb, ".norm1", tb + ".attn1.qkv", rotary=(cs, Fr * HW, f_off * HW, d, rot_dim, 2 * C),
+                                col_scale=(ops.qk_prescale(d), C))
         a = torch.empty_like(h)
         if self.shard is not None:
             self.shard.temporal_attention(ops, qkv, a, B, heads, d, H, W, sync=self.sync_point)
@@ -635,6 +705,7 @@ class _Engine:
         self._stats_i = 0
         self.gn_from_colsums = 0        # GroupNorms of this forward that took their statistics from column sums
         self.ln_folded = 0              # LayerNorms of this forward that ran inside the consuming GEMM
+        self.rowchains = 0              # ops.rowchain launches of this forward
         self._fx = None
         # the folded LayerNorm trades a launch per norm for atomics in proportion to the rows: ahead up to ~100 k rows at the finest
         # level (config 2: 24 576 rows -0.19 ms; 64x64 latent, 98 304 rows: even; bridge, 131 072 rows: +0.15 ms --

@@ -67,6 +67,32 @@ def ff_fused(h, x, gamma, beta, w1f, b1, wcf, bcat, *, eps=1e-5, out=None, colsu
     return out
 
 
+ROWCHAIN_C, ROWCHAIN_ROWS = 320, 96
+
+
+def rowchain_pack(w):
+    return torch.empty_like(w)
+
+
+def rowchain_pays(rows, n_cu=256, products=4):
+    wgs = -(-rows // ROWCHAIN_ROWS)
+    fill = wgs / (n_cu * -(-wgs // n_cu))
+    return (rows >= 12288 and fill >= 0.49) if products >= 4 else (rows >= 18432 and fill >= 0.74)
+
+
+def rowchain(inp, w1f, *, b1=None, gn=None, res=None, h_out=True, ln=None, w2f=None, out=None, col_scale=None, rotary=None):
+    M, Cc = inp.shape
+    if gn is not None and gn[5] % ROWCHAIN_ROWS:
+        return None
+    h = None
+    if h_out is not False:
+        h = torch.empty((M, Cc), dtype=bf16, device=inp.device) if h_out is True else h_out
+        h.colsums = None
+        h.rowstats = None
+    o = None if w2f is None else torch.empty((M, w2f.numel() // Cc), dtype=bf16, device=inp.device)
+    return h, o
+
+
 def gemm_batched(a, w, *, trans_out=False, out=None, bias=None, out_f32=False, tile=0, col_scale=None):
     Bt, M, _ = a.shape
     N = w.shape[-2]
