@@ -35,7 +35,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0                     # same guide: HBM3E 8 TB/s (spec)
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16
-PMC_TRAFFIC_FILE = "r05_pmc_traffic.json"
+PMC_TRAFFIC_FILE = "r06_pmc_traffic.json"
 WORKLOAD = dict(b=1, cond_frames=2, frames=12, latent=32, ddim_steps=50, scale=7.5)
 # BASELINE.json configs: [1] is the bench line (default); the others are parity-test cases that can be timed on request
 WORKLOADS = {
@@ -434,8 +434,8 @@ def main():
                 raise ValueError(f"{PMC_TRAFFIC_FILE} was taken on library build {str(pmc.get('build_sha256'))[:12]}, this is "
                                  f"{built[:12]}")
             # like for like with `achieved` / `algorithmic_bytes_per_launch`: the launch-weighted mean over EVERY kernel family of the
-            # class (the tile kernels, the 256 x 320 tile, the weight-stationary pair, the fused feed-forward), not the tile kernels alone
-            fams = {k: v for k, v in pmc["kernels"].items() if k.startswith(("seer_gemm", "seer_ff_fused", "seer_conv_ws"))}
+            # class (the tile kernels, the 256 x 320 tile, the weight-stationary pair, the fused feed-forward, the row chains), not the tile kernels alone
+            fams = {k: v for k, v in pmc["kernels"].items() if k.startswith(("seer_gemm", "seer_ff_fused", "seer_rowchain"))}
             traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in fams.values()) / sum(v["launches"] for v in fams.values()))
             traffic_families = sorted(fams)
             ff_traffic = pmc["kernels"].get("seer_ff_fused_c320_kernel", {}).get("hbm_bytes_per_launch")
@@ -450,7 +450,8 @@ def main():
             if tag.startswith("attn b24 Sq1024 Sk1024 d40"):
                 attn_block["in_step_us"] = round(ms / calls * 1e3, 2)
         roofline = dict(bound="mfma", kernel="seer_gemm_kernel (bf16 MFMA GEMM / implicit-GEMM conv3x3, all tiles; the class also holds the "
-                                             "ten seer_ff_fused_c320_kernel launches, accounted with the MACs of the two GEMMs each contains)",
+                                             "ten seer_ff_fused_c320_kernel and the fifteen seer_rowchain_c320_kernel launches, accounted "
+                                             "with the MACs of the GEMMs each contains)",
                         achieved=round(gm["tflops"], 2), peak=MFMA_BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=round(gm["tflops"] / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), traffic=traffic,
                         traffic_unit="bytes beyond L2 per launch (2*FETCH_SIZE + WRITE_SIZE, PMC), launch-weighted over the class's kernel families",

@@ -19,7 +19,7 @@ def per_kernel(path, counter):
         if r["Counter_Name"] != counter:
             continue
         name = r["Kernel_Name"]
-        fam = "seer_ff_fused_c320_kernel" if "seer_ff_fused_c320_kernel" in name else "seer_gemm_ws_kernel" if "seer_gemm_ws_kernel" in name else "seer_gemm_t320_kernel" if "seer_gemm_t320_kernel" in name else "seer_gemm_kernel" if "seer_gemm_kernel" in name else (
+        fam = "seer_rowchain_c320_kernel" if "seer_rowchain_c320_kernel" in name else "seer_ff_fused_c320_kernel" if "seer_ff_fused_c320_kernel" in name else "seer_gemm_ws_kernel" if "seer_gemm_ws_kernel" in name else "seer_gemm_t320_kernel" if "seer_gemm_t320_kernel" in name else "seer_gemm_kernel" if "seer_gemm_kernel" in name else (
             "seer_attn40_kernel" if "seer_attn40_kernel" in name else ("seer_attn_kernel" if "seer_attn_kernel" in name else None))
         if fam is None:
             for k in ("gn_stats", "gn_apply", "gn_finalize", "layernorm", "splitk_reduce"):

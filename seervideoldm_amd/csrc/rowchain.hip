@@ -80,7 +80,9 @@ __device__ __forceinline__ void a_got(AFrag& f) {
 }
 __device__ __forceinline__ bf16x8 as_bf(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
 
-template <bool F16>
+// FULL: M is a multiple of 96 and h is stored -- every store of every tile is issued by every wave, so the head of a product can wait for its fragments by
+// COUNT (the 15 row stores of the epilogue in between are younger and stay in flight) instead of draining the queue
+template <bool F16, bool FULL>
 __global__ void __launch_bounds__(256, 1) seer_rowchain_c320_kernel(const RcArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const T = smem;
@@ -111,7 +113,7 @@ __global__ void __launch_bounds__(256, 1) seer_rowchain_c320_kernel(const RcArgs
         for (int i = 0; i < 15; ++i) {
             const int q = wave * 15 + i, pnl = q / 12, rg = q - pnl * 12;
             const u32x4 v = *reinterpret_cast<const u32x4*>(src + pnl * RC_PANEL + rg * 1024 + lane * 16);
-            if (m0 + rg * 8 + drow < p.M) store16_out(dst + (int64_t)(m0 + rg * 8 + drow) * ld + pnl * 64 + dchunk, v);
+            if (FULL || m0 + rg * 8 + drow < p.M) store16_out(dst + (int64_t)(m0 + rg * 8 + drow) * ld + pnl * 64 + dchunk, v);
         }
     };
 
@@ -141,8 +143,12 @@ __global__ void __launch_bounds__(256, 1) seer_rowchain_c320_kernel(const RcArgs
         AFrag a0, a1;
         a_req(a0, T0 + fo0);
         a_got(a0);
-        got10<0>(wa);
-        got10<0>(wb);
+        // S1 was requested before S0 (see the tail of this loop), the epilogue's 15 row stores behind both
+        // (ONE pair of wait statements on every path -- two pairs under a branch would make the fragment registers a merge of two
+        // definitions, and the copy at the join would read registers still in flight -- in front of it, where nothing can be counted, a drain)
+        if (!FULL) wait_vm<0>();            // (FULL: 15 row stores behind the requests -- or, at the first product, nothing at all: phase 0 drained the queue)
+        got10<15>(wb);
+        got10<15>(wa);
         // S0 (wa)
         a_req(a1, T0 + fo1);                             mfma_y(&wa.r[0], a0); a_got(a1);
         a_req(a0, T0 + RC_PANEL + fo0);                  mfma_y(&wa.r[5], a1); a_got(a0);
@@ -229,7 +235,7 @@ __global__ void __launch_bounds__(256, 1) seer_rowchain_c320_kernel(const RcArgs
 #pragma unroll 1
     for (int g = 0; g <= p.n2; ++g) {
         const unsigned char* wnext = g < p.n2 ? w2_wave + (int64_t)g * RC_MAT_BYTES : wcur;
-        gemm320(wcur, wnext);
+        gemm320(wcur, wnext);               // (FULL: every epilogue stores its 15 pieces -- h included, the host sees to that)
         wcur = wnext;
         if (g == 0) {
             // ================= h = T W1^T + b1 (+ res), through T; stored =================
@@ -256,11 +262,51 @@ __global__ void __launch_bounds__(256, 1) seer_rowchain_c320_kernel(const RcArgs
                 }
                 __builtin_amdgcn_sched_barrier(0);          // one column fragment at a time: the scheduler would hoist all 30 loads
             }
-            barrier_lds();                  // h complete in T
-            if (p.h) store_tile(T, p.h, p.ldh);
-            if (p.n2 > 0 && p.ln_gamma) {
+        } else {
+            // ================= out third t = T W2_t^T, rotary / column scale, through U; stored =================
+            const int t = g - 1;
+            if (t > 0) barrier_lds();       // every wave has read its pieces of the previous third out of U (the residual's last reader sits two barriers back)
+            const bool rot = t < p.rot_thirds;
+            const float sc = t < p.scale_thirds ? p.col_scale : 1.f;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int n = 80 * wave + 16 * j + 4 * fq;
+                const int pnl = n >> 6, ch = (n & 63) >> 3;
+                const int hc = n % p.rot_head_dim;                               // channel inside its head (heads are whole quads)
+                const bool rq = rot && hc < p.rot_dim;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const int row = 16 * i + frow;
+                    f32x4 v = Y[i][j];
+                    if (rq) {
+                        const int pos = (m0 + row) % p.rot_tokens_per_batch + p.rot_pos_offset;
+                        const f32x4 cs = *reinterpret_cast<const f32x4*>(p.rot_table + ((int64_t)pos * (p.rot_dim / 2) + hc / 2) * 2);
+                        const f32x2 r01 = rot_pair(f32x2{v[0], v[1]}, cs[0], cs[1]);
+                        const f32x2 r23 = rot_pair(f32x2{v[2], v[3]}, cs[2], cs[3]);
+                        v = f32x4{r01[0], r01[1], r23[0], r23[1]};
+                    }
+                    u32x2 o;
+                    o[0] = pack2t<F16>(v[0] * sc, v[1] * sc);
+                    o[1] = pack2t<F16>(v[2] * sc, v[3] * sc);
+                    *reinterpret_cast<u32x2*>(U + pnl * RC_PANEL + row * 128 + ((ch ^ (row & 7)) * 16) + (n & 7) * 2) = o;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- the staged tile leaves as whole rows.  ONE store site behind the branch: in a FULL launch its 15 pieces are issued on
+        // every path around the loop, which is what the counted wait at the head of the next product stands on (and what
+        // asm_check.py can see: the structurised branch above has paths through neither epilogue in its flow graph)
+        barrier_lds();                      // the tile (h in T / the third in U) complete
+        {
+            const unsigned char* ssrc = g == 0 ? T : U;
+            bf16* sdst = g == 0 ? p.h : p.out + (g - 1) * RC_C;
+            const int sld = g == 0 ? p.ldh : p.ldo;
+            if (FULL || sdst) store_tile(ssrc, sdst, sld);
+        }
+        if (g == 0 && p.n2 > 0) {
+            if (p.ln_gamma) {
                 // ================= LayerNorm of h in place (two-pass statistics in registers, as seer_layernorm) =================
-                if (p.h) barrier_lds();     // the store read pieces of (panel, row group); the normalisation owns whole rows
+                barrier_lds();              // the store read pieces of (panel, row group); the normalisation owns whole rows
                 for (int pass = 0; pass < 3; ++pass) {
                     const int row = wave * 24 + pass * 8 + (lane >> 3);
                     float v[5][8];
@@ -296,38 +342,6 @@ __global__ void __launch_bounds__(256, 1) seer_rowchain_c320_kernel(const RcArgs
                 }
             }
             barrier_lds();                  // T = LN(h)
-        } else {
-            // ================= out third t = T W2_t^T, rotary / column scale, through U; stored =================
-            const int t = g - 1;
-            if (t > 0) barrier_lds();       // every wave has read its pieces of the previous third out of U (the residual's last reader sits two barriers back)
-            const bool rot = t < p.rot_thirds;
-            const float sc = t < p.scale_thirds ? p.col_scale : 1.f;
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                const int n = 80 * wave + 16 * j + 4 * fq;
-                const int pnl = n >> 6, ch = (n & 63) >> 3;
-                const int hc = n % p.rot_head_dim;                               // channel inside its head (heads are whole quads)
-                const bool rq = rot && hc < p.rot_dim;
-#pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    const int row = 16 * i + frow;
-                    f32x4 v = Y[i][j];
-                    if (rq) {
-                        const int pos = (m0 + row) % p.rot_tokens_per_batch + p.rot_pos_offset;
-                        const f32x4 cs = *reinterpret_cast<const f32x4*>(p.rot_table + ((int64_t)pos * (p.rot_dim / 2) + hc / 2) * 2);
-                        const f32x2 r01 = rot_pair(f32x2{v[0], v[1]}, cs[0], cs[1]);
-                        const f32x2 r23 = rot_pair(f32x2{v[2], v[3]}, cs[2], cs[3]);
-                        v = f32x4{r01[0], r01[1], r23[0], r23[1]};
-                    }
-                    u32x2 o;
-                    o[0] = pack2t<F16>(v[0] * sc, v[1] * sc);
-                    o[1] = pack2t<F16>(v[2] * sc, v[3] * sc);
-                    *reinterpret_cast<u32x2*>(U + pnl * RC_PANEL + row * 128 + ((ch ^ (row & 7)) * 16) + (n & 7) * 2) = o;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            barrier_lds();                  // the third complete in U
-            store_tile(U, p.out + t * RC_C, p.ldo);
         }
     }
 }
@@ -383,8 +397,10 @@ extern "C" int seer_rowchain_c320(const seer_rowchain_desc* d, void* stream) {
                    reinterpret_cast<uintptr_t>(d->res) | reinterpret_cast<uintptr_t>(d->w2f) | reinterpret_cast<uintptr_t>(d->out);
     if (al & 15) return SEER_EINVAL;
     std::call_once(g_rc_once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_rowchain_c320_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_rowchain_c320_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_rowchain_c320_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_rowchain_c320_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_rowchain_c320_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_rowchain_c320_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS);
     });
     RcArgs a;
     a.in = reinterpret_cast<const bf16*>(d->in); a.ld_in = d->ld_in;
@@ -399,10 +415,15 @@ extern "C" int seer_rowchain_c320(const seer_rowchain_desc* d, void* stream) {
     a.rot_head_dim = d->rot_head_dim > 0 ? d->rot_head_dim : RC_C; a.rot_dim = d->rot_dim; a.rot_thirds = d->w2f ? d->rot_thirds : 0;
     a.M = (int)d->M;
     const dim3 grid((unsigned)((d->M + RC_BM - 1) / RC_BM));
-    if (d->dtype == SEER_DT_F16)
-        hipLaunchKernelGGL(seer_rowchain_c320_kernel<true>, grid, dim3(256), RC_LDS, reinterpret_cast<hipStream_t>(stream), a);
-    else
-        hipLaunchKernelGGL(seer_rowchain_c320_kernel<false>, grid, dim3(256), RC_LDS, reinterpret_cast<hipStream_t>(stream), a);
+    const bool full = d->M % RC_BM == 0 && d->h != nullptr;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d->dtype == SEER_DT_F16) {
+        if (full) hipLaunchKernelGGL((seer_rowchain_c320_kernel<true, true>), grid, dim3(256), RC_LDS, st, a);
+        else hipLaunchKernelGGL((seer_rowchain_c320_kernel<true, false>), grid, dim3(256), RC_LDS, st, a);
+    } else {
+        if (full) hipLaunchKernelGGL((seer_rowchain_c320_kernel<false, true>), grid, dim3(256), RC_LDS, st, a);
+        else hipLaunchKernelGGL((seer_rowchain_c320_kernel<false, false>), grid, dim3(256), RC_LDS, st, a);
+    }
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }

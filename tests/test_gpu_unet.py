@@ -507,7 +507,8 @@ def test_full_size_step_fp16_storage_matches_the_reference(device):
     m.use_graph = False
     # the statistics and LayerNorm forms of the bf16 engine are in use here too (no silent fallback to the slow forms)
     eng = m._engine
-    assert eng.gn_from_colsums >= eng.n_groupnorms() - 8 and eng.ln_folded >= 60, (eng.gn_from_colsums, eng.ln_folded)
+    assert eng.gn_from_colsums >= eng.n_groupnorms() - 8 and eng.ln_folded + eng.rowchains >= 60 and eng.rowchains == 15, \
+        (eng.gn_from_colsums, eng.ln_folded, eng.rowchains)
 
 
 def test_autocast_selects_the_storage_type(device):
