@@ -369,13 +369,15 @@ int seer_ff_fused_c320_dt(const void* h, int32_t ldh, const void* x, int32_t ldx
  * in the storage type `dtype` (SEER_DT_*), row strides multiples of 8 elements, h may alias res.  GroupNorm: gn_stats [batch][groups][2]
  * fp32 (sum, sum of squares per (batch element, group): what seer_groupnorm_stats* write), gn_count elements per group, rows_per_batch
  * a multiple of 96 (SEER_ENOSYS otherwise: a workgroup's 96 rows may not straddle two batch elements); NULL = no normalisation of
- * the input.  ln_gamma / ln_beta NULL = no LayerNorm.  w1f / w2f: the matrices in FRAGMENT order (seer_rowchain_pack).  The first
+ * the input; or gn_fx [gn_fx_reps][batch][2][320] int64, the fixed-point column sums the producer of `in` ACCUMULATED
+ * (seer_gemm_desc::colsum_fx): no statistics launch in front.  ln_gamma / ln_beta NULL = no LayerNorm.  w1f / w2f: the matrices in FRAGMENT order (seer_rowchain_pack).  The first
  * rot_thirds thirds are rotated like SEER_EPI_ROTARY (table of seer_rotary_table, position = row % rot_tokens_per_batch +
  * rot_pos_offset, heads of rot_head_dim channels, the first rot_dim rotated), then the first scale_thirds thirds are multiplied by
  * col_scale (the q columns leave as q * scale * log2(e) for SEER_ATTN_Q_PRESCALED).  All pointers 16-byte aligned. */
 typedef struct seer_rowchain_desc {
     const void* in; int32_t ld_in;
-    const float* gn_stats; double gn_count; float gn_eps; const float* gn_gamma; const float* gn_beta; int64_t rows_per_batch; int32_t groups;
+    const float* gn_stats; const int64_t* gn_fx; int32_t gn_fx_reps;
+    double gn_count; float gn_eps; const float* gn_gamma; const float* gn_beta; int64_t rows_per_batch; int32_t groups;
     const void* w1f; const float* b1; const void* res; int32_t ldr; void* h; int32_t ldh;
     const float* ln_gamma; const float* ln_beta; float ln_eps;
     const void* w2f; int32_t n2; void* out; int32_t ldo;

@@ -76,7 +76,7 @@ class AttnDesc(C.Structure):
 class RowChainDesc(C.Structure):
     _fields_ = [
         ("inp", C.c_void_p), ("ld_in", C.c_int32),
-        ("gn_stats", C.c_void_p), ("gn_count", C.c_double), ("gn_eps", C.c_float), ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p),
+        ("gn_stats", C.c_void_p), ("gn_fx", C.c_void_p), ("gn_fx_reps", C.c_int32), ("gn_count", C.c_double), ("gn_eps", C.c_float), ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p),
         ("rows_per_batch", C.c_int64), ("groups", C.c_int32),
         ("w1f", C.c_void_p), ("b1", C.c_void_p), ("res", C.c_void_p), ("ldr", C.c_int32), ("h", C.c_void_p), ("ldh", C.c_int32),
         ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float),

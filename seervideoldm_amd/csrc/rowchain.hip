@@ -27,13 +27,14 @@ constexpr int RC_KS = RC_C / 64;                     // 5 K steps
 constexpr int RC_PANEL = RC_BM * 128;                // 12 288
 constexpr int RC_T_BYTES = RC_KS * RC_PANEL;         // 61 440
 constexpr int RC_CONST_FLOATS = 5 * RC_C;            // gn scale | gn shift | ln gamma | ln beta | b1
-constexpr int RC_LDS = 2 * RC_T_BYTES + RC_CONST_FLOATS * 4;
+constexpr int RC_FX_BYTES = RC_C * 16;               // (sum, sum of squares) per channel as int64: the accumulated statistics of the input
+constexpr int RC_LDS = 2 * RC_T_BYTES + RC_CONST_FLOATS * 4 + RC_FX_BYTES;
 constexpr int RC_W_BLOCK = 10 * 1024;                // one wave's fragments of a K step of 64: [k32 2][5 column fragments][64 lanes][16 B]
 constexpr int RC_MAT_BYTES = RC_C * RC_C * 2;        // one packed 320 x 320 matrix
 
 struct RcArgs {
     const bf16* in; int ld_in;
-    const float* gn_stats; float gn_inv_count, gn_eps; const float* gn_gamma; const float* gn_beta; int rows_per_batch, groups;
+    const float* gn_stats; const int64_t* gn_fx; int gn_fx_reps; float gn_inv_count, gn_eps; const float* gn_gamma; const float* gn_beta; int rows_per_batch, groups;
     const unsigned char* w1f; const float* b1; const bf16* res; int ldr; bf16* h; int ldh;
     const float* ln_gamma; const float* ln_beta; float ln_eps;
     const unsigned char* w2f; int n2; bf16* out; int ldo;
@@ -180,16 +181,47 @@ __global__ void __launch_bounds__(256, 1) seer_rowchain_c320_kernel(const RcArgs
     req10(wb, voff, w1_wave + 4 * RC_W_BLOCK);
     {
         // GroupNorm of the input as a per-channel scale / shift of this tile's batch element (a tile never straddles two: the host
-        // admits rows_per_batch % 96 == 0 only); LayerNorm affine; bias
-        const int b = p.gn_stats ? m0 / p.rows_per_batch : 0;
-        const int cpg = p.gn_stats ? RC_C / p.groups : 1;
+        // admits rows_per_batch % 96 == 0 only) -- from (sum, sum of squares) per group (gn_stats), or from the fixed-point column sums
+        // its producer ACCUMULATED (gn_fx [reps][batch][2][320] int64, seer_gemm_desc::colsum_fx: no statistics launch at all; the
+        // replicas and a group's channels are added as integers, one conversion per group in double, as gn_apply_cs_kernel<FX>);
+        // LayerNorm affine; bias
+        const bool gn = p.gn_stats || p.gn_fx;
+        const int b = gn ? m0 / p.rows_per_batch : 0;
+        const int cpg = gn ? RC_C / p.groups : 1;
+        long long* fxs = reinterpret_cast<long long*>(smem + 2 * RC_T_BYTES + RC_CONST_FLOATS * 4);
+        if (p.gn_fx) {
+            const int nb = p.M / p.rows_per_batch;
+            for (int c = tid; c < RC_C; c += 256) {
+                long long sm = 0, sq = 0;
+                for (int r = 0; r < p.gn_fx_reps; ++r) {
+                    const long long* q = reinterpret_cast<const long long*>(p.gn_fx) + (int64_t)((r * nb + b) * 2) * RC_C + c;
+                    sm += q[0];
+                    sq += q[RC_C];
+                }
+                fxs[2 * c] = sm;
+                fxs[2 * c + 1] = sq;
+            }
+            __syncthreads();
+        }
         for (int c = tid; c < RC_C; c += 256) {
             float sc = 1.f, sh = 0.f;
-            if (p.gn_stats) {
-                const f32x2 st = *reinterpret_cast<const f32x2*>(p.gn_stats + ((int64_t)b * p.groups + c / cpg) * 2);
-                const float mean = st[0] * p.gn_inv_count;
-                float var = st[1] * p.gn_inv_count - mean * mean;
-                var = var > 0.f ? var : 0.f;
+            if (gn) {
+                float mean, var;
+                if (p.gn_fx) {
+                    long long sm = 0, sq = 0;
+                    const int c0 = (c / cpg) * cpg;
+                    for (int e = 0; e < cpg; ++e) { sm += fxs[2 * (c0 + e)]; sq += fxs[2 * (c0 + e) + 1]; }
+                    const double k = (double)p.gn_inv_count / (double)(1 << SEER_GN_FX_SHIFT);
+                    const double md = (double)sm * k;
+                    double vd = (double)sq * k - md * md;
+                    mean = (float)md;
+                    var = (float)(vd > 0.0 ? vd : 0.0);
+                } else {
+                    const f32x2 st = *reinterpret_cast<const f32x2*>(p.gn_stats + ((int64_t)b * p.groups + c / cpg) * 2);
+                    mean = st[0] * p.gn_inv_count;
+                    var = st[1] * p.gn_inv_count - mean * mean;
+                    var = var > 0.f ? var : 0.f;
+                }
                 sc = rsqrtf(var + p.gn_eps) * p.gn_gamma[c];
                 sh = p.gn_beta[c] - mean * sc;
             }
@@ -205,7 +237,7 @@ __global__ void __launch_bounds__(256, 1) seer_rowchain_c320_kernel(const RcArgs
 
     // lane l: row (l >> 3) of each pass of 8 rows, LDS position l & 7 of every panel = logical chunk (l & 7) ^ (row & 7)
     const int lc = (lane & 7) ^ (lane >> 3);
-    if (p.gn_stats) {
+    if (p.gn_stats || p.gn_fx) {
         // ---- GroupNorm apply in place (wave w: rows 24 w .. 24 w + 23)
         for (int pass = 0; pass < 3; ++pass) {
             const int row = wave * 24 + pass * 8 + (lane >> 3);
@@ -379,7 +411,9 @@ extern "C" int seer_rowchain_c320(const seer_rowchain_desc* d, void* stream) {
     if (!d->h && !d->w2f) return SEER_EINVAL;
     if (d->h && (d->ldh % 8 || d->ldh < RC_C)) return SEER_EINVAL;
     if (d->res && (d->ldr % 8 || d->ldr < RC_C)) return SEER_EINVAL;
-    if (d->gn_stats) {
+    if (d->gn_stats && d->gn_fx) return SEER_EINVAL;
+    if (d->gn_fx && d->gn_fx_reps < 1) return SEER_EINVAL;
+    if (d->gn_stats || d->gn_fx) {
         if (!d->gn_gamma || !d->gn_beta || d->gn_count <= 0 || d->groups <= 0 || RC_C % d->groups) return SEER_EINVAL;
         if (d->rows_per_batch <= 0 || d->rows_per_batch % RC_BM || d->M % d->rows_per_batch) return SEER_ENOSYS;     // a tile may not straddle two batch elements
     }
@@ -404,8 +438,9 @@ extern "C" int seer_rowchain_c320(const seer_rowchain_desc* d, void* stream) {
     });
     RcArgs a;
     a.in = reinterpret_cast<const bf16*>(d->in); a.ld_in = d->ld_in;
-    a.gn_stats = d->gn_stats; a.gn_inv_count = d->gn_stats ? (float)(1.0 / d->gn_count) : 0.f; a.gn_eps = d->gn_eps;
-    a.gn_gamma = d->gn_gamma; a.gn_beta = d->gn_beta; a.rows_per_batch = d->gn_stats ? (int)d->rows_per_batch : 1; a.groups = d->gn_stats ? d->groups : 1;
+    const bool gn = d->gn_stats || d->gn_fx;
+    a.gn_stats = d->gn_stats; a.gn_fx = d->gn_fx; a.gn_fx_reps = d->gn_fx_reps; a.gn_inv_count = gn ? (float)(1.0 / d->gn_count) : 0.f; a.gn_eps = d->gn_eps;
+    a.gn_gamma = d->gn_gamma; a.gn_beta = d->gn_beta; a.rows_per_batch = gn ? (int)d->rows_per_batch : 1; a.groups = gn ? d->groups : 1;
     a.w1f = reinterpret_cast<const unsigned char*>(d->w1f); a.b1 = d->b1; a.res = reinterpret_cast<const bf16*>(d->res); a.ldr = d->ldr;
     a.h = reinterpret_cast<bf16*>(d->h); a.ldh = d->ldh;
     a.ln_gamma = d->ln_gamma; a.ln_beta = d->ln_beta; a.ln_eps = d->ln_eps;

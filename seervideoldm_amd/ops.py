@@ -708,7 +708,8 @@ def rowchain_pays(rows: int, n_cu: Optional[int] = None, products: int = 4) -> b
 def rowchain(inp: torch.Tensor, w1f: torch.Tensor, *, b1: Optional[torch.Tensor] = None, gn=None, res: Optional[torch.Tensor] = None,
              h_out=True, ln=None, w2f: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, col_scale=None, rotary=None):
     """h = [GroupNorm(inp)] W1^T + b1 [+ res];  out = LayerNorm(h) [W2_0 | ...]^T  as ONE launch at 320 channels (seer_rowchain_c320).
-    gn = (stats [B, G, 2] fp32, count, eps, gamma, beta, rows_per_batch); ln = (gamma, beta, eps); w1f / w2f from rowchain_pack;
+    gn = (stats [B, G, 2] fp32 -- or the ColSumsFx the producer of inp accumulated: no statistics launch --, count, eps, gamma, beta,
+    rows_per_batch[, groups]); ln = (gamma, beta, eps); w1f / w2f from rowchain_pack;
     h_out: True = a new tensor, a tensor = write there (may be `res`), False = h is not stored; col_scale = (factor, thirds);
     rotary = (table, tokens_per_batch, pos_offset, head_dim, rot_dim, thirds).  Returns (h or None, out or None), or None when the
     launch is refused (SEER_ENOSYS: a 96-row tile would straddle two batch elements of the GroupNorm)."""
@@ -721,11 +722,18 @@ def rowchain(inp: torch.Tensor, w1f: torch.Tensor, *, b1: Optional[torch.Tensor]
     if b1 is not None:
         _req(b1, torch.float32, "b1"); d.b1 = _p(b1)
     if gn is not None:
-        stats, count, eps, gamma, beta, rows_pb = gn
-        _req(stats, torch.float32, "gn stats"); _req(gamma, torch.float32, "gn gamma"); _req(beta, torch.float32, "gn beta")
-        assert stats.is_contiguous() and stats.dim() == 3 and stats.shape[2] == 2 and M % rows_pb == 0 and stats.shape[0] == M // rows_pb
-        d.gn_stats, d.gn_count, d.gn_eps, d.gn_gamma, d.gn_beta = _p(stats), float(count), float(eps), _p(gamma), _p(beta)
-        d.rows_per_batch, d.groups = rows_pb, stats.shape[1]
+        stats, count, eps, gamma, beta, rows_pb = gn[:6]
+        _req(gamma, torch.float32, "gn gamma"); _req(beta, torch.float32, "gn beta")
+        assert M % rows_pb == 0
+        if isinstance(stats, ColSumsFx):
+            assert stats.C == Cc and stats.buf.shape[1] == M // rows_pb and len(gn) > 6
+            d.gn_fx, d.gn_fx_reps, d.groups = _p(stats.buf), stats.reps, int(gn[6])
+        else:
+            _req(stats, torch.float32, "gn stats")
+            assert stats.is_contiguous() and stats.dim() == 3 and stats.shape[2] == 2 and stats.shape[0] == M // rows_pb
+            d.gn_stats, d.groups = _p(stats), stats.shape[1]
+        d.gn_count, d.gn_eps, d.gn_gamma, d.gn_beta = float(count), float(eps), _p(gamma), _p(beta)
+        d.rows_per_batch = rows_pb
     if res is not None:
         _req16(res, "res", inp)
         assert res.shape == (M, Cc) and res.stride(1) == 1

@@ -461,7 +461,7 @@ class _Engine:
         return ops.groupnorm_apply(x1, x2, B, self.G, stats, count, eps, self.w[name + ".weight"],
                                    self.w[name + ".bias"], silu)
 
-    def _cb(self, B, rows_pb):
+    def _cb(self, B, rows_pb, for_chain=False):
         """`colsum_batch` of a launch whose output (rows_pb rows per batch element) feeds a GroupNorm: (B, arena) = accumulate in
         fixed point, B = per-tile sums.  The accumulated form wins where the tensor is small (its apply launch owns slices of
         64..128 channels: 160-byte pieces of a 640-byte row at the 32x32 level, ~20 % below the full-row kernel's bandwidth, and
@@ -469,16 +469,28 @@ class _Engine:
         finalize + apply, at the 32x32 level 12.6 / 27.9 against 11.3 / 25.6 (profiles/r04_gn_fx_by_level.log)."""
         if not self.gn_colsums:
             return 0
-        return (B, self._fx) if (self._fx is not None and rows_pb <= FX_MAX_ROWS_PB) else B
+        return (B, self._fx) if (self._fx is not None and (rows_pb <= FX_MAX_ROWS_PB or for_chain)) else B
+
+    def _chain_next(self, C, B, rows_pb):
+        """will a transformer's GroupNorm -> proj_in -> norm1 -> q|k|v over [B * rows_pb, C] run as one launch (ops.rowchain)?  Its
+        producer then ACCUMULATES the column sums whatever the tensor's size (_cb(for_chain=True)): the chain reads them directly and
+        the statistics launch in front of it goes too (the apply launch that made the accumulated form lose at the 32x32 level is
+        not run at all there)"""
+        ops = self.ops
+        return bool(self.rowchain and self.shard is None and self._fx is not None and C == getattr(ops, "ROWCHAIN_C", -1) and
+                    rows_pb % ops.ROWCHAIN_ROWS == 0 and ops.rowchain_pays(B * rows_pb))
 
     def _gn_stats(self, x, B, rows_pb):
-        """(stats [B, G, 2], count) of the GroupNorm over x alone, for a launch that applies the normalisation itself (ops.rowchain):
-        from the producer's per-tile column sums, else from a pass over x.  None: the accumulated fixed-point form (small tensors) or a
-        sharded engine -- the caller keeps the separate launches."""
+        """(statistics, count) of the GroupNorm over x alone, for a launch that applies the normalisation itself (ops.rowchain): the
+        producer's accumulated fixed-point sums as they are, else stats [B, G, 2] from its per-tile column sums or from a pass over x.
+        None: a sharded engine -- the caller keeps the separate launches."""
         ops = self.ops
         cs = getattr(x, "colsums", None)
-        if self.shard is not None or isinstance(cs, getattr(ops, "ColSumsFx", ())):
+        if self.shard is not None:
             return None
+        if isinstance(cs, getattr(ops, "ColSumsFx", ())):
+            self.gn_from_colsums += 1
+            return cs, rows_pb * (x.shape[1] // self.G)         # the producer's accumulated sums: read by the chain itself
         stats = self._stats_arena[self._stats_i]
         self._stats_i += 1
         if self.gn_colsums and cs is not None:
@@ -499,7 +511,7 @@ class _Engine:
         if st is None:
             return None
         r = ops.rowchain(x, w[p + ".rc.proj_in"], b1=w[p + ".proj_in.bias"],
-                         gn=(st[0], st[1], 1e-6, w[p + ".norm.weight"], w[p + ".norm.bias"], rows_pb),
+                         gn=(st[0], st[1], 1e-6, w[p + ".norm.weight"], w[p + ".norm.bias"], rows_pb, self.G),
                          ln=(w[tb + ".norm1.weight"], w[tb + ".norm1.bias"], 1e-5), w2f=w[tb + ".rc.qkv"], col_scale=(qs, 1), rotary=rotary)
         if r is None:
             self._stats_i = i0
@@ -507,8 +519,9 @@ class _Engine:
         self.rowchains += 1
         return r
 
-    def _resnet(self, p, x, skip, geo):
-        """ResnetBlock3D (resnet.py:174-208); `skip` is the channel-concat partner of unet_3d_blocks.py:596,712."""
+    def _resnet(self, p, x, skip, geo, feeds_transformer=False):
+        """ResnetBlock3D (resnet.py:174-208); `skip` is the channel-concat partner of unet_3d_blocks.py:596,712.  feeds_transformer:
+        the output's only GroupNorm is the next transformer's (see _chain_next)."""
         ops, w = self.ops, self.w
         B, Fr, H, W = geo
         rows_pb = Fr * H * W
@@ -524,6 +537,8 @@ class _Engine:
         else:
             assert skip is None
             sc = x
+        if feeds_transformer and self._chain_next(w[p + ".conv2.weight"].shape[0], B, rows_pb):
+            cb = self._cb(B, rows_pb, for_chain=True)
         return ops.conv3x3(h, w[p + ".conv2.weight"], B * Fr, H, W, bias=w[p + ".conv2.bias"], residual=sc, colsum_batch=cb)
 
     def _ln_gemm(self, h, tb, norm, wkey, bias_key=None, **kw):
@@ -613,7 +628,8 @@ class _Engine:
         # (the fused feed-forward normalises its rows itself: no row statistics asked of their producer)
         ops.gemm(a, w[tb + ".attn2.to_out.0.weight"], bias=w[tb + ".attn2.to_out.0.bias"], residual=h, out=h,
                  **({} if self._ff_fused_rows(p, h) else self._rs()))
-        return self._ff_proj_out(p, tb, h, x, self._cb(B, Fr * HW))
+        # (the output's only GroupNorm is the temporal transformer's: accumulated sums when that one runs as a chain)
+        return self._ff_proj_out(p, tb, h, x, self._cb(B, Fr * HW, for_chain=self._chain_next(C, B, Fr * HW)))
 
     def _cross_scores(self, q, k, B, Fr, H, W, heads, d, L):
         """`attention_scores` of the text cross attention (attention.py:556-584: scale * Q K^T before the softmax) as
@@ -737,7 +753,7 @@ class _Engine:
         for i in range(n):
             p = f"down_blocks.{i}"
             for j in range(lpb):
-                x = self._resnet(f"{p}.resnets.{j}", x, None, geo)
+                x = self._resnet(f"{p}.resnets.{j}", x, None, geo, feeds_transformer=i < n - 1)
                 if i < n - 1:
                     x = self._text_transformer(f"{p}.attentions.{j}", x, geo)
                     x = self._temporal_transformer(f"{p}.temporal_attentions.{j}", x, geo, cond_frame)
@@ -748,14 +764,14 @@ class _Engine:
                                 colsum_batch=self._cb(B, Fr * ((geo[2] - 1) // 2 + 1) * ((geo[3] - 1) // 2 + 1)))
                 geo = (B, Fr, (geo[2] - 1) // 2 + 1, (geo[3] - 1) // 2 + 1)
                 skips.append(x)
-        x = self._resnet("mid_block.resnets.0", x, None, geo)
+        x = self._resnet("mid_block.resnets.0", x, None, geo, feeds_transformer=True)
         x = self._text_transformer("mid_block.attentions.0", x, geo)
         x = self._temporal_transformer("mid_block.temporal_attentions.0", x, geo, cond_frame)
         x = self._resnet("mid_block.resnets.1", x, None, geo)
         for i in range(n):
             p = f"up_blocks.{i}"
             for j in range(lpb + 1):
-                x = self._resnet(f"{p}.resnets.{j}", x, skips.pop(), geo)
+                x = self._resnet(f"{p}.resnets.{j}", x, skips.pop(), geo, feeds_transformer=i > 0)
                 if i > 0:
                     x = self._text_transformer(f"{p}.attentions.{j}", x, geo)
                     x = self._temporal_transformer(f"{p}.temporal_attentions.{j}", x, geo, cond_frame)

@@ -105,3 +105,30 @@ def test_rowchain_refuses_a_tile_across_two_batch_elements(device):
     ops.groupnorm_stats(x, None, 2, 32, stats)
     g = _rand((C,), device, 3)
     assert ops.rowchain(x, w, gn=(stats, 200 * 10, 1e-6, g, g, 200)) is None
+
+
+def test_groupnorm_from_the_producers_accumulated_sums(device):
+    """the chain reads the fixed-point column sums its input's producer accumulated (seer_gemm_desc::colsum_fx): no statistics launch
+    in front; same result as from the (sum, sum of squares) per group of a statistics pass up to the statistics' rounding"""
+    from seervideoldm_amd import ops
+    B, rows_pb, G = 2, 12288, 32
+    M = B * rows_pb
+    a = _rand((M, 320), device, 1).to(bf16)
+    wprod = _rand((C, 320), device, 2, 320 ** -0.5).to(bf16)
+    arena = ops.FxArena(device, 1 << 18)
+    x = ops.gemm(a, wprod, bias=_rand((C,), device, 3), colsum_batch=(B, arena))
+    assert isinstance(x.colsums, ops.ColSumsFx)
+    gg, gb = _rand((C,), device, 4) * 0.2 + 1.0, _rand((C,), device, 5) * 0.2
+    wp = ops.rowchain_pack(_rand((C, C), device, 6, C ** -0.5).to(bf16))
+    wq = ops.rowchain_pack(_rand((3 * C, C), device, 7, C ** -0.5).to(bf16))
+    lg, lb = _rand((C,), device, 8) * 0.2 + 1.0, _rand((C,), device, 9) * 0.2
+    count = rows_pb * (C // G)
+    h1, q1 = ops.rowchain(x, wp, gn=(x.colsums, count, 1e-6, gg, gb, rows_pb, G), ln=(lg, lb, 1e-5), w2f=wq)
+    stats = torch.zeros((B, G, 2), device=device)
+    ops.groupnorm_stats(x, None, B, G, stats)
+    h2, q2 = ops.rowchain(x, wp, gn=(stats, count, 1e-6, gg, gb, rows_pb), ln=(lg, lb, 1e-5), w2f=wq)
+    assert _rel(h1, h2) < 2e-3 and _rel(q1, q2) < 2e-3, (_rel(h1, h2), _rel(q1, q2))
+    xn = Fn.group_norm(x.float().reshape(B, rows_pb, C).permute(0, 2, 1), G, gg, gb, 1e-6).permute(0, 2, 1).reshape(M, C)
+    # (reference through the same packed weights is the other test's job; here: the normalisation itself)
+    h3 = ops.rowchain(x, wp, gn=(x.colsums, count, 1e-6, gg, gb, rows_pb, G))[0]
+    assert torch.equal(h3, h1)
