@@ -362,20 +362,20 @@ int seer_ff_fused_c320_dt(const void* h, int32_t ldh, const void* x, int32_t ldx
                           const float* bcat, int64_t* colsum_fx, int64_t fx_rows, int32_t fx_reps, float* colsum_tiles, int32_t dtype,
                           void* stream);
 /* The row-local chains in front of the attention launches of a transformer block at the 320-channel level, ONE launch (csrc/rowchain.hip):
- *     h   = [GroupNorm(in)] W1^T + b1 [+ res]                          (stored when h != NULL)
+ *     h   = [GroupNorm(inp)] W1^T + b1 [+ res]                         (stored when h != NULL)
  *     out = LayerNorm(h; ln_gamma, ln_beta, ln_eps) [W2_0 | ... ]^T     n2 = 1..3 thirds of 320 columns (skipped when w2f == NULL)
  * GroupNorm -> proj_in -> norm1 -> to_q | to_k | to_v (seer/models/attention.py:129-145, 231-240, 308-318; the temporal block's rotary
- * embedding :649-651 as rot_*), or attn1.to_out + residual -> norm2 -> attn2.to_q (:316-322).  in, res, h [M][320], out [M][n2 * 320]
+ * embedding :649-651 as rot_*), or attn1.to_out + residual -> norm2 -> attn2.to_q (:316-322).  inp, res, h [M][320], out [M][n2 * 320]
  * in the storage type `dtype` (SEER_DT_*), row strides multiples of 8 elements, h may alias res.  GroupNorm: gn_stats [batch][groups][2]
  * fp32 (sum, sum of squares per (batch element, group): what seer_groupnorm_stats* write), gn_count elements per group, rows_per_batch
  * a multiple of 96 (SEER_ENOSYS otherwise: a workgroup's 96 rows may not straddle two batch elements); NULL = no normalisation of
- * the input; or gn_fx [gn_fx_reps][batch][2][320] int64, the fixed-point column sums the producer of `in` ACCUMULATED
+ * the input; or gn_fx [gn_fx_reps][batch][2][320] int64, the fixed-point column sums the producer of `inp` ACCUMULATED
  * (seer_gemm_desc::colsum_fx): no statistics launch in front.  ln_gamma / ln_beta NULL = no LayerNorm.  w1f / w2f: the matrices in FRAGMENT order (seer_rowchain_pack).  The first
  * rot_thirds thirds are rotated like SEER_EPI_ROTARY (table of seer_rotary_table, position = row % rot_tokens_per_batch +
  * rot_pos_offset, heads of rot_head_dim channels, the first rot_dim rotated), then the first scale_thirds thirds are multiplied by
  * col_scale (the q columns leave as q * scale * log2(e) for SEER_ATTN_Q_PRESCALED).  All pointers 16-byte aligned. */
 typedef struct seer_rowchain_desc {
-    const void* in; int32_t ld_in;
+    const void* inp; int32_t ld_in;
     const float* gn_stats; const int64_t* gn_fx; int32_t gn_fx_reps;
     double gn_count; float gn_eps; const float* gn_gamma; const float* gn_beta; int64_t rows_per_batch; int32_t groups;
     const void* w1f; const float* b1; const void* res; int32_t ldr; void* h; int32_t ldh;

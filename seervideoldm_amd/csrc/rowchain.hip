@@ -405,7 +405,7 @@ extern "C" int seer_rowchain_pack(const void* W, int32_t ld, int32_t n_mats, voi
 }
 
 extern "C" int seer_rowchain_c320(const seer_rowchain_desc* d, void* stream) {
-    if (!d || !d->in || !d->w1f || d->M <= 0 || d->M >= (1ll << 31) - RC_BM) return SEER_EINVAL;
+    if (!d || !d->inp || !d->w1f || d->M <= 0 || d->M >= (1ll << 31) - RC_BM) return SEER_EINVAL;
     if (d->dtype != SEER_DT_BF16 && d->dtype != SEER_DT_F16) return SEER_EINVAL;
     if (d->ld_in % 8 || d->ld_in < RC_C) return SEER_EINVAL;
     if (!d->h && !d->w2f) return SEER_EINVAL;
@@ -427,7 +427,7 @@ extern "C" int seer_rowchain_c320(const seer_rowchain_desc* d, void* stream) {
                 return SEER_EINVAL;
         }
     }
-    uintptr_t al = reinterpret_cast<uintptr_t>(d->in) | reinterpret_cast<uintptr_t>(d->w1f) | reinterpret_cast<uintptr_t>(d->h) |
+    uintptr_t al = reinterpret_cast<uintptr_t>(d->inp) | reinterpret_cast<uintptr_t>(d->w1f) | reinterpret_cast<uintptr_t>(d->h) |
                    reinterpret_cast<uintptr_t>(d->res) | reinterpret_cast<uintptr_t>(d->w2f) | reinterpret_cast<uintptr_t>(d->out);
     if (al & 15) return SEER_EINVAL;
     std::call_once(g_rc_once, [] {
@@ -437,7 +437,7 @@ extern "C" int seer_rowchain_c320(const seer_rowchain_desc* d, void* stream) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_rowchain_c320_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS);
     });
     RcArgs a;
-    a.in = reinterpret_cast<const bf16*>(d->in); a.ld_in = d->ld_in;
+    a.in = reinterpret_cast<const bf16*>(d->inp); a.ld_in = d->ld_in;
     const bool gn = d->gn_stats || d->gn_fx;
     a.gn_stats = d->gn_stats; a.gn_fx = d->gn_fx; a.gn_fx_reps = d->gn_fx_reps; a.gn_inv_count = gn ? (float)(1.0 / d->gn_count) : 0.f; a.gn_eps = d->gn_eps;
     a.gn_gamma = d->gn_gamma; a.gn_beta = d->gn_beta; a.rows_per_batch = gn ? (int)d->rows_per_batch : 1; a.groups = gn ? d->groups : 1;

@@ -43,7 +43,7 @@ def test_desc_struct_layout_matches_header():
     """field order of the ctypes structs == field order of the C structs (parsed from the header)."""
     from seervideoldm_amd import _lib
     text = HEADER.read_text()
-    for cname, cls in (("seer_gemm_desc", _lib.GemmDesc), ("seer_attn_desc", _lib.AttnDesc)):
+    for cname, cls in (("seer_gemm_desc", _lib.GemmDesc), ("seer_attn_desc", _lib.AttnDesc), ("seer_rowchain_desc", _lib.RowChainDesc)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), text, flags=re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         fields = []
@@ -70,6 +70,13 @@ def test_argument_validation_without_gpu(lib_path):
     a.Q = a.K = a.V = a.O = 1
     a.batch, a.heads, a.head_dim, a.Sq, a.Sk = 1, 8, 64, 16, 16     # head_dim 64 is not built
     assert lib.seer_attn_fwd(ctypes.byref(a), None) == -38
+    r = _lib.RowChainDesc()
+    assert lib.seer_rowchain_c320(None, None) == -22 and lib.seer_rowchain_c320(ctypes.byref(r), None) == -22
+    r.inp = r.w1f = r.h = 16
+    r.M, r.ld_in, r.ldh = 200, 320, 320
+    r.gn_stats = r.gn_gamma = r.gn_beta = 16
+    r.gn_count, r.groups, r.rows_per_batch = 1000.0, 32, 100          # a 96-row tile would straddle two batch elements
+    assert lib.seer_rowchain_c320(ctypes.byref(r), None) == -38
 
 
 def test_header_is_plain_c_and_the_c_caller_links(lib_path):

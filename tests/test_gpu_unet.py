@@ -533,6 +533,29 @@ def test_autocast_selects_the_storage_type(device):
         m._engine = None
 
 
+def test_accelerate_prepare_under_the_shipped_mixed_precision(device):
+    """inference_img.py:93 as shipped: `accelerator.prepare(sunet, fstext_model)` with `mixed_precision: "fp16"`
+    (configs/inference_base.yaml:16) through the REAL accelerate: prepare() wraps forward in fp16 autocast and converts the output to
+    fp32 -- the engine must take fp16 storage from that state and land where the explicit compute_dtype lands, bit for bit"""
+    from accelerate import Accelerator
+    cfg = dict(CFG_MINI)
+    sd = synth.synth_state_dict(synth.unet_param_shapes(cfg))
+    x, ctx, t = _randn((1, 4, 2, 16, 16), 3).to(device), _randn((1, 2, 77, cfg["cross_attention_dim"]), 4).to(device), torch.tensor([501], device=device)
+    ref = SeerUNet(**cfg, compute_dtype=torch.float16)
+    ref.load_state_dict(sd, strict=True)
+    want = ref.to(device).eval()(x, t, ctx, cond_frame=1)
+    m = SeerUNet(**cfg)
+    m.load_state_dict(sd, strict=True)
+    acc = Accelerator(mixed_precision="fp16")
+    pm = acc.prepare(m.eval())
+    got = pm(x, t, ctx, cond_frame=1)
+    inner = acc.unwrap_model(pm)
+    assert inner._engine is not None and inner._engine.dt == torch.float16
+    assert got.dtype == torch.float32 and torch.equal(got, want)
+    oracle = O.unet_forward(sd, cfg, x.cpu(), t.cpu(), ctx.cpu(), cond_frame=1)
+    assert _rel(got, oracle) <= REL_L2_F16
+
+
 def test_bridge_config_single_gpu(device):
     """BASELINE config 3 on one GPU: CFG batch 8 (4 samples x [uc, c]) x 16 frames (1 conditioning) x 32^2, full-width UNet.
     (0) against the REAL reference's output at this size; (a) finite, right shape; (b) a sample's result does not depend on its batch slot or on its neighbours: rows 0 and 4 of
