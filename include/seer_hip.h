@@ -368,7 +368,7 @@ int seer_ff_fused_c320_dt(const void* h, int32_t ldh, const void* x, int32_t ldx
  * embedding :649-651 as rot_*), or attn1.to_out + residual -> norm2 -> attn2.to_q (:316-322).  inp, res, h [M][320], out [M][n2 * 320]
  * in the storage type `dtype` (SEER_DT_*), row strides multiples of 8 elements, h may alias res.  GroupNorm: gn_stats [batch][groups][2]
  * fp32 (sum, sum of squares per (batch element, group): what seer_groupnorm_stats* write), gn_count elements per group, rows_per_batch
- * a multiple of 96 (SEER_ENOSYS otherwise: a workgroup's 96 rows may not straddle two batch elements); NULL = no normalisation of
+ * >= 96 (SEER_ENOSYS otherwise: a workgroup's 96 rows span at most two batch elements); NULL = no normalisation of
  * the input; or gn_fx [gn_fx_reps][batch][2][320] int64, the fixed-point column sums the producer of `inp` ACCUMULATED
  * (seer_gemm_desc::colsum_fx): no statistics launch in front.  ln_gamma / ln_beta NULL = no LayerNorm.  w1f / w2f: the matrices in FRAGMENT order (seer_rowchain_pack).  The first
  * rot_thirds thirds are rotated like SEER_EPI_ROTARY (table of seer_rotary_table, position = row % rot_tokens_per_batch +

@@ -15,7 +15,7 @@
 // registers in a host-packed fragment order (one contiguous KiB per wave and load, two K steps ahead, every wait a compile-time
 // count), the activation fragments come from T one sub step ahead -- and leaves through LDS as whole rows.  What never reaches memory:
 // the normalised copy of x (31 MB written + read per block at 24 576 rows), and h is read back by nobody in this launch.
-// LDS: 61 440 (T) + 61 440 (residual in / staged output) + 6 400 (constants) = 129 280 bytes.
+// LDS: 61 440 (T) + 61 440 (residual in / staged output) + 8 960 (constants) + 10 240 (accumulated sums) = 142 080 bytes.
 #include "seer_common.h"
 #include <mutex>
 
@@ -26,8 +26,8 @@ constexpr int RC_BM = 96;
 constexpr int RC_KS = RC_C / 64;                     // 5 K steps
 constexpr int RC_PANEL = RC_BM * 128;                // 12 288
 constexpr int RC_T_BYTES = RC_KS * RC_PANEL;         // 61 440
-constexpr int RC_CONST_FLOATS = 5 * RC_C;            // gn scale | gn shift | ln gamma | ln beta | b1
-constexpr int RC_FX_BYTES = RC_C * 16;               // (sum, sum of squares) per channel as int64: the accumulated statistics of the input
+constexpr int RC_CONST_FLOATS = 7 * RC_C;            // gn scale | gn shift (first batch element of the tile) | ln gamma | ln beta | b1 | gn scale | gn shift (second)
+constexpr int RC_FX_BYTES = 2 * RC_C * 16;           // (sum, sum of squares) per channel as int64, two batch elements: the accumulated statistics of the input
 constexpr int RC_LDS = 2 * RC_T_BYTES + RC_CONST_FLOATS * 4 + RC_FX_BYTES;
 constexpr int RC_W_BLOCK = 10 * 1024;                // one wave's fragments of a K step of 64: [k32 2][5 column fragments][64 lanes][16 B]
 constexpr int RC_MAT_BYTES = RC_C * RC_C * 2;        // one packed 320 x 320 matrix
@@ -180,36 +180,40 @@ __global__ void __launch_bounds__(256, 1) seer_rowchain_c320_kernel(const RcArgs
     req10(wa, voff, w1_wave);
     req10(wb, voff, w1_wave + 4 * RC_W_BLOCK);
     {
-        // GroupNorm of the input as a per-channel scale / shift of this tile's batch element (a tile never straddles two: the host
-        // admits rows_per_batch % 96 == 0 only) -- from (sum, sum of squares) per group (gn_stats), or from the fixed-point column sums
+        // GroupNorm of the input as a per-channel scale / shift of the (at most two: rows_per_batch >= 96) batch elements this tile's
+        // rows belong to -- from (sum, sum of squares) per group (gn_stats), or from the fixed-point column sums
         // its producer ACCUMULATED (gn_fx [reps][batch][2][320] int64, seer_gemm_desc::colsum_fx: no statistics launch at all; the
         // replicas and a group's channels are added as integers, one conversion per group in double, as gn_apply_cs_kernel<FX>);
         // LayerNorm affine; bias
         const bool gn = p.gn_stats || p.gn_fx;
-        const int b = gn ? m0 / p.rows_per_batch : 0;
+        const int nb = gn ? p.M / p.rows_per_batch : 1;
+        const int b0 = gn ? m0 / p.rows_per_batch : 0;          // a tile spans at most two batch elements (rows_per_batch >= 96)
         const int cpg = gn ? RC_C / p.groups : 1;
         long long* fxs = reinterpret_cast<long long*>(smem + 2 * RC_T_BYTES + RC_CONST_FLOATS * 4);
         if (p.gn_fx) {
-            const int nb = p.M / p.rows_per_batch;
-            for (int c = tid; c < RC_C; c += 256) {
+            for (int i = tid; i < 2 * RC_C; i += 256) {
+                const int which = i / RC_C, c = i - which * RC_C;
+                const int b = min(b0 + which, nb - 1);
                 long long sm = 0, sq = 0;
                 for (int r = 0; r < p.gn_fx_reps; ++r) {
                     const long long* q = reinterpret_cast<const long long*>(p.gn_fx) + (int64_t)((r * nb + b) * 2) * RC_C + c;
                     sm += q[0];
                     sq += q[RC_C];
                 }
-                fxs[2 * c] = sm;
-                fxs[2 * c + 1] = sq;
+                fxs[2 * i] = sm;
+                fxs[2 * i + 1] = sq;
             }
             __syncthreads();
         }
-        for (int c = tid; c < RC_C; c += 256) {
+        for (int i = tid; i < 2 * RC_C; i += 256) {
+            const int which = i / RC_C, c = i - which * RC_C;
             float sc = 1.f, sh = 0.f;
             if (gn) {
+                const int b = min(b0 + which, nb - 1);
                 float mean, var;
                 if (p.gn_fx) {
                     long long sm = 0, sq = 0;
-                    const int c0 = (c / cpg) * cpg;
+                    const int c0 = which * RC_C + (c / cpg) * cpg;
                     for (int e = 0; e < cpg; ++e) { sm += fxs[2 * (c0 + e)]; sq += fxs[2 * (c0 + e) + 1]; }
                     const double k = (double)p.gn_inv_count / (double)(1 << SEER_GN_FX_SHIFT);
                     const double md = (double)sm * k;
@@ -225,11 +229,13 @@ __global__ void __launch_bounds__(256, 1) seer_rowchain_c320_kernel(const RcArgs
                 sc = rsqrtf(var + p.gn_eps) * p.gn_gamma[c];
                 sh = p.gn_beta[c] - mean * sc;
             }
-            cst[c] = sc;
-            cst[RC_C + c] = sh;
-            cst[2 * RC_C + c] = p.ln_gamma ? p.ln_gamma[c] : 1.f;
-            cst[3 * RC_C + c] = p.ln_beta ? p.ln_beta[c] : 0.f;
-            cst[4 * RC_C + c] = p.b1 ? p.b1[c] : 0.f;
+            cst[(which ? 5 : 0) * RC_C + c] = sc;
+            cst[(which ? 6 : 1) * RC_C + c] = sh;
+            if (!which) {
+                cst[2 * RC_C + c] = p.ln_gamma ? p.ln_gamma[c] : 1.f;
+                cst[3 * RC_C + c] = p.ln_beta ? p.ln_beta[c] : 0.f;
+                cst[4 * RC_C + c] = p.b1 ? p.b1[c] : 0.f;
+            }
         }
     }
     wait_vm<0>();
@@ -239,15 +245,17 @@ __global__ void __launch_bounds__(256, 1) seer_rowchain_c320_kernel(const RcArgs
     const int lc = (lane & 7) ^ (lane >> 3);
     if (p.gn_stats || p.gn_fx) {
         // ---- GroupNorm apply in place (wave w: rows 24 w .. 24 w + 23)
+        const int first_b = m0 / p.rows_per_batch;
         for (int pass = 0; pass < 3; ++pass) {
             const int row = wave * 24 + pass * 8 + (lane >> 3);
+            const bool second = (m0 + row) / p.rows_per_batch != first_b;       // the row belongs to the tile's second batch element
 #pragma unroll
             for (int q = 0; q < 5; ++q) {
                 unsigned char* cell = T + q * RC_PANEL + row * 128 + (lane & 7) * 16;
                 float v[8];
                 unpack8t<F16>(*reinterpret_cast<const u32x4*>(cell), v);
-                const f32x4* sp = reinterpret_cast<const f32x4*>(cst + q * 64 + lc * 8);
-                const f32x4* hp = reinterpret_cast<const f32x4*>(cst + RC_C + q * 64 + lc * 8);
+                const f32x4* sp = reinterpret_cast<const f32x4*>(cst + (second ? 5 : 0) * RC_C + q * 64 + lc * 8);
+                const f32x4* hp = reinterpret_cast<const f32x4*>(cst + (second ? 6 : 1) * RC_C + q * 64 + lc * 8);
                 const f32x4 s0 = sp[0], s1 = sp[1], h0 = hp[0], h1 = hp[1];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -415,7 +423,8 @@ extern "C" int seer_rowchain_c320(const seer_rowchain_desc* d, void* stream) {
     if (d->gn_fx && d->gn_fx_reps < 1) return SEER_EINVAL;
     if (d->gn_stats || d->gn_fx) {
         if (!d->gn_gamma || !d->gn_beta || d->gn_count <= 0 || d->groups <= 0 || RC_C % d->groups) return SEER_EINVAL;
-        if (d->rows_per_batch <= 0 || d->rows_per_batch % RC_BM || d->M % d->rows_per_batch) return SEER_ENOSYS;     // a tile may not straddle two batch elements
+        if (d->rows_per_batch <= 0 || d->M % d->rows_per_batch) return SEER_EINVAL;
+        if (d->rows_per_batch < RC_BM) return SEER_ENOSYS;       // a 96-row tile would span more than two batch elements
     }
     if ((d->ln_gamma == nullptr) != (d->ln_beta == nullptr)) return SEER_EINVAL;
     if (d->w2f) {

@@ -82,7 +82,7 @@ def rowchain_pays(rows, n_cu=256, products=4):
 
 def rowchain(inp, w1f, *, b1=None, gn=None, res=None, h_out=True, ln=None, w2f=None, out=None, col_scale=None, rotary=None):
     M, Cc = inp.shape
-    if gn is not None and gn[5] % ROWCHAIN_ROWS:
+    if gn is not None and gn[5] < ROWCHAIN_ROWS:
         return None
     h = None
     if h_out is not False:

@@ -75,7 +75,7 @@ def test_argument_validation_without_gpu(lib_path):
     r.inp = r.w1f = r.h = 16
     r.M, r.ld_in, r.ldh = 200, 320, 320
     r.gn_stats = r.gn_gamma = r.gn_beta = 16
-    r.gn_count, r.groups, r.rows_per_batch = 1000.0, 32, 100          # a 96-row tile would straddle two batch elements
+    r.gn_count, r.groups, r.rows_per_batch = 500.0, 32, 50           # a 96-row tile would span three batch elements
     assert lib.seer_rowchain_c320(ctypes.byref(r), None) == -38
 
 

@@ -29,7 +29,8 @@ def _rotary_ref(y, M, heads, d, rot, freqs, T, off=0):
     return v.reshape(M, heads * d)
 
 
-@pytest.mark.parametrize("dt,B,rows_pb,rotary", [(bf16, 2, 12288, False), (bf16, 2, 1536, True), (f16, 2, 3072, True), (bf16, 1, 96, False)])
+@pytest.mark.parametrize("dt,B,rows_pb,rotary", [(bf16, 2, 12288, False), (bf16, 2, 1536, True), (f16, 2, 3072, True), (bf16, 1, 96, False),
+                                                  (bf16, 3, 1000, True), (f16, 8, 200, False)])      # tiles that span two batch elements
 def test_groupnorm_proj_in_layernorm_qkv(device, dt, B, rows_pb, rotary):
     from seervideoldm_amd import ops
     M, G = B * rows_pb, 32
@@ -97,14 +98,14 @@ def test_to_out_residual_layernorm_q_in_place(device, dt, M):
     assert torch.equal(h1, h)
 
 
-def test_rowchain_refuses_a_tile_across_two_batch_elements(device):
+def test_rowchain_refuses_a_tile_across_three_batch_elements(device):
     from seervideoldm_amd import ops
-    x = _rand((2 * 200, C), device, 1).to(bf16)
+    x = _rand((4 * 40, C), device, 1).to(bf16)
     w = ops.rowchain_pack(_rand((C, C), device, 2, 0.05).to(bf16))
-    stats = torch.zeros((2, 32, 2), device=device)
-    ops.groupnorm_stats(x, None, 2, 32, stats)
+    stats = torch.zeros((4, 32, 2), device=device)
+    ops.groupnorm_stats(x, None, 4, 32, stats)
     g = _rand((C,), device, 3)
-    assert ops.rowchain(x, w, gn=(stats, 200 * 10, 1e-6, g, g, 200)) is None
+    assert ops.rowchain(x, w, gn=(stats, 40 * 10, 1e-6, g, g, 40)) is None
 
 
 def test_groupnorm_from_the_producers_accumulated_sums(device):
