@@ -11,7 +11,6 @@ There is no CPU path: calling forward with CPU tensors, or without the built lib
 """
 from __future__ import annotations
 
-import contextlib
 import json
 import os
 from collections import OrderedDict
@@ -266,9 +265,6 @@ class _Engine:
         # model.rowchain = False / SEER_ROWCHAIN=0: the separate launches)
         self.rowchain = bool(getattr(model, "rowchain", os.environ.get("SEER_ROWCHAIN", "1") != "0")) and hasattr(self.ops, "rowchain")
         self.rowchains = 0
-        self.temb_fork = os.environ.get("SEER_TEMB_FORK", "1") != "0"
-        self._side = None
-        self._temb_join = None
         self.gn_from_colsums = 0
         self.w: Dict[str, torch.Tensor] = {}
         self._pack(sd)
@@ -531,9 +527,6 @@ class _Engine:
         rows_pb = Fr * H * W
         cb = self._cb(B, rows_pb)          # outputs that feed a GroupNorm leave their column sums behind
         h = self._gn(x, skip, B, rows_pb, p + ".norm1", self.eps, True)
-        if self._temb_join is not None:    # the first reader of the time embedding: the side stream joins here
-            self._temb_join()
-            self._temb_join = None
         off, n = self.temb_slices[p]
         temb = self._temb[:, off:off + n]
         h = ops.conv3x3(h, w[p + ".conv1.weight"], B * Fr, H, W, bias=w[p + ".conv1.bias"], rowvec=temb,
@@ -748,22 +741,12 @@ class _Engine:
                 self._fx_arena = ops.FxArena(sample.device, need)
             self._fx_arena.reset()
             self._fx = self._fx_arena if fx_gn else None
-        # the time-embedding chain (four latency-bound launches over two rows, 38 us) depends on the timestep alone and its first reader
-        # is the first ResNet's conv1: on a side stream it runs beside conv_in and the first GroupNorm (a fork / join the step's hipGraph
-        # records as a second branch).  SEER_TEMB_FORK=0 / a sharded engine: in line.
-        fork = self.temb_fork and self.shard is None and sample.is_cuda
-        if fork:
-            if self._side is None:
-                assert not torch.cuda.is_current_stream_capturing(), "the side stream must exist before a graph capture (eager warm-up first)"
-                self._side = torch.cuda.Stream(device=sample.device)
-            main = torch.cuda.current_stream(sample.device)
-            self._side.wait_stream(main)
-        with (torch.cuda.stream(self._side) if fork else contextlib.nullcontext()):
-            emb = ops.timestep_embedding(t, boc[0], self.cfg.flip_sin_to_cos, self.cfg.freq_shift)
-            emb = ops.linear_smallm(emb, w["time_embedding.linear_1.weight"], w["time_embedding.linear_1.bias"], silu_out=True)
-            emb = ops.linear_smallm(emb, w["time_embedding.linear_2.weight"], w["time_embedding.linear_2.bias"])
-            self._temb = ops.linear_smallm(emb, w["temb_all.w"], w["temb_all.b"], silu_in=True)
-        self._temb_join = (lambda: main.wait_stream(self._side)) if fork else None
+        emb = ops.timestep_embedding(t, boc[0], self.cfg.flip_sin_to_cos, self.cfg.freq_shift)
+        emb = ops.linear_smallm(emb, w["time_embedding.linear_1.weight"], w["time_embedding.linear_1.bias"], silu_out=True)
+        emb = ops.linear_smallm(emb, w["time_embedding.linear_2.weight"], w["time_embedding.linear_2.bias"])
+        self._temb = ops.linear_smallm(emb, w["temb_all.w"], w["temb_all.b"], silu_in=True)
+        # (on a side stream beside conv_in -- a fork / join in the step's graph -- this chain cost the step +0.35 ms:
+        #  profiles/r06_temb_fork_rejected.log)
 
         x = ops.conv_in(sample, w["conv_in.weight"], w["conv_in.bias"]) if self.dt == bf16 else \
             ops.conv_in(sample, w["conv_in.weight"], w["conv_in.bias"], dtype=self.dt)
