@@ -46,12 +46,16 @@ def test_engine_folds_layernorms_into_the_consuming_gemm(mini):
     275-277, 308-327 runs as one GEMM over the un-normalised rows and lands on the oracle like the layernorm form does"""
     sd, m = mini
     x, ctx, t = _randn((1, 4, 2, 16, 16), 1), _randn((1, 2, 77, 256), 2), torch.tensor([501])
-    eng = _Engine(m, ops=tob)
+    m.rowchain = False          # (the chains of ops.rowchain take norm1 / norm2 of 320-channel blocks: test_engine_runs_the_row_chains)
+    try:
+        eng = _Engine(m, ops=tob)
+        plain = _Engine(m, ops=tob, fold_ln=False)
+    finally:
+        del m.rowchain
     n_ln = sum(1 for k in sd if ".transformer_blocks." in k and k.endswith((".norm1.weight", ".norm2.weight", ".norm3.weight")))
     with torch.no_grad():
         got = eng.run(x, t, ctx, 0)
         assert eng.ln_fold and eng.ln_folded == n_ln == len(eng.wln), (eng.ln_folded, n_ln, len(eng.wln))
-        plain = _Engine(m, ops=tob, fold_ln=False)
         two = plain.run(x, t, ctx, 0)
         assert plain.ln_folded == 0
         ref = O.unet_forward(sd, CFG_MINI, x, t, ctx, cond_frame=0)
@@ -113,3 +117,29 @@ def test_engine_return_attn_matches_oracle(mini):
     for a, r in zip(attn, ref_attn):
         assert a.shape == r.shape and a.dtype == torch.float32
         assert ((a - r).norm() / r.norm()).item() < 3e-2
+
+
+@pytest.mark.parametrize("B,Fr,H,cond_frame", [(1, 2, 16, 0), (2, 3, 8, 1)])
+def test_engine_runs_the_row_chains(mini, B, Fr, H, cond_frame):
+    """host logic of the row-local chains (unet._Engine._rc_in, _chain_next; ops.rowchain): at 320 channels GroupNorm -> proj_in -> norm1
+    -> q|k|v (rotary on the temporal block's q and k, the q prescale) and attn1.to_out + residual -> norm2 -> attn2.to_q are one call
+    each -- the statistics come from the producers' accumulated sums (the producer of a chain's input accumulates whatever its size),
+    the residual stream is updated in place -- and the schedule lands on the oracle like the separate launches do"""
+    sd, m = mini
+    eng = _Engine(m, ops=tob)
+    assert eng.rowchain and any(k.endswith(".rc.proj_in") for k in eng.w)
+    x, ctx, t = _randn((B, 4, Fr, H, H), 1), _randn((B, Fr, 77, 256), 2), torch.tensor([501] * B)
+    with torch.no_grad():
+        got = eng.run(x, t, ctx, cond_frame)
+        # lpb = 1: 3 down + mid + 6 up attention sites, a text and a temporal block each; the text blocks run two chains.  At 8x8 the
+        # two lowest levels hold fewer than 96 rows per batch element: those sites keep the separate launches
+        sites = sum(1 for k in eng.w if k.endswith(".rc.proj_in"))
+        assert sites == 20 and 0 < eng.rowchains <= 30, eng.rowchains
+        m.rowchain = False
+        try:
+            sep = _Engine(m, ops=tob).run(x, t, ctx, cond_frame)
+        finally:
+            del m.rowchain
+        ref = O.unet_forward(sd, CFG_MINI, x, t, ctx, cond_frame=cond_frame)
+    e_chain, e_sep = ((got - ref).norm() / ref.norm()).item(), ((sep - ref).norm() / ref.norm()).item()
+    assert e_chain < 3e-2 and e_chain < 1.5 * e_sep + 1e-3, (e_chain, e_sep)

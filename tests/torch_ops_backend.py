@@ -123,6 +123,73 @@ def _gemm_tail(acc, bias, residual, rowvec, rows_per_batch, geglu, silu, out_f32
     return _epilogue(acc, bias, geglu, rowvec, rows_per_batch, silu, residual, out_f32, out)
 
 
+# ---- stand-in of ops.rowchain (seer_rowchain_c320): the row-local chains in front of the attention launches, one call -----------------
+ROWCHAIN_C, ROWCHAIN_ROWS = 320, 96
+ROWCHAIN_MIN_ROWS = 96         # the CPU tests' small shapes take the chain too (the product asks the device: ops.rowchain_pays)
+
+
+def rowchain_pack(w):
+    """the kernel reads its matrices in a fragment order; the stand-in keeps [n * 320, 320] (tagged: only rowchain() may read it)"""
+    assert w.dtype == bf16 and w.shape[1] == ROWCHAIN_C and w.shape[0] % ROWCHAIN_C == 0
+    p = w.clone()
+    p.rowchain_packed = True
+    return p
+
+
+def rowchain_pays(rows, n_cu=None, products=4):
+    return rows >= ROWCHAIN_MIN_ROWS
+
+
+def rowchain(inp, w1f, *, b1=None, gn=None, res=None, h_out=True, ln=None, w2f=None, out=None, col_scale=None, rotary=None):
+    assert getattr(w1f, "rowchain_packed", False) and inp.shape[1] == ROWCHAIN_C and inp.dtype == bf16
+    M = inp.shape[0]
+    x = inp.float()
+    if gn is not None:
+        stats, count, eps, gamma, beta, rows_pb = gn[:6]
+        if rows_pb < ROWCHAIN_ROWS:
+            return None                                                   # SEER_ENOSYS: a tile would span three batch elements
+        B = M // rows_pb
+        if isinstance(stats, ColSumsFx):
+            G = gn[6]
+            g = stats.buf.sum(0).reshape(B, 2, G, ROWCHAIN_C // G).sum(3).double() / FX_SCALE
+            mean, ex2 = (g[:, 0] / count).float(), (g[:, 1] / count)
+            var = (ex2 - (g[:, 0] / count) ** 2).clamp_min(0).float()
+        else:
+            G = stats.shape[1]
+            mean = stats[..., 0] / count
+            var = (stats[..., 1] / count - mean * mean).clamp_min(0)
+        sc = (torch.rsqrt(var + eps)[:, :, None] * gamma.reshape(G, -1)[None]).reshape(B, ROWCHAIN_C)        # per (batch element, channel)
+        sh = beta[None] - (mean[:, :, None].expand(-1, -1, ROWCHAIN_C // G).reshape(B, ROWCHAIN_C)) * sc
+        x = (x.reshape(B, rows_pb, ROWCHAIN_C) * sc[:, None] + sh[:, None]).reshape(M, ROWCHAIN_C).to(bf16).float()   # the tile is 16-bit
+    acc = _mm(x, w1f.float().t())
+    if b1 is not None:
+        acc = acc + b1
+    if res is not None:
+        acc = acc + res.float()
+    hq = acc.to(bf16)
+    h = None
+    if h_out is not False:
+        if h_out is True:
+            h = hq
+        else:
+            h_out.copy_(hq)
+            h = h_out
+        h.colsums = None
+        h.rowstats = None
+    o = None
+    if w2f is not None:
+        assert getattr(w2f, "rowchain_packed", False)
+        n2 = w2f.shape[0] // ROWCHAIN_C
+        t = hq.float()
+        if ln is not None:
+            t = F.layer_norm(t, (ROWCHAIN_C,), ln[0], ln[1], ln[2]).to(bf16).float()
+        acc2 = _mm(t, w2f.float().t())
+        rot = None if rotary is None else (rotary[0], rotary[1], rotary[2], rotary[3], rotary[4], rotary[5] * ROWCHAIN_C)
+        cs = None if col_scale is None else (col_scale[0], col_scale[1] * ROWCHAIN_C)
+        o = _gemm_tail(acc2, None, None, None, 0, False, False, False, out, rot, cs)
+    return h, o
+
+
 def gemm_batched(a, w, *, trans_out=False, out=None, bias=None, out_f32=False, tile=0, col_scale=None):
     acc = torch.einsum("bmk,bnk->bmn" if w.dim() == 3 else "bmk,nk->bmn", a.float(), w.float())
     if bias is not None:
