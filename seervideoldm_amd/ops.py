@@ -697,12 +697,15 @@ def rowchain_pays(rows: int, n_cu: Optional[int] = None, products: int = 4) -> b
     """a workgroup owns 96 rows for the whole launch (as ff_fused), so a launch takes rounds x ~30 us (four products) / ~20 us (two)
     whatever its rows: ahead of the launches it replaces where its workgroups fill the chip's rounds (scripts/lab_rowchain.py,
     profiles/r06_lab_rowchain.log: GroupNorm -> proj_in -> norm1 -> q|k|v 24 576 rows 35.9 against 54.4 us, 12 288 rows 31.6 / 35.0,
-    6 144 rows 30.7 / 23.3; to_out + residual -> norm2 -> to_q 26.0 / 27.5, 21.2 / 19.3, 20.5 / 15.1)"""
+    6 144 rows 30.7 / 23.3; to_out + residual -> norm2 -> to_q 24.5 / 27.3, 21.2 / 19.3, 20.5 / 15.1); 28 672 rows (config 2 at 14
+    frames) are 299 workgroups -- a second round for 43 of them: not taken"""
     if n_cu is None:
         n_cu = device_cus()
     wgs = -(-rows // ROWCHAIN_ROWS)
     fill = wgs / (n_cu * -(-wgs // n_cu))
-    return (rows >= 12288 and fill >= 0.49) if products >= 4 else (rows >= 18432 and fill >= 0.74)
+    if products >= 4 and wgs <= n_cu:
+        return rows >= 12288          # one round: ahead from half the chip's workgroups up
+    return rows >= 18432 and fill >= 0.74      # several rounds cost rounds x ~33 us whatever the last one holds (as ff_fused_pays)
 
 
 def rowchain(inp: torch.Tensor, w1f: torch.Tensor, *, b1: Optional[torch.Tensor] = None, gn=None, res: Optional[torch.Tensor] = None,

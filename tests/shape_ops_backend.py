@@ -77,7 +77,9 @@ def rowchain_pack(w):
 def rowchain_pays(rows, n_cu=256, products=4):
     wgs = -(-rows // ROWCHAIN_ROWS)
     fill = wgs / (n_cu * -(-wgs // n_cu))
-    return (rows >= 12288 and fill >= 0.49) if products >= 4 else (rows >= 18432 and fill >= 0.74)
+    if products >= 4 and wgs <= n_cu:
+        return rows >= 12288
+    return rows >= 18432 and fill >= 0.74
 
 
 def rowchain(inp, w1f, *, b1=None, gn=None, res=None, h_out=True, ln=None, w2f=None, out=None, col_scale=None, rotary=None):

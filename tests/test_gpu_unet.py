@@ -511,6 +511,28 @@ def test_full_size_step_fp16_storage_matches_the_reference(device):
         (eng.gn_from_colsums, eng.ln_folded, eng.rowchains)
 
 
+@pytest.mark.parametrize("name,shape,seeds,cond", [("unet_full_F14.npz", (2, 4, 14, 32, 32), (51, 52), 2), ("unet_full_F17.npz", (2, 4, 17, 32, 32), (51, 52), 1),
+                                                   ("unet_full_64.npz", (2, 4, 2, 64, 64), (1, 2), 0)])
+def test_fp16_storage_on_the_other_full_size_fixtures(device, name, shape, seeds, cond):
+    """the fp16-storage engine on the reference-made fixtures of the other regimes -- 14 / 17 frames (ragged key tiles of the temporal
+    windows; rows per batch element that are no multiple of a chain's 96-row tile), the 64x64 latent (4096-token spatial attention on
+    the generic kernel, windowed mid block) -- to the fp16 calibration"""
+    if "full16" not in _cache:
+        cfg = dict(synth.SD15_UNET_CFG)
+        m16 = SeerUNet(**cfg, compute_dtype=torch.float16).to(device)
+        m16.load_state_dict(synth.synth_state_dict(synth.unet_param_shapes(cfg), device=device), strict=True)
+        _cache["full16"] = m16.eval()
+    m = _cache["full16"]
+    x, ctx = _randn(shape, seeds[0]), _randn((shape[0], shape[2], 77, 768), seeds[1])
+    g = _full_fixture(name, x, ctx)
+    t = torch.from_numpy(g["timestep"])
+    got = m(x.to(device), t.to(device), ctx.to(device), cond_frame=cond)
+    ref = torch.from_numpy(g["y"])
+    rel = _rel(got, ref)
+    print(f"[parity] {name}, fp16 storage: rel_l2={rel:.4g} (bound {REL_L2_F16:.3g})")
+    assert m._engine.dt == torch.float16 and torch.isfinite(got).all() and rel <= REL_L2_F16, rel
+
+
 def test_autocast_selects_the_storage_type(device):
     """`accelerator.prepare(sunet, ...)` under mixed_precision "fp16" wraps forward in torch.autocast(dtype=float16)
     (inference_img.py:93 with the shipped yaml): the engine then stores fp16; under bf16 autocast, or none, bf16"""
