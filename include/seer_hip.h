@@ -257,8 +257,9 @@ typedef struct seer_attn_desc {
  * bf16 rounding of q) and the generic kernel scales the fp32 scores. */
 #define SEER_ATTN_Q_PRESCALED 1u
 /* Q, K, V and O hold IEEE half (fp16) instead of bf16 -- the UNet engine under fp16 autocast (every reference yaml ships
- * mixed_precision: "fp16").  fp32 scores, statistics and accumulation as always; P is rounded to fp16 for the PV product.  Runs the
- * generic kernel at every head dim (variant 0 or 1; no lse: inference only). */
+ * mixed_precision: "fp16").  fp32 scores, statistics and accumulation as always; P is rounded to fp16 for the PV product.  head_dim 40
+ * from 256 keys up runs the d = 40 kernel's TRACKED form (its fast path needs bf16's exponent range), everything else the generic
+ * kernel (variant 0, 1 or 5; no lse: inference only). */
 #define SEER_ATTN_F16 2u
 
 int seer_attn_fwd(const seer_attn_desc* desc /* host */, void* stream);

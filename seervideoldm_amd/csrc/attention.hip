@@ -88,18 +88,6 @@ struct TokMap {
 // F16 (SEER_ATTN_F16): Q, K, V and O hold IEEE half instead of bf16 -- the same 16-bit loads, LDS images and transposed reads (the
 // bf16 vector types below are containers of bits); only the MFMA opcode, the constant 1.0 of the denominator column, the conversion
 // of P and the output pack differ.  P <= 2^defer_thr = 16 is far inside the half range; probabilities below 6e-8 flush to zero.
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
-template <bool F16>
-__device__ __forceinline__ f32x16 mma32(const bf16x8& a, const bf16x8& b, const f32x16& c) {
-    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
-    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-template <bool F16>
-__device__ __forceinline__ bf16 to16(float v) {      // the 16-bit storage value of v, in a bf16-typed container
-    if constexpr (F16) return __builtin_bit_cast(bf16, (_Float16)v);
-    else return (bf16)v;
-}
-
 template <int D, bool DBUF, bool F16 = false>
 __global__ void __launch_bounds__(256) seer_attn_kernel(const seer_attn_desc p, const int ws_log2, const float defer_thr) {
     using C = AttnCfg<D>;
@@ -451,10 +439,13 @@ extern "C" int seer_attn_fwd(const seer_attn_desc* desc, void* stream) {
     if (d.variant < 0 || d.variant > 7 || d.variant == 4) return SEER_EINVAL;
     if ((d.variant == 2 || d.variant == 3 || d.variant == 5 || d.variant == 7) && d.head_dim != 40) return SEER_EINVAL;
     if (d.causal_offset < 0 || (d.causal && d.Sq + d.causal_offset > d.Sk)) return SEER_EINVAL;
-    if ((d.flags & SEER_ATTN_F16) && (d.lse || (d.variant != 0 && d.variant != 1))) return SEER_EINVAL;      // inference, generic kernel
+    if ((d.flags & SEER_ATTN_F16) && (d.lse || (d.variant != 0 && d.variant != 1 && d.variant != 5))) return SEER_EINVAL;      // inference
     switch (d.head_dim) {
         case 40:
-            if (d.flags & SEER_ATTN_F16) return launch_attn<40>(d, ws_log2, st);          // (the d = 40 kernel is bf16 only)
+            // IEEE-half operands: the d = 40 kernel's TRACKED form from 256 keys up (its fast path lives off bf16's exponent range),
+            // the generic kernel below that and for variant 1
+            if (d.flags & SEER_ATTN_F16)
+                return (d.variant == 1 || (d.variant == 0 && d.Sk < 256)) ? launch_attn<40>(d, ws_log2, st) : seer_attn40_launch(d, ws_log2, st);
             // the d = 40 kernel pays ~3 us of set-up (constant region, LDS-DMA plan, reference pre-pass) that short key
             // sequences do not earn back (text cross-attention, Sk = 77: 18.7 vs 16.6 us, profiles/r02_attn40_variants.log)
             if (d.variant == 1 || d.variant == 6 || (d.variant == 0 && d.Sk < 256)) return launch_attn<40>(d, ws_log2, st);

@@ -41,6 +41,7 @@ constexpr int A40_STAGE = 2 * A40_HALF;             // 20480
 constexpr int A40_ZBYTES = 1472;                    // constant region: zeros with bf16 1.0 at bytes 0, 160, 1280, 1440
 constexpr float A40_NEG_INF = -__builtin_inff();
 constexpr float A40_THR = 16.0f;                    // TRACK: re-base when a score exceeds the reference by 2^16
+constexpr float A40_THR_F16 = 14.0f;                // ... by 2^14 on IEEE-half operands (P <= 2^14: the half range ends at 2^16)
 
 struct TokMap40 {
     int ws_log2;   // -1: identity
@@ -55,6 +56,20 @@ struct TokMap40 {
     }
 };
 
+// a half-representable value >= x, at most one half ulp above it (x finite, |x| < 60000): the softmax reference of the half form
+__device__ __forceinline__ float f16_ceil(float x) {
+    x = fminf(fmaxf(x, -60000.f), 60000.f);
+    if (x > 0.f && x < 6.2e-5f) return 6.103515625e-5f;
+    if (x <= 0.f && x > -6.2e-5f) return 0.f;
+    _Float16 h = (_Float16)x;
+    float f = (float)h;
+    if (f < x) {
+        unsigned short b = __builtin_bit_cast(unsigned short, h);
+        b = (b & 0x8000u) ? (unsigned short)(b - 1) : (unsigned short)(b + 1);
+        f = (float)__builtin_bit_cast(_Float16, b);
+    }
+    return f;
+}
 // smallest bf16-representable value >= x (x finite)
 __device__ __forceinline__ float bf16_ceil(float x) {
     unsigned u = __builtin_bit_cast(unsigned, x);
@@ -193,10 +208,13 @@ extern "C" long long* seer_lab_a40_stamps() {
 // waited for with vmcnt(0) at the top of the next tile.  3 (ring): tile t + 2 is requested DURING tile t, one piece per sub tile behind
 // the sub tile's Q K^T MFMAs, and the top of a tile waits only for ITS pieces (vmcnt(5): the next tile's five stay in flight) -- the
 // per-tile wait + barrier + issue burst was a third of a tile period (profiles/r02_attn40_stamps.log).
-template <int QB, bool TRACK_ONLY, bool PLAIN, int NST = 2>
+// F16 (SEER_ATTN_F16): IEEE-half operands.  Only the TRACKED form exists there: the fast path fixes its reference after 32 keys and lives
+// off bf16's 8 exponent bits (P up to 2^127); with the reference tracked P <= 2^14 fits the half range.
+template <int QB, bool TRACK_ONLY, bool PLAIN, int NST = 2, bool F16 = false>
 __global__ void __launch_bounds__(256, (QB == 1 && NST == 2) ? 3 : 2) seer_attn40_kernel(const seer_attn_desc p, const int ws_log2_arg, const int nqb) {
     const int ws_log2 = PLAIN ? -1 : ws_log2_arg;
     const bool causal = PLAIN ? false : (p.causal != 0);
+    static_assert(!F16 || TRACK_ONLY, "IEEE-half operands: the tracked form only");
     constexpr int D = A40_D;
     constexpr int QW = 32 * QB;                      // queries per wave
     // NST K|V stages + the constant region
@@ -249,7 +267,7 @@ __global__ void __launch_bounds__(256, (QB == 1 && NST == 2) ? 3 : 2) seer_attn4
     //      V' columns 44.. = zeros = zreg + 8 (+160, ...).
     for (int i = tid; i < A40_ZBYTES / 4; i += 256) {
         const int off = i * 4;
-        reinterpret_cast<unsigned*>(zreg)[i] = (off == 0 || off == 160 || off == 1280 || off == 1440) ? 0x3f80u : 0u;
+        reinterpret_cast<unsigned*>(zreg)[i] = (off == 0 || off == 160 || off == 1280 || off == 1440) ? (F16 ? 0x3c00u : 0x3f80u) : 0u;
     }
     const unsigned ZONE = lds_addr(zreg);
 
@@ -337,10 +355,10 @@ __global__ void __launch_bounds__(256, (QB == 1 && NST == 2) ? 3 : 2) seer_attn4
                 u32x4 raw = qraw[qb][s];
                 if (s == 2 && lh) raw = u32x4{0u, 0u, 0u, 0u};
                 float f[8];
-                unpack8(raw, f);
+                unpack8t<F16>(raw, f);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) f[j] *= cscale;
-                const u32x4 scaled = pack8(f);
+                const u32x4 scaled = pack8t<F16>(f);
                 qf[qb][s] = __builtin_bit_cast(bf16x8, pre ? raw : scaled);
             }
         start_stream_2();
@@ -366,9 +384,9 @@ __global__ void __launch_bounds__(256, (QB == 1 && NST == 2) ? 3 : 2) seer_attn4
         lds_read_k3(kp, lh ? ZONE : kp + 64, kf[0], kf[1], kf[2]);
     };
     auto qk = [&](const bf16x8 (&kf)[3], int qb) {
-        f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[qb][0], zero16, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[qb][1], s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2], qf[qb][2], s, 0, 0, 0);
+        f32x16 s = mma32<F16>(kf[0], qf[qb][0], zero16);
+        s = mma32<F16>(kf[1], qf[qb][1], s);
+        s = mma32<F16>(kf[2], qf[qb][2], s);
         return s;
     };
     auto mask_scores = [&](f32x16& s, int kb, int qb) {
@@ -382,7 +400,7 @@ __global__ void __launch_bounds__(256, (QB == 1 && NST == 2) ? 3 : 2) seer_attn4
     };
     auto set_ref = [&](int qb, float m) {            // the reference rides in Q' column 40 (lanes of the upper half)
         m_run[qb] = m;
-        if (lh) qf[qb][2][0] = (bf16)(-m);
+        if (lh) qf[qb][2][0] = to16<F16>(-m);
     };
 
     // one pass over the keys; `track` selects the reference handling and the rounding of P.
@@ -435,7 +453,7 @@ __global__ void __launch_bounds__(256, (QB == 1 && NST == 2) ? 3 : 2) seer_attn4
 #pragma unroll
                     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
                     mx = xhalf_max40(mx);
-                    set_ref(qb, mx == A40_NEG_INF ? 0.f : bf16_ceil(mx));
+                    set_ref(qb, mx == A40_NEG_INF ? 0.f : (F16 ? f16_ceil(mx) : bf16_ceil(mx)));
                 }
             }
 
@@ -537,8 +555,9 @@ __global__ void __launch_bounds__(256, (QB == 1 && NST == 2) ? 3 : 2) seer_attn4
 #pragma unroll
                         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
                         mx = xhalf_max40(mx);
-                        if (!__all(mx <= A40_THR)) {
-                            const float m_new = mx > A40_THR ? bf16_ceil(m_run[qb] + mx) : m_run[qb];
+                        constexpr float THR = F16 ? A40_THR_F16 : A40_THR;
+                        if (!__all(mx <= THR)) {
+                            const float m_new = mx > THR ? (F16 ? f16_ceil(m_run[qb] + mx) : bf16_ceil(m_run[qb] + mx)) : m_run[qb];
                             const float delta = m_new - m_run[qb];
                             const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
@@ -556,7 +575,7 @@ __global__ void __launch_bounds__(256, (QB == 1 && NST == 2) ? 3 : 2) seer_attn4
                     for (int i = 0; i < 8; ++i) {
                         const float e0 = __builtin_amdgcn_exp2f(s[2 * i]), e1 = __builtin_amdgcn_exp2f(s[2 * i + 1]);
                         if constexpr (TRACK)
-                            pk[i >> 2][i & 3] = pack2(e0, e1);
+                            pk[i >> 2][i & 3] = pack2t<F16>(e0, e1);
                         else        // truncation: {e1[31:16], e0[31:16]}
                             pk[i >> 2][i & 3] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, e1),
                                                                       __builtin_bit_cast(unsigned, e0), 0x07060302u);
@@ -564,8 +583,8 @@ __global__ void __launch_bounds__(256, (QB == 1 && NST == 2) ? 3 : 2) seer_attn4
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2) {
                         const bf16x8 pb = __builtin_bit_cast(bf16x8, pk[s2]);
-                        oacc[qb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s2][0], pb, oacc[qb][0], 0, 0, 0);
-                        oacc[qb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s2][1], pb, oacc[qb][1], 0, 0, 0);
+                        oacc[qb][0] = mma32<F16>(vf[s2][0], pb, oacc[qb][0]);
+                        oacc[qb][1] = mma32<F16>(vf[s2][1], pb, oacc[qb][1]);
                     }
                 }
                 A40_STAMP();
@@ -628,8 +647,8 @@ __global__ void __launch_bounds__(256, (QB == 1 && NST == 2) ? 3 : 2) seer_attn4
             const f32x16& o = oacc[qb][g >> 2];
             const int r0 = 4 * (g & 3);
             u32x2 w;
-            w[0] = pack2(o[r0] * inv, o[r0 + 1] * inv);
-            w[1] = pack2(o[r0 + 2] * inv, o[r0 + 3] * inv);
+            w[0] = pack2t<F16>(o[r0] * inv, o[r0 + 1] * inv);
+            w[1] = pack2t<F16>(o[r0 + 2] * inv, o[r0 + 3] * inv);
             *reinterpret_cast<u32x2*>(orow + 16 * g) = w;
         }
     }
@@ -665,6 +684,14 @@ int seer_attn40_launch(const seer_attn_desc& d, int ws_log2, hipStream_t st) {
     }
     const bool track = d.variant == 5 || d.lse != nullptr;
     const bool plain = ws_log2 < 0 && !d.causal && d.causal_offset == 0;
+    if (d.flags & SEER_ATTN_F16) {          // IEEE-half operands: the tracked form (32 queries per wave), nothing else
+        const int nqbh = (d.Sq + 127) / 128;
+        dim3 gridh((unsigned)(nqbh * nbatch * d.heads));
+        if (plain) hipLaunchKernelGGL((seer_attn40_kernel<1, true, true, 2, true>), gridh, dim3(256), 0, st, d, ws_log2, nqbh);
+        else hipLaunchKernelGGL((seer_attn40_kernel<1, true, false, 2, true>), gridh, dim3(256), 0, st, d, ws_log2, nqbh);
+        SEER_LAUNCH_CHECK();
+        return SEER_OK;
+    }
     // 64 queries per wave: K / V fragments, LDS-DMA issue and barriers are shared by two query blocks, and the two blocks are
     // software-pipelined (both Q K^T chains first, then block 0's exponentials under block 1's chain, block 0's P V under block
     // 1's exponentials); 240 registers, two waves per SIMD.  [192, 1024, 40]: 53.2 vs 56.3 us, [192, 4096, 40]: 582 vs 643 us
