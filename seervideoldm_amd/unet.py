@@ -477,16 +477,17 @@ class _Engine:
         the statistics launch in front of it goes too (the apply launch that made the accumulated form lose at the 32x32 level is
         not run at all there)"""
         ops = self.ops
-        return bool(self.rowchain and self.shard is None and self._fx is not None and C == getattr(ops, "ROWCHAIN_C", -1) and
+        return bool(self.rowchain and (self.shard is None or not self.shard.exact_stats) and self._fx is not None and
+                    C == getattr(ops, "ROWCHAIN_C", -1) and
                     rows_pb >= ops.ROWCHAIN_ROWS and ops.rowchain_pays(B * rows_pb))
 
     def _gn_stats(self, x, B, rows_pb):
         """(statistics, count) of the GroupNorm over x alone, for a launch that applies the normalisation itself (ops.rowchain): the
         producer's accumulated fixed-point sums as they are, else stats [B, G, 2] from its per-tile column sums or from a pass over x.
-        None: a sharded engine -- the caller keeps the separate launches."""
+        None: a frame-sharded engine -- the caller keeps the separate launches (batch groups alone run the single-process forms)."""
         ops = self.ops
         cs = getattr(x, "colsums", None)
-        if self.shard is not None:
+        if self.shard is not None and self.shard.exact_stats:      # frame shards exchange the statistics between the two steps
             return None
         if isinstance(cs, getattr(ops, "ColSumsFx", ())):
             self.gn_from_colsums += 1
