@@ -331,16 +331,35 @@ class SeerTrainer:
         lse2 = tops.attn_lse_buffer(B * Fr, heads, HW, x.device)
         ops.attention(q2, kv[:, :C], kv[:, C:], a2, lse=lse2, **kw2)
         h2 = ops.gemm(a2, w[tb + ".attn2.to_out.0.weight"], bias=w[tb + ".attn2.to_out.0.bias"], residual=h1)
-        h3, sff = self._ff_fwd(None, w, self._unet_ff_names(tb), h2)
-        out = ops.gemm(h3, w[p + ".proj_out.weight"], bias=w[p + ".proj_out.bias"], residual=x, colsum_batch=self._cb(B))
+        if (p + ".ffproj.w") in w:
+            # the text blocks are frozen: ff.net.2 and proj_out as ONE two-source GEMM over [h2 | g] (the engine's folded pair,
+            # unet._Engine._pack: x + [Wp | Wp W2] [h2 | g] + (Wp b2 + bp)) -- the backward needs neither h3 nor their weights apart
+            g3, b3, w1, b1, _, _ = self._unet_ff_names(tb)
+            n3 = ops.layernorm(h2, w[g3], w[b3])
+            pre = ops.gemm(n3, w[w1], bias=w[b1])
+            g = tops.geglu_fwd(pre)
+            out = ops.gemm(h2, w[p + ".ffproj.w"], a2=g, bias=w[p + ".ffproj.b"], residual=x, colsum_batch=self._cb(B))
+            sff = (h2, n3, pre)
+        else:
+            h3, sff = self._ff_fwd(None, w, self._unet_ff_names(tb), h2)
+            out = ops.gemm(h3, w[p + ".proj_out.weight"], bias=w[p + ".proj_out.bias"], residual=x, colsum_batch=self._cb(B))
         return out, (p, C, sg, h0, qkv, a1, lse1, kw1, h1, q2, kv, a2, lse2, kw2, sff)
 
     def _text_bwd(self, saved, dout, stop_after_kv=False):
         ops, tops, w = self.ops, self.tops, self.w
         p, C, sg, h0, qkv, a1, lse1, kw1, h1, q2, kv, a2, lse2, kw2, sff = saved
         tb = p + ".transformer_blocks.0"
-        dh3 = self._lin_bwd(None, w, p + ".proj_out.weight", None, None, dout)
-        dh2 = self._ff_bwd(None, w, self._unet_ff_names(tb), sff, dh3)
+        if (p + ".ffproj.w") in w:
+            # [d h3 | d g] = dout [Wp | Wp W2]: the two input gradients of the folded pair from ONE GEMM
+            g3, _, w1, _, _, _ = self._unet_ff_names(tb)
+            hf, n3, pre = sff
+            both = ops.gemm(dout, self._frozenT(p + ".ffproj.w"))
+            dpre = tops.geglu_bwd(pre, both[:, C:])
+            dn3 = self._lin_bwd(None, w, w1, None, None, dpre)
+            dh2 = tops.layernorm_bwd(hf, dn3, w[g3], dres=both[:, :C])
+        else:
+            dh3 = self._lin_bwd(None, w, p + ".proj_out.weight", None, None, dout)
+            dh2 = self._ff_bwd(None, w, self._unet_ff_names(tb), sff, dh3)
         # text cross attention: dK|dV go straight into this block's column range of the shared [B*F*L, sum 2C] buffer
         da2 = self._lin_bwd(None, w, tb + ".attn2.to_out.0.weight", None, None, dh2)
         c0 = self._kv_cols[tb]
