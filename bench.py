@@ -16,7 +16,8 @@ units, no data-path collective; linear by construction) is timed in the same run
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel class (the MFMA GEMM / implicit-GEMM conv template,
 93 % of the step's FLOPs) from HIP-event timings taken inside this process; `cpu_baseline` times the CPU oracle
-(oracle/seer_oracle.py, a port of the reference algorithm) on the host cores on a bounded sample.
+(oracle/seer_oracle.py, a port of the reference algorithm) on the host cores: one warm-up + three timed FULL steps.
+`python bench.py --gpus N` without a launcher starts its N ranks itself; `--dtype fp16` times the fp16-storage engine (an extra).
 """
 from __future__ import annotations
 
