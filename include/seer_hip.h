@@ -391,6 +391,13 @@ int seer_rowchain_c320(const seer_rowchain_desc* desc /* host */, void* stream);
 /* n_mats 320 x 320 matrices -- rows 320 t .. 320 t + 319 of W [n_mats * 320][ld], 16-bit elements -- into the kernel's fragment order:
  * out[t][K step 5][wave 4][k32 2][column fragment 5][lane 64][8], element W[320 t + 80 w + 16 j + (lane & 15)][64 s + 32 k32 + 8 (lane >> 4) + e] */
 int seer_rowchain_pack(const void* W, int32_t ld, int32_t n_mats, void* out, void* stream);
+/* ... with a prologue: the rows the launch reads as h are  h + a Wo^T + bo  -- the attention's to_out projection and its residual
+ * (seer/models/attention.py:237-240, 316-322), computed in the tile and stored nowhere (this launch is their only reader).  a [M][320]
+ * (row stride lda), wof = Wo [320][320] in the fragment order of seer_rowchain_pack, bo [320] fp32; a == NULL: no prologue. */
+int seer_ff_fused_c320_pre(const void* a, int32_t lda, const void* wof, const float* bo, const void* h, int32_t ldh, const void* x,
+                           int32_t ldx, void* y, int32_t ldy, int64_t M, const float* gamma, const float* beta, float eps,
+                           const void* w1f, const float* b1, const void* wcf, const float* bcat, int64_t* colsum_fx, int64_t fx_rows,
+                           int32_t fx_reps, float* colsum_tiles, int32_t dtype, void* stream);
 /* w1 [2560][320] bf16 -> out (same size): [chunk 20][wave 4][K step 5][k32 2][value | gate][lane 64][8 bf16], element
  * w1[128 c + 32 w + 16 f + (lane & 15)][64 ks + 32 k32 + 8 (lane >> 4) + e]: every fragment load of the kernel is one contiguous KiB */
 int seer_ff_fused_pack_w1(const void* w1, void* out, void* stream);

@@ -13,7 +13,7 @@ _PKG = Path(__file__).resolve().parent
 _LIB_PATH = _PKG / "lib" / "libseer_hip.so"
 _lib = None
 
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 SEER_GEMM_PLAIN = 0
 SEER_GEMM_CONV3X3 = 1
@@ -131,6 +131,8 @@ SIGNATURES = {
                               C.c_int),
     "seer_rowchain_c320": ([C.POINTER(RowChainDesc), _vp], C.c_int),
     "seer_rowchain_pack": ([_vp, _i32, _i32, _vp, _vp], C.c_int),
+    "seer_ff_fused_c320_pre": ([_vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _i64, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _i64, _i32,
+                                _vp, _i32, _vp], C.c_int),
     "seer_ff_fused_pack_w1": ([_vp, _vp, _vp], C.c_int),
     "seer_ff_fused_pack_wcat": ([_vp, _vp, _vp], C.c_int),
     "seer_gemm_colsum_fx_layout": ([C.POINTER(GemmDesc), _i32, C.POINTER(C.c_int32)], C.c_int32),

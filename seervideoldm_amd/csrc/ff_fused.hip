@@ -74,6 +74,9 @@ struct FfArgs {
     int64_t* colsum_fx;                     // [reps][M / fx_rows][2][FF_C] fixed-point column sums (seer_gemm_desc::colsum_fx) or NULL
     int fx_rows, fx_reps;                   // rows per batch element (a multiple of 16, at least 96), replicas
     float* colsum_tiles;                    // [M / 96][FF_C][2] fp32 per-tile column sums (seer_gemm_desc::colsum) or NULL
+    // optional prologue (seer_ff_fused_c320_pre): the rows of `h` are h = h + a Wo^T + bo first -- the attention's to_out projection and
+    // its residual (attention.py:316-322, 237-240), whose output nobody but this launch reads
+    const bf16* a; int lda; const unsigned char* wof; const float* bo;
 };
 
 __device__ __forceinline__ unsigned lds_u32(const void* ptr) {
@@ -146,7 +149,7 @@ __device__ __forceinline__ bf16x8 as_bf(const u32x4& v) { return __builtin_bit_c
 
 // F16: h, x, y and both weight matrices hold IEEE half (the fp16 engine): same loads, LDS images and schedule; the MFMA opcode and
 // the pack / unpack of LayerNorm, GEGLU, residual and column sums differ
-template <bool F16>
+template <bool F16, bool PRE = false>
 __global__ void __launch_bounds__(256, 1) seer_ff_fused_c320_kernel(const FfArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const T = smem;
@@ -205,22 +208,10 @@ __global__ void __launch_bounds__(256, 1) seer_ff_fused_c320_kernel(const FfArgs
             for (int j = 0; j < 5; ++j) Y[i][j] = mma16<F16>(as_bf(w5[j]), as_bf(a.r[i]), Y[i][j]);
     };
 
-    // ================= phase 0: the tile of h; gamma, beta, b1 into LDS; Y = h Wp^T (K steps 0..4 of [Wp | Wp W2]) =================
-    // the first two K steps of the stream are requested before anything else
-    load_tile(p.h, p.ldh);
+    // Y += T W^T for five K steps of a fragment-packed matrix whose steps 0 and 1 are requested (wcr, s1); every wait a count of the
+    // requests issued behind the one waited for
     W10 s1;
-    req10(wcr, voff, wc_wave + 0 * 4 * FF_WC_BLOCK);
-    req10(s1, voff, wc_wave + 1 * 4 * FF_WC_BLOCK);
-    for (int i = tid; i < (2 * FF_C + 2 * FF_INNER) / 4; i += 256) {
-        const f32x4* src = i < FF_C / 4 ? reinterpret_cast<const f32x4*>(p.gamma) + i
-                           : i < FF_C / 2 ? reinterpret_cast<const f32x4*>(p.beta) + (i - FF_C / 4)
-                                          : reinterpret_cast<const f32x4*>(p.b1) + (i - FF_C / 2);
-        reinterpret_cast<f32x4*>(cst)[i] = *src;
-    }
-    wait_vm<0>();                           // this wave's pieces of the tile (and S0, S1) are in
-    __syncthreads();                        // T and the constants complete
-    FF_STAMP();                             // 1
-    {
+    auto prod5 = [&](const unsigned char* wbase) {
         AFrag a0, a1;
         // sub step (s, k32) of K step s reads panel s; the next sub step's fragments are requested before this one's MFMAs
         a_req(a0, T0 + fo0);
@@ -230,22 +221,75 @@ __global__ void __launch_bounds__(256, 1) seer_ff_fused_c320_kernel(const FfArgs
         // S0 (wcr)
         a_req(a1, T0 + fo1);                             mfma_y(&wcr.r[0], a0); a_got(a1);
         a_req(a0, T0 + FF_PANEL + fo0);                  mfma_y(&wcr.r[5], a1); a_got(a0);
-        req10(wcr, voff, wc_wave + 2 * 4 * FF_WC_BLOCK);                        // S2 -> wcr
+        req10(wcr, voff, wbase + 2 * 4 * FF_WC_BLOCK);                          // S2 -> wcr
         // S1
         a_req(a1, T0 + FF_PANEL + fo1);                  mfma_y(&s1.r[0], a0);  a_got(a1);
         a_req(a0, T0 + 2 * FF_PANEL + fo0);              mfma_y(&s1.r[5], a1);  a_got(a0);
-        req10(s1, voff, wc_wave + 3 * 4 * FF_WC_BLOCK);                         // S3 -> s1; behind S2: S3
+        req10(s1, voff, wbase + 3 * 4 * FF_WC_BLOCK);                           // S3 -> s1; behind S2: S3
         // S2
         a_req(a1, T0 + 2 * FF_PANEL + fo1); got10<10>(wcr); mfma_y(&wcr.r[0], a0); a_got(a1);
         a_req(a0, T0 + 3 * FF_PANEL + fo0);              mfma_y(&wcr.r[5], a1); a_got(a0);
-        req10(wcr, voff, wc_wave + 4 * 4 * FF_WC_BLOCK);                        // S4 -> wcr; behind S3: S4
+        req10(wcr, voff, wbase + 4 * 4 * FF_WC_BLOCK);                          // S4 -> wcr; behind S3: S4
         // S3
         a_req(a1, T0 + 3 * FF_PANEL + fo1); got10<10>(s1); mfma_y(&s1.r[0], a0); a_got(a1);
         a_req(a0, T0 + 4 * FF_PANEL + fo0);              mfma_y(&s1.r[5], a1);  a_got(a0);
         // S4
         a_req(a1, T0 + 4 * FF_PANEL + fo1); got10<0>(wcr); mfma_y(&wcr.r[0], a0); a_got(a1);
         mfma_y(&wcr.r[5], a1);
+    };
+
+    if constexpr (PRE) {
+        // ================= prologue: h <- h + a Wo^T + bo, through T (nothing of it is stored: this launch is its only reader) =========
+        // the residual quads of this lane (row 16 i + frow, columns 80 w + 16 j + 4 fq ..) ride in registers under the product
+        load_tile(p.a, p.lda);
+        const unsigned char* const wo_wave = p.wof + (int64_t)wave * FF_WC_BLOCK;
+        req10(wcr, voff, wo_wave + 0 * 4 * FF_WC_BLOCK);
+        req10(s1, voff, wo_wave + 1 * 4 * FF_WC_BLOCK);
+        u32x2 rq[6][5];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int m = min(m0 + 16 * i + frow, p.M - 1);
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+                rq[i][j] = *reinterpret_cast<const u32x2*>(p.h + (int64_t)m * p.ldh + 80 * wave + 16 * j + 4 * fq);
+        }
+        wait_vm<0>();
+        __syncthreads();                    // the tile of a complete
+        prod5(wo_wave);
+        barrier_lds();                      // every wave has finished reading a
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int n = 80 * wave + 16 * j + 4 * fq;
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bo + n);
+            const int pnl = n >> 6, ch = (n & 63) >> 3;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int row = 16 * i + frow;
+                const f32x2 r01 = unpack2t<F16>(rq[i][j][0]), r23 = unpack2t<F16>(rq[i][j][1]);
+                u32x2 o;
+                o[0] = pack2t<F16>(Y[i][j][0] + bb[0] + r01[0], Y[i][j][1] + bb[1] + r01[1]);
+                o[1] = pack2t<F16>(Y[i][j][2] + bb[2] + r23[0], Y[i][j][3] + bb[3] + r23[1]);
+                *reinterpret_cast<u32x2*>(T + pnl * FF_PANEL + row * 128 + ((ch ^ (row & 7)) * 16) + (n & 7) * 2) = o;
+                Y[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
     }
+
+    // ================= phase 0: the tile of h; gamma, beta, b1 into LDS; Y = h Wp^T (K steps 0..4 of [Wp | Wp W2]) =================
+    // the first two K steps of the stream are requested before anything else
+    if constexpr (!PRE) load_tile(p.h, p.ldh);
+    req10(wcr, voff, wc_wave + 0 * 4 * FF_WC_BLOCK);
+    req10(s1, voff, wc_wave + 1 * 4 * FF_WC_BLOCK);
+    for (int i = tid; i < (2 * FF_C + 2 * FF_INNER) / 4; i += 256) {
+        const f32x4* src = i < FF_C / 4 ? reinterpret_cast<const f32x4*>(p.gamma) + i
+                           : i < FF_C / 2 ? reinterpret_cast<const f32x4*>(p.beta) + (i - FF_C / 4)
+                                          : reinterpret_cast<const f32x4*>(p.b1) + (i - FF_C / 2);
+        reinterpret_cast<f32x4*>(cst)[i] = *src;
+    }
+    wait_vm<0>();                           // this wave's pieces of the tile (and S0, S1) are in
+    __syncthreads();                        // T (PRE: the rows of h written above) and the constants complete
+    FF_STAMP();                             // 1
+    prod5(wc_wave);
     // chunk 0's W1 fragments (its slice of [Wp | Wp W2] follows behind H(0), as in every iteration)
 #pragma unroll
     for (int ks = 0; ks < FF_KS; ++ks) req4(w1r[ks], voff, w1_wave + ks * 4096);
@@ -588,6 +632,15 @@ extern "C" int seer_ff_fused_c320_dt(const void* h, int32_t ldh, const void* x, 
                                      const float* gamma, const float* beta, float eps, const void* w1f, const float* b1, const void* wcf,
                                      const float* bcat, int64_t* colsum_fx, int64_t fx_rows, int32_t fx_reps, float* colsum_tiles,
                                      int32_t dtype, void* stream) {
+    return seer_ff_fused_c320_pre(nullptr, 0, nullptr, nullptr, h, ldh, x, ldx, y, ldy, M, gamma, beta, eps, w1f, b1, wcf, bcat, colsum_fx, fx_rows,
+                                  fx_reps, colsum_tiles, dtype, stream);
+}
+extern "C" int seer_ff_fused_c320_pre(const void* a_in, int32_t lda, const void* wof, const float* bo, const void* h, int32_t ldh, const void* x,
+                                      int32_t ldx, void* y, int32_t ldy, int64_t M, const float* gamma, const float* beta, float eps,
+                                      const void* w1f, const float* b1, const void* wcf, const float* bcat, int64_t* colsum_fx, int64_t fx_rows,
+                                      int32_t fx_reps, float* colsum_tiles, int32_t dtype, void* stream) {
+    if (a_in && (!wof || !bo || lda % 8 || lda < FF_C || ldh % 4 ||
+                 ((reinterpret_cast<uintptr_t>(a_in) | reinterpret_cast<uintptr_t>(wof) | reinterpret_cast<uintptr_t>(bo)) & 15))) return SEER_EINVAL;
     if (dtype != SEER_DT_BF16 && dtype != SEER_DT_F16) return SEER_EINVAL;
     if (!h || !x || !y || !gamma || !beta || !w1f || !b1 || !wcf || !bcat) return SEER_EINVAL;
     if (M <= 0 || M >= ((int64_t)1 << 31) - FF_BM || ldh % 8 || ldx % 8 || ldy % 8 || ldh < FF_C || ldx < FF_C || ldy < FF_C) return SEER_EINVAL;
@@ -597,8 +650,10 @@ extern "C" int seer_ff_fused_c320_dt(const void* h, int32_t ldh, const void* x, 
     if (colsum_fx && (fx_rows < FF_BM || fx_rows % 16 || M % fx_rows || fx_reps <= 0)) return SEER_EINVAL;
     if (colsum_tiles && M % FF_BM) return SEER_EINVAL;
     std::call_once(g_ff_once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_ff_fused_c320_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_ff_fused_c320_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_ff_fused_c320_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_ff_fused_c320_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_ff_fused_c320_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seer_ff_fused_c320_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
     });
     FfArgs a;
     a.h = reinterpret_cast<const bf16*>(h); a.x = reinterpret_cast<const bf16*>(x); a.y = reinterpret_cast<bf16*>(y);
@@ -606,10 +661,16 @@ extern "C" int seer_ff_fused_c320_dt(const void* h, int32_t ldh, const void* x, 
     a.gamma = gamma; a.beta = beta; a.eps = eps;
     a.w1f = reinterpret_cast<const unsigned char*>(w1f); a.b1 = b1; a.wcf = reinterpret_cast<const unsigned char*>(wcf); a.bcat = bcat;
     a.colsum_fx = colsum_fx; a.fx_rows = (int)fx_rows; a.fx_reps = fx_reps; a.colsum_tiles = colsum_tiles;
-    if (dtype == SEER_DT_F16)
-        hipLaunchKernelGGL(seer_ff_fused_c320_kernel<true>, dim3((unsigned)((M + FF_BM - 1) / FF_BM)), dim3(256), FF_LDS, reinterpret_cast<hipStream_t>(stream), a);
-    else
-        hipLaunchKernelGGL(seer_ff_fused_c320_kernel<false>, dim3((unsigned)((M + FF_BM - 1) / FF_BM)), dim3(256), FF_LDS, reinterpret_cast<hipStream_t>(stream), a);
+    a.a = reinterpret_cast<const bf16*>(a_in); a.lda = lda; a.wof = reinterpret_cast<const unsigned char*>(wof); a.bo = bo;
+    const dim3 grid((unsigned)((M + FF_BM - 1) / FF_BM));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (a_in) {
+        if (dtype == SEER_DT_F16) hipLaunchKernelGGL((seer_ff_fused_c320_kernel<true, true>), grid, dim3(256), FF_LDS, st, a);
+        else hipLaunchKernelGGL((seer_ff_fused_c320_kernel<false, true>), grid, dim3(256), FF_LDS, st, a);
+    } else {
+        if (dtype == SEER_DT_F16) hipLaunchKernelGGL((seer_ff_fused_c320_kernel<true, false>), grid, dim3(256), FF_LDS, st, a);
+        else hipLaunchKernelGGL((seer_ff_fused_c320_kernel<false, false>), grid, dim3(256), FF_LDS, st, a);
+    }
     SEER_LAUNCH_CHECK();
     return SEER_OK;
 }

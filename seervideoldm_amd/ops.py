@@ -646,12 +646,14 @@ def ff_fused_pack(w1: torch.Tensor, wcat: torch.Tensor):
 
 def ff_fused(h: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, w1f: torch.Tensor, b1: torch.Tensor,
              wcf: torch.Tensor, bcat: torch.Tensor, *, eps: float = 1e-5, out: Optional[torch.Tensor] = None,
-             colsum_batch=0) -> Optional[torch.Tensor]:
+             colsum_batch=0, pre=None) -> Optional[torch.Tensor]:
     """y = x + [Wp | Wp W2] [h | GEGLU(LayerNorm(h) W1^T + b1)] + bcat as ONE launch (seer_ff_fused_c320): the feed-forward of a
     transformer block and the transformer's proj_out with both residual adds, at the 320-channel level.  w1f, wcf from
     ff_fused_pack; b1 in the interleaved GEGLU row order, bcat = Wp b2 + bp.  colsum_batch as in gemm(): (B, arena) -> out.colsums =
-    the ColSumsFx of y, B -> the per-tile ColSums (96-row tiles; only where no tile straddles two batch elements).  Returns None
-    (nothing launched) when the shape is not the kernel's: C = 320."""
+    the ColSumsFx of y, B -> the per-tile ColSums (96-row tiles; only where no tile straddles two batch elements).
+    pre = (a, wof, bo): the rows the launch reads as h are h + a Wo^T + bo -- the attention's to_out projection and its residual, in
+    the same launch (seer_ff_fused_c320_pre; wof = rowchain_pack(Wo)); h itself is not written.  Returns None (nothing launched) when
+    the shape is not the kernel's: C = 320."""
     M, Cc = h.shape
     if Cc != FF_FUSED_C or M == 0:
         return None
@@ -672,10 +674,16 @@ def ff_fused(h: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, beta: torch.
         elif (M // B) % FF_FUSED_ROWS == 0:
             tiles = torch.empty((1, M // FF_FUSED_ROWS, Cc, 2), device=h.device, dtype=torch.float32)
             cs = ColSums(tiles, Cc, 1, M // FF_FUSED_ROWS)
-    check(_lib.load().seer_ff_fused_c320_dt(_p(h), h.stride(0), _p(x), x.stride(0), _p(out), out.stride(0), M, _p(gamma), _p(beta),
-                                            float(eps), _p(w1f), _p(b1), _p(wcf), _p(bcat), fx.data_ptr() if fx is not None else None,
-                                            fx_rows, fx.shape[0] if fx is not None else 0, _p(tiles) if tiles is not None else None,
-                                            dt, _stream()), "seer_ff_fused_c320")
+    pa, lda, pw, pb = None, 0, None, None
+    if pre is not None:
+        a, wof, bo = pre
+        _req16(a, "pre a", h); _req16(wof, "pre wof", h); _req(bo, torch.float32, "pre bo")
+        assert a.shape == h.shape and a.stride(1) == 1 and wof.numel() == Cc * Cc and wof.is_contiguous() and bo.numel() == Cc
+        pa, lda, pw, pb = _p(a), a.stride(0), _p(wof), _p(bo)
+    check(_lib.load().seer_ff_fused_c320_pre(pa, lda, pw, pb, _p(h), h.stride(0), _p(x), x.stride(0), _p(out), out.stride(0), M, _p(gamma),
+                                             _p(beta), float(eps), _p(w1f), _p(b1), _p(wcf), _p(bcat),
+                                             fx.data_ptr() if fx is not None else None, fx_rows, fx.shape[0] if fx is not None else 0,
+                                             _p(tiles) if tiles is not None else None, dt, _stream()), "seer_ff_fused_c320")
     out.colsums = cs
     out.rowstats = None
     return out

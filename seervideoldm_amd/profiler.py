@@ -43,10 +43,11 @@ class TimedOps:
     def ff_fused(self, h, x, gamma, beta, w1f, b1, wcf, bcat, **k):
         # norm3 -> ff.net.0 (GEGLU) -> [proj_out | proj_out ff.net.2] + residuals as one launch: the MACs of the two GEMMs it holds
         M, Cc = h.shape
-        flops = 2.0 * M * Cc * (8 * Cc) + 2.0 * M * (5 * Cc) * Cc
-        nbytes = 2 * (3 * M * Cc + w1f.numel() + wcf.numel())
+        pre = k.get("pre") is not None          # the block's last to_out + residual as the launch's prologue: its MACs and its operand
+        flops = 2.0 * M * Cc * (8 * Cc) + 2.0 * M * (5 * Cc) * Cc + (2.0 * M * Cc * Cc if pre else 0.0)
+        nbytes = 2 * ((4 if pre else 3) * M * Cc + w1f.numel() + wcf.numel() + (Cc * Cc if pre else 0))
         return self._timed("gemm", flops, nbytes, self._base.ff_fused, h, x, gamma, beta, w1f, b1, wcf, bcat,
-                           _tag=f"ff_fused M{M} C{Cc}", **k)
+                           _tag=f"ff_fused M{M} C{Cc}" + (" pre" if pre else ""), **k)
 
     def rowchain(self, inp, w1f, **k):
         # one or more 320 x 320 products over the same rows (GroupNorm / LayerNorm in between) as one launch: their MACs
@@ -170,7 +171,7 @@ class TimedOps:
                     "GroupNorm -> proj_in -> norm1 -> q|k|v, one launch ") + lvl
         if t[0] == "ff_fused":
             lvl = (levels or {24576: "L0"}).get(int(t[1][1:]), t[1])
-            return f"fused feed-forward (norm3, ff.net.0 GEGLU, ff.net.2 | proj_out +res) {lvl}"
+            return f"fused feed-forward ({'to_out +res, ' if 'pre' in t else ''}norm3, ff.net.0 GEGLU, ff.net.2 | proj_out +res) {lvl}"
         if t[0] == "conv":
             return f"conv3x3 {t[2]}"
         if t[0] == "conv_up2x":

@@ -265,6 +265,9 @@ class _Engine:
         # model.rowchain = False / SEER_ROWCHAIN=0: the separate launches)
         self.rowchain = bool(getattr(model, "rowchain", os.environ.get("SEER_ROWCHAIN", "1") != "0")) and hasattr(self.ops, "rowchain")
         self.rowchains = 0
+        # ... and the block's last to_out + residual as a prologue of the fused feed-forward (SEER_FF_PRE=0: its own launch)
+        self.ff_pre = self.rowchain and self.ff_fused and os.environ.get("SEER_FF_PRE", "1") != "0"
+        self._ffpre_bias: Dict[str, str] = {}
         self.gn_from_colsums = 0
         self.w: Dict[str, torch.Tensor] = {}
         self._pack(sd)
@@ -384,6 +387,11 @@ class _Engine:
                     if (tb + ".attn2.q") in w:
                         w[tb + ".rc.to_out"] = self.ops.rowchain_pack(w[tb + ".attn1.to_out.0.weight"])
                         w[tb + ".rc.q"] = self.ops.rowchain_pack(w[tb + ".attn2.q"])
+                    # the LAST to_out of the block (text: attn2, temporal: attn1) as the fused feed-forward's prologue (ops.ff_fused(pre=))
+                    last = tb + (".attn2" if (tb + ".attn2.q") in w else ".attn1") + ".to_out.0"
+                    if (pth + ".ff_fused.w1f") in w and self.ff_pre:
+                        w[tb + ".ffpre.wo"] = self.ops.rowchain_pack(w[last + ".weight"])
+                        self._ffpre_bias[tb] = last + ".bias"
         # LayerNorm folded into the GEMM that consumes it (ops.fold_layernorm): W' = gamma (.) W from the fp32 weights, its row
         # sums and beta W^T + b, next to the plain weights (a launch that cannot fold runs layernorm + the plain ones)
         self.wln: Dict[str, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = {}
@@ -569,15 +577,22 @@ class _Engine:
         """will _ff_proj_out run transformer `p`'s feed-forward over the rows of h as the fused launch?"""
         return (p + ".ff_fused.w1f") in self.w and self.ops.ff_fused_pays(h.shape[0])
 
-    def _ff_proj_out(self, p, tb, h, x, cb):
+    def _ff_pre(self, p, tb, h):
+        """will the block's last to_out + residual ride in the fused feed-forward launch (ops.ff_fused(pre=))?"""
+        return (tb + ".ffpre.wo") in self.w and self._ff_fused_rows(p, h)
+
+    def _ff_proj_out(self, p, tb, h, x, cb, a=None):
         """the feed-forward of block `tb` and the transformer's proj_out + residual x: folded into one two-source GEMM when the
-        block's weights were (see _pack), else ff.net.2 + residual and proj_out + residual as two launches"""
+        block's weights were (see _pack), else ff.net.2 + residual and proj_out + residual as two launches.  `a` (only with
+        _ff_pre): the attention output whose to_out projection + residual h the fused launch computes itself."""
         ops, w = self.ops, self.w
         if self._ff_fused_rows(p, h):
+            pre = None if a is None else (a, w[tb + ".ffpre.wo"], w[self._ffpre_bias[tb]])
             y = ops.ff_fused(h, x, w[tb + ".norm3.weight"], w[tb + ".norm3.bias"], w[p + ".ff_fused.w1f"],
-                             w[tb + ".ff.net.0.proj.bias"], w[p + ".ff_fused.wcf"], w[p + ".ffproj.b"], colsum_batch=cb)
+                             w[tb + ".ff.net.0.proj.bias"], w[p + ".ff_fused.wcf"], w[p + ".ffproj.b"], colsum_batch=cb, pre=pre)
             if y is not None:
                 return y
+        assert a is None, "the to_out prologue exists only inside the fused feed-forward launch"
         if (p + ".ffproj.w") in w:
             g = self._ln_gemm(h, tb, ".norm3", tb + ".ff.net.0.proj.weight", tb + ".ff.net.0.proj.bias", geglu=True)
             return ops.gemm(h, w[p + ".ffproj.w"], a2=g, bias=w[p + ".ffproj.b"], residual=x, colsum_batch=cb)
@@ -626,11 +641,14 @@ class _Engine:
         if self._attn_list is not None and p in self._attn_wanted:
             self._attn_list.append(self._cross_scores(q, kv[:, :C], B, Fr, H, W, heads, d, L))
         ops.attention(q, kv[:, :C], kv[:, C:], a, batch=B * Fr, heads=heads, head_dim=d, Sq=HW, Sk=L, q_prescaled=True)
+        # (the output's only GroupNorm is the temporal transformer's: accumulated sums when that one runs as a chain)
+        cb = self._cb(B, Fr * HW, for_chain=self._chain_next(C, B, Fr * HW))
+        if self._ff_pre(p, tb, h):
+            return self._ff_proj_out(p, tb, h, x, cb, a=a)      # attn2.to_out + residual inside the fused feed-forward launch
         # (the fused feed-forward normalises its rows itself: no row statistics asked of their producer)
         ops.gemm(a, w[tb + ".attn2.to_out.0.weight"], bias=w[tb + ".attn2.to_out.0.bias"], residual=h, out=h,
                  **({} if self._ff_fused_rows(p, h) else self._rs()))
-        # (the output's only GroupNorm is the temporal transformer's: accumulated sums when that one runs as a chain)
-        return self._ff_proj_out(p, tb, h, x, self._cb(B, Fr * HW, for_chain=self._chain_next(C, B, Fr * HW)))
+        return self._ff_proj_out(p, tb, h, x, cb)
 
     def _cross_scores(self, q, k, B, Fr, H, W, heads, d, L):
         """`attention_scores` of the text cross attention (attention.py:556-584: scale * Q K^T before the softmax) as
@@ -693,6 +711,8 @@ class _Engine:
                               Sq=Fr * HW, Sk=Fr * HW, causal=True, q_prescaled=True)
         # FF skips the conditioning frames (attention.py:241-246); frames are the slow index inside a batch element
         skip_f = cond_frame if self.shard is None else self.shard.local_cond_frames(cond_frame)
+        if skip_f <= 0 and self._ff_pre(p, tb, h):
+            return self._ff_proj_out(p, tb, h, x, self._cb(B, Fr * HW), a=a)    # attn1.to_out + residual inside the fused feed-forward launch
         ops.gemm(a, w[tb + ".attn1.to_out.0.weight"], bias=w[tb + ".attn1.to_out.0.bias"], residual=h, out=h,
                  **({} if skip_f <= 0 and self._ff_fused_rows(p, h) else self._rs()))
         if skip_f <= 0:

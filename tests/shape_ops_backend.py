@@ -57,7 +57,7 @@ def ff_fused_pack(w1, wcat):
     return torch.empty_like(w1), torch.empty_like(wcat)
 
 
-def ff_fused(h, x, gamma, beta, w1f, b1, wcf, bcat, *, eps=1e-5, out=None, colsum_batch=0):
+def ff_fused(h, x, gamma, beta, w1f, b1, wcf, bcat, *, eps=1e-5, out=None, colsum_batch=0, pre=None):
     M, Cc = h.shape
     if Cc != FF_FUSED_C or M == 0:
         return None

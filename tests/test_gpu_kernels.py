@@ -1249,6 +1249,47 @@ def test_ff_fused_c320(device, M, B, strided):
     assert torch.equal(y2, y)
 
 
+@pytest.mark.parametrize("dt,M,strided", [(bf16, 24576, False), (bf16, 1000, True), (torch.float16, 6144, False)])
+def test_ff_fused_c320_with_the_to_out_prologue(device, dt, M, strided):
+    """seer_ff_fused_c320_pre: the rows the fused feed-forward reads as h are h + a Wo^T + bo -- the attention's to_out projection and
+    its residual (attention.py:237-240, 316-322) -- computed in the launch's tile and stored nowhere; against the two launches
+    (to_out + residual, then the fused feed-forward) and the fp32 formula"""
+    from seervideoldm_amd import ops
+    from seervideoldm_amd.weights import geglu_row_order
+    C, inner = 320, 1280
+    ld = C + 64 if strided else C
+    a = _rand((M, ld), device, 11).to(dt)[:, :C]
+    h0 = _rand((M, ld), device, 1).to(dt)[:, :C]
+    x = _rand((M, C), device, 2).to(dt)
+    wo, bo = _rand((C, C), device, 12, C ** -0.5).to(dt), 0.1 * _rand((C,), device, 13)
+    gamma, beta = 1.0 + 0.2 * _rand((C,), device, 3), 0.1 * _rand((C,), device, 4)
+    w1 = _rand((2 * inner, C), device, 5, C ** -0.5).to(dt)
+    b1 = 0.2 * _rand((2 * inner,), device, 6)
+    wcat = _rand((C, C + inner), device, 7, (C + inner) ** -0.5).to(dt)
+    bcat = 0.2 * _rand((C,), device, 8)
+    order = geglu_row_order(inner, device)
+    w1p, b1p = w1[order].contiguous(), b1[order].contiguous()
+    w1f, wcf = ops.ff_fused_pack(w1p, wcat)
+    h_keep = h0.clone()
+    y = ops.ff_fused(h0, x, gamma, beta, w1f, b1p, wcf, bcat, pre=(a, ops.rowchain_pack(wo), bo))
+    assert y is not None and y.dtype == dt and torch.equal(h0, h_keep), "the residual stream is read, not written"
+    # the two launches it replaces: same roundings at the same places (h rounded to 16 bits once)
+    h2 = ops.gemm(a.contiguous(), wo, bias=bo, residual=h0.contiguous())
+    y2 = ops.ff_fused(h2, x, gamma, beta, w1f, b1p, wcf, bcat)
+    tol = 4e-3 if dt == bf16 else 6e-4
+    rel2 = ((y.float() - y2.float()).norm() / y2.float().norm()).item()
+    assert rel2 < tol, rel2
+    # the formula
+    h = (h0.float() + a.float() @ wo.float().t() + bo).to(dt).float()
+    hn = Fn.layer_norm(h, (C,), gamma, beta, 1e-5).to(dt).float()
+    pre = hn @ w1.float().t() + b1
+    g = (pre[:, :inner] * Fn.gelu(pre[:, inner:])).to(dt).float()
+    ref = x.float() + torch.cat([h, g], 1) @ wcat.float().t() + bcat
+    rel = ((y.float() - ref).norm() / ref.norm()).item()
+    assert rel < tol, rel
+    assert torch.equal(ops.ff_fused(h0, x, gamma, beta, w1f, b1p, wcf, bcat, pre=(a, ops.rowchain_pack(wo), bo)), y)
+
+
 def test_ff_fused_c320_refuses_other_widths_and_the_engine_takes_it_where_it_pays(device):
     from seervideoldm_amd import ops
     z = torch.zeros((96, 640), device=device, dtype=bf16)
