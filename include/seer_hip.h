@@ -525,6 +525,25 @@ int64_t seer_gemm_tn_workspace_bytes(int32_t M, int32_t N, int32_t K);
 int seer_gemm_tn_f32(const void* A, int32_t lda, const void* B, int32_t ldb, int32_t M, int32_t N, int32_t K, float* C,
                      float* colsum, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* The weight gradients of MANY layers in one launch (ABI 24).  In the reference every trainable nn.Linear gets its `.grad` from
+ * autograd's backward (train.py:382 `accelerator.backward(loss)`), one product per layer wherever the walk reaches it; none of them
+ * depends on another and nothing reads them before the optimizer (train.py:383-386), so a backward pass may leave them to its end:
+ * `items` is a HOST array (the launch carries its problem table in the kernel arguments, 48 problems per launch: a captured launch keeps
+ * it), item i as seer_gemm_tn_f32's arguments.  A problem is split over ceil(M / 16384) workgroups per tile (SEER_TN_GROUP_ROWS: the group fills the chip by its number of problems);
+ * slices meet in `workspace` (seer_gemm_tn_grouped_workspace_bytes) and one more launch adds them in slice order.  Results are
+ * independent of how problems are grouped: a problem's bits depend on its own (M, N, K) only. */
+typedef struct seer_tn_item {
+    const void* A;          /* dY [M][N] bf16, row pitch lda */
+    const void* B;          /* X  [M][K] bf16, row pitch ldb */
+    float* C;               /* dW [N][K] fp32 */
+    float* colsum;          /* [N] fp32 or NULL */
+    int32_t lda, ldb, M, N, K;
+    int32_t reserved;
+} seer_tn_item;
+int64_t seer_gemm_tn_grouped_workspace_bytes(const seer_tn_item* items /* host */, int32_t n_items);
+int seer_gemm_tn_grouped_f32(const seer_tn_item* items /* host */, int32_t n_items, void* workspace, int64_t workspace_bytes,
+                             void* stream);
+
 /* y[c*ldy + r] = x[r*ldx + c]; columns rows..ldy-1 of y are zero filled */
 int seer_transpose_bf16(const void* x, int64_t rows, int32_t cols, int32_t ldx, void* y, int64_t ldy, void* stream);
 

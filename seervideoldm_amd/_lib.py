@@ -13,7 +13,7 @@ _PKG = Path(__file__).resolve().parent
 _LIB_PATH = _PKG / "lib" / "libseer_hip.so"
 _lib = None
 
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 SEER_GEMM_PLAIN = 0
 SEER_GEMM_CONV3X3 = 1
@@ -71,6 +71,11 @@ class AttnDesc(C.Structure):
         ("flags", C.c_uint32), ("variant", C.c_int32),
         ("q_hs", C.c_int64), ("k_hs", C.c_int64), ("v_hs", C.c_int64),
     ]
+
+
+class TnItem(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("colsum", C.c_void_p),
+                ("lda", C.c_int32), ("ldb", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("reserved", C.c_int32)]
 
 
 class RowChainDesc(C.Structure):
@@ -163,6 +168,8 @@ SIGNATURES = {
     "seer_attn_bwd": ([C.POINTER(AttnBwdDesc), _vp], C.c_int),
     "seer_gemm_tn_workspace_bytes": ([_i32, _i32, _i32], C.c_int64),
     "seer_gemm_tn_f32": ([_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp], C.c_int),
+    "seer_gemm_tn_grouped_workspace_bytes": ([C.POINTER(TnItem), _i32], C.c_int64),
+    "seer_gemm_tn_grouped_f32": ([C.POINTER(TnItem), _i32, _vp, _i64, _vp], C.c_int),
     "seer_transpose_bf16": ([_vp, _i64, _i32, _i32, _vp, _i64, _vp], C.c_int),
     "seer_transpose_batched_bf16": ([_vp, _i32, _i64, _vp], C.c_int),
     "seer_colsum_workspace_floats": ([_i64, _i32], C.c_int64),

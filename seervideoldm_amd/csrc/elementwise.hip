@@ -653,7 +653,7 @@ extern "C" int seer_gaussian_sample(const float* moments, int32_t N, int32_t C, 
     return SEER_OK;
 }
 
-extern "C" int seer_abi_version(void) { return 23; }
+extern "C" int seer_abi_version(void) { return 24; }
 extern "C" const char* seer_build_arch(void) { return "gfx950"; }
 extern "C" const char* seer_strerror(int code) {
     switch (code) {

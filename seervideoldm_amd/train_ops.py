@@ -69,6 +69,32 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     return out
 
 
+def gemm_tn_grouped(problems) -> None:
+    """problems: [(a [M, N], b [M, K], out [N, K] fp32, colsum [N] fp32 or None), ...] -- out_i = a_i^T @ b_i (and colsum_i = the column
+    sums of a_i) for all of them in ONE launch (+ one for the K slices of the long ones): the deferred weight gradients of a backward
+    pass (seer_gemm_tn_grouped_f32).  A problem's result does not depend on what it is grouped with."""
+    if not problems:
+        return
+    lib = _lib.load()
+    items = (_lib.TnItem * len(problems))()
+    for it, (a, b, out, colsum) in zip(items, problems):
+        _req(a, bf16, "a"); _req(b, bf16, "b"); _req(out, torch.float32, "out")
+        assert a.dim() == 2 and b.dim() == 2 and a.shape[0] == b.shape[0] and a.stride(1) == 1 and b.stride(1) == 1
+        M, N = a.shape
+        K = b.shape[1]
+        assert out.shape == (N, K) and out.is_contiguous()
+        if colsum is not None:
+            _req(colsum, torch.float32, "colsum")
+            assert colsum.is_contiguous() and colsum.numel() == N
+        it.A, it.B, it.C, it.colsum = _p(a), _p(b), _p(out), _p(colsum)
+        it.lda, it.ldb, it.M, it.N, it.K = a.stride(0), b.stride(0), M, N, K
+    nbytes = lib.seer_gemm_tn_grouped_workspace_bytes(items, len(problems))
+    if nbytes < 0:
+        check(int(nbytes), "seer_gemm_tn_grouped_workspace_bytes")
+    ws = torch.empty((nbytes // 4,), device=problems[0][0].device, dtype=torch.float32) if nbytes else None
+    check(lib.seer_gemm_tn_grouped_f32(items, len(problems), _p(ws), nbytes, _stream()), "seer_gemm_tn_grouped_f32")
+
+
 def transpose(x: torch.Tensor, pad_to: int = 64) -> torch.Tensor:
     """x [rows, cols] (row-strided view) -> [cols, round_up(rows, pad_to)] with the pad columns zero."""
     _req(x, bf16, "x")

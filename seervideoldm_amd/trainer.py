@@ -170,6 +170,10 @@ class SeerTrainer:
         self._graphs: Dict[Tuple, Tuple] = {}           # captured forward+backward, keyed on the input shapes
         self._graph_broken = False
         self._early_hu = None                           # handle of a UNet-segment all-reduce started inside the step
+        # weight gradients: deferred to the end of each backward walk and launched as a group (SEER_DW_GROUPED=0: one launch per layer
+        # where the walk reaches it)
+        self._dw_deferred = os.environ.get("SEER_DW_GROUPED", "1") != "0" and hasattr(tops, "gemm_tn_grouped")
+        self._dw: List[Tuple] = []
 
     # ================================================================================================ helpers
     def _frozenT(self, key: str) -> torch.Tensor:
@@ -203,11 +207,21 @@ class SeerTrainer:
         """y = x W^T + b.  P != None: the layer trains (dW, db into P.g).  Returns dx (+ dres) or None."""
         ops, tops = self.ops, self.tops
         if P is not None:
-            tops.gemm_tn(dy, x, out=P.view(P.g, wkey), colsum=P.view(P.g, bkey) if bkey is not None else None)
+            prob = (dy, x, P.view(P.g, wkey), P.view(P.g, bkey) if bkey is not None else None)
+            if self._dw_deferred:       # nothing reads a weight gradient before the optimizer: all of a pass's products in one launch
+                self._dw.append(prob)   # (_flush_dw); dy and x are kept alive, and nothing writes to them, until then
+            else:
+                tops.gemm_tn(prob[0], prob[1], out=prob[2], colsum=prob[3])
         if not need_dx:
             return None
         WT = P.wT[wkey] if P is not None else self._frozenT(wkey)
         return ops.gemm(dy, WT, residual=dres, out=out)
+
+    def _flush_dw(self):
+        """the weight-gradient products the backward walk left behind (`_lin_bwd`), as one grouped launch"""
+        if self._dw:
+            self.tops.gemm_tn_grouped(self._dw)
+            self._dw = []
 
     def _cb(self, B):
         """`colsum_batch` of a launch whose output feeds a GroupNorm: accumulate into the step's arena when there is one"""
@@ -286,14 +300,13 @@ class SeerTrainer:
         pre = ops.gemm(n3, W[w1], bias=W[b1])
         g = tops.geglu_fwd(pre)
         out = ops.gemm(g, W[w2], bias=W[b2], residual=hf, out=out)
-        return out, (hf, n3, pre)
+        return out, (hf, n3, pre, g if P is not None else None)     # a trainable ff.net.2 reads g again (its weight gradient)
 
     def _ff_bwd(self, P, W, names, saved, dout, dx=None):
         """returns d hf (LayerNorm path + residual path); `dx`: where to write it"""
         tops = self.tops
         g3, b3, w1, b1, w2, b2 = names
-        hf, n3, pre = saved
-        g = tops.geglu_fwd(pre) if P is not None else None
+        hf, n3, pre, g = saved
         dg = self._lin_bwd(P, W, w2, b2, g, dout)
         dpre = tops.geglu_bwd(pre, dg)
         dn3 = self._lin_bwd(P, W, w1, b1, n3, dpre)
@@ -339,7 +352,7 @@ class SeerTrainer:
             pre = ops.gemm(n3, w[w1], bias=w[b1])
             g = tops.geglu_fwd(pre)
             out = ops.gemm(h2, w[p + ".ffproj.w"], a2=g, bias=w[p + ".ffproj.b"], residual=x, colsum_batch=self._cb(B))
-            sff = (h2, n3, pre)
+            sff = (h2, n3, pre, None)
         else:
             h3, sff = self._ff_fwd(None, w, self._unet_ff_names(tb), h2)
             out = ops.gemm(h3, w[p + ".proj_out.weight"], bias=w[p + ".proj_out.bias"], residual=x, colsum_batch=self._cb(B))
@@ -352,7 +365,7 @@ class SeerTrainer:
         if (p + ".ffproj.w") in w:
             # [d h3 | d g] = dout [Wp | Wp W2]: the two input gradients of the folded pair from ONE GEMM
             g3, _, w1, _, _, _ = self._unet_ff_names(tb)
-            hf, n3, pre = sff
+            hf, n3, pre, _ = sff
             both = ops.gemm(dout, self._frozenT(p + ".ffproj.w"))
             dpre = tops.geglu_bwd(pre, both[:, C:])
             dn3 = self._lin_bwd(None, w, w1, None, None, dpre)
@@ -580,6 +593,7 @@ class SeerTrainer:
         if WT is None:
             WT = torch.cat([self._frozenT(tb + ".attn2.kv") for tb in self._kv_cols], 1).contiguous()      # [Dc, sum 2C]
             self._wT["__kv_all__"] = WT
+        self._flush_dw()                                 # the UNet's gradient segment is final when phase A ends
         return ops.gemm(self._dkv_all, WT)
 
     # ================================================================================================ FSText
@@ -689,6 +703,7 @@ class SeerTrainer:
                                    dqkv[:, 2 * C:], **kw1)
                 dn1 = self._lin_bwd(P, W, p + ".attn1.qkv", None, n1, dqkv)
                 dx = tops.layernorm_bwd(x0, dn1, W[p + ".norm1.w"], dres=dx1, dgamma=G(p + ".norm1.w"), dbeta=G(p + ".norm1.b"))
+        self._flush_dw()
         # token embeddings: learnable_query sees every row, pos_embed[src[f], :l] the rows of frame f summed over the batch
         tops.colsum(dx, out=G("learnable_query").reshape(-1))
         gp = G("pos_embed")

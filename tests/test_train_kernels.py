@@ -385,6 +385,39 @@ def test_gemm_tn(device, M, N, K):
     _rel(cs, dy.float().sum(0), 1e-5, f"gemm_tn colsum {M}x{N}")
 
 
+def test_gemm_tn_grouped(device):
+    """the deferred weight gradients of a backward walk in one launch: every problem against the fp32 product, ragged shapes and
+    strided views included, split and unsplit ones side by side, more problems than one launch's table holds; a problem's
+    bits do not depend on its companions"""
+    from seervideoldm_amd import train_ops
+    shapes = [(924, 768, 768), (12288, 960, 320), (1536, 320, 1280), (160, 1280, 1280), (100, 2560, 320), (3072, 640, 2560),
+              (64, 8, 8), (1000, 136, 72), (2049, 320, 320), (4096, 128, 136)]
+    shapes = shapes + [(192 + 64 * i, 320, 320) for i in range(45)]              # 55 problems: two launches
+    probs, refs = [], []
+    for i, (M, N, K) in enumerate(shapes):
+        dy = _rand((M, N + 8), device, 2 * i + 1).to(bf16)[:, :N]
+        x = _rand((M, K + 16), device, 2 * i + 2).to(bf16)[:, 8:8 + K]
+        out = torch.full((N, K), float("nan"), device=device)
+        cs = torch.full((N,), float("nan"), device=device) if i % 2 == 0 else None
+        probs.append((dy, x, out, cs))
+        refs.append((dy.float().t() @ x.float(), dy.float().sum(0)))
+    train_ops.gemm_tn_grouped(probs)
+    for (dy, x, out, cs), (r, rc), sh in zip(probs, refs, shapes):
+        _rel(out, r, 2e-3, f"gemm_tn_grouped {sh}")
+        if cs is not None:
+            _rel(cs, rc, 1e-5, f"gemm_tn_grouped colsum {sh}")
+    # alone, in another order, beside other problems: the same bits
+    for i in (1, 8, 0, 30):
+        dy, x, out, cs = probs[i]
+        o2 = torch.empty_like(out)
+        c2 = torch.empty_like(cs) if cs is not None else None
+        train_ops.gemm_tn_grouped([(dy, x, o2, c2)])
+        assert torch.equal(o2, out) and (cs is None or torch.equal(c2, cs)), shapes[i]
+    outs = [torch.empty_like(p[2]) for p in probs]
+    train_ops.gemm_tn_grouped([(p[0], p[1], o, None) for p, o in zip(probs, outs)][::-1])
+    assert all(torch.equal(o, p[2]) for p, o in zip(probs, outs))
+
+
 def test_text_loss_grad(device):
     from seervideoldm_amd import train_ops
     b, Fr, L, C = 2, 5, 77, 192

@@ -79,6 +79,11 @@ def gemm_tn(a, b, out=None, colsum=None):
     return out
 
 
+def gemm_tn_grouped(problems):
+    for a, b, out, colsum in problems:
+        gemm_tn(a, b, out=out, colsum=colsum)
+
+
 def transpose(x, pad_to=64):
     rows, cols = x.shape
     ld = (rows + pad_to - 1) // pad_to * pad_to
