@@ -576,6 +576,20 @@ int seer_colsum_bf16(const void* x, int64_t rows, int32_t cols, int32_t ldx, flo
 int seer_layernorm_bwd(const void* x, const void* dy, int64_t rows, int32_t C, int32_t ldx, int32_t lddy, const float* gamma,
                        float eps, const void* dres, int32_t ldres, void* dx, int32_t lddx, float* dgamma, float* dbeta,
                        float* workspace, void* stream);
+/* The same, leaving d gamma / d beta as partial slabs: workspace[slab][2][C] (v 0 = d beta, v 1 = d gamma), seer_layernorm_bwd_slabs(rows)
+ * slabs; seer_colfinal_grouped adds the slabs of MANY norms in one launch (ABI 24: the finals of every LayerNorm a backward walk
+ * passed, deferred to its end -- nothing reads them before the optimizer, train.py:383-386).  Bits as seer_layernorm_bwd's. */
+int64_t seer_layernorm_bwd_slabs(int64_t rows);
+int seer_layernorm_bwd_partials(const void* x, const void* dy, int64_t rows, int32_t C, int32_t ldx, int32_t lddy, const float* gamma,
+                                float eps, const void* dres, int32_t ldres, void* dx, int32_t lddx, float* workspace, void* stream);
+/* out_v[c] = sum over k < nblocks of ws[(k * NV + v) * C + c], k in a fixed order; `items` is a HOST array (64 per launch, by value) */
+typedef struct seer_colfinal_item {
+    const float* ws;
+    float* out0;            /* v = 0, or NULL */
+    float* out1;            /* v = 1, or NULL */
+    int32_t nblocks, NV, C, reserved;
+} seer_colfinal_item;
+int seer_colfinal_grouped(const seer_colfinal_item* items /* host */, int32_t n_items, void* stream);
 
 /* GroupNorm (+ optional SiLU) backward over (C/G, F, H, W) per (b, g); stats/count/eps/gamma/beta/silu as in the forward
  * pair seer_groupnorm_stats / seer_groupnorm_apply.  dy bf16 [rows, C1+C2]; dx1/dx2 are the gradients of the two concat

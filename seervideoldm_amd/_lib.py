@@ -78,6 +78,11 @@ class TnItem(C.Structure):
                 ("lda", C.c_int32), ("ldb", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("reserved", C.c_int32)]
 
 
+class ColfinalItem(C.Structure):
+    _fields_ = [("ws", C.c_void_p), ("out0", C.c_void_p), ("out1", C.c_void_p),
+                ("nblocks", C.c_int32), ("NV", C.c_int32), ("C", C.c_int32), ("reserved", C.c_int32)]
+
+
 class RowChainDesc(C.Structure):
     _fields_ = [
         ("inp", C.c_void_p), ("ld_in", C.c_int32),
@@ -175,6 +180,9 @@ SIGNATURES = {
     "seer_colsum_workspace_floats": ([_i64, _i32], C.c_int64),
     "seer_colsum_bf16": ([_vp, _i64, _i32, _i32, _vp, _vp, _vp], C.c_int),
     "seer_layernorm_bwd": ([_vp, _vp, _i64, _i32, _i32, _i32, _vp, _f32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp], C.c_int),
+    "seer_layernorm_bwd_slabs": ([_i64], C.c_int64),
+    "seer_layernorm_bwd_partials": ([_vp, _vp, _i64, _i32, _i32, _i32, _vp, _f32, _vp, _i32, _vp, _i32, _vp, _vp], C.c_int),
+    "seer_colfinal_grouped": ([C.POINTER(ColfinalItem), _i32, _vp], C.c_int),
     "seer_groupnorm_bwd_workspace_floats": ([_i32, _i32, _i64, _i32], C.c_int64),
     "seer_groupnorm_bwd": ([_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _f64, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp,
                             _vp, _vp, _vp, _vp], C.c_int),

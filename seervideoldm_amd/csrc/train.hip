@@ -284,6 +284,44 @@ __global__ void __launch_bounds__(1024) colfinal_kernel(const float* __restrict_
     }
 }
 
+// the same for many (ws, out) pairs in one launch: the d gamma / d beta finals of every LayerNorm a backward walk passed, deferred to
+// its end (nothing reads them before the optimizer).  Table by value in the kernel arguments; block -> (item, column block, v)
+constexpr int CF_GROUP = 64;
+struct CfItem {
+    const float* ws; float* out0; float* out1;
+    int nblocks, NV, C, blk0;
+};
+struct CfGroup {
+    CfItem it[CF_GROUP];
+    int n;
+};
+__global__ void __launch_bounds__(1024) colfinal_grouped_kernel(const CfGroup g) {
+    __shared__ float red[16][64];
+    const int blk = blockIdx.x;
+    int i = 0;
+    while (i + 1 < g.n && blk >= g.it[i + 1].blk0) ++i;
+    const CfItem& q = g.it[i];
+    const int local = blk - q.blk0;
+    const int cblocks = (q.C + 63) / 64;
+    const int v = local / cblocks;
+    const int cl = threadIdx.x & 63, kl = threadIdx.x >> 6;
+    const int c = (local % cblocks) * 64 + cl;
+    float s = 0.f;
+    if (c < q.C) {
+        const float* w = q.ws + (int64_t)v * q.C + c;
+        for (int k = kl; k < q.nblocks; k += 16) s += w[(int64_t)k * q.NV * q.C];
+    }
+    red[kl][cl] = s;
+    __syncthreads();
+    if (kl == 0 && c < q.C) {
+        float t = 0.f;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) t += red[l][cl];
+        float* o = v == 0 ? q.out0 : q.out1;
+        if (o) o[c] = t;
+    }
+}
+
 // GroupNorm backward, middle stage: the chunk partials of colpartial_kernel<2> (per (b, c): A = sum gy, Bv = sum gy xhat) -> per
 // (b, g) projections s1 = sum_c gamma_c A_bc, s2 = sum_c gamma_c B_bc (scaled by 1/count), and dgamma_c = sum_b B_bc,
 // dbeta_c = sum_b A_bc.  One block per group: 16 chunk lanes x 64 channel lanes add the partials (then in lane order: a fixed
@@ -843,9 +881,18 @@ extern "C" int seer_colsum_bf16(const void* x, int64_t rows, int32_t cols, int32
     return SEER_OK;
 }
 
-extern "C" int seer_layernorm_bwd(const void* x, const void* dy, int64_t rows, int32_t C, int32_t ldx, int32_t lddy,
-                                  const float* gamma, float eps, const void* dres, int32_t ldres, void* dx, int32_t lddx,
-                                  float* dgamma, float* dbeta, float* workspace, void* stream) {
+namespace {
+int64_t ln_bwd_slabs(int64_t rows) {
+    const int64_t blocks = (rows + 7) / 8;
+    return blocks > 1024 ? 1024 : blocks;
+}
+}  // namespace
+
+extern "C" int64_t seer_layernorm_bwd_slabs(int64_t rows) { return rows > 0 ? ln_bwd_slabs(rows) : SEER_EINVAL; }
+
+static int layernorm_bwd_impl(const void* x, const void* dy, int64_t rows, int32_t C, int32_t ldx, int32_t lddy,
+                              const float* gamma, float eps, const void* dres, int32_t ldres, void* dx, int32_t lddx,
+                              float* dgamma, float* dbeta, float* workspace, bool partials_only, void* stream) {
     if (!x || !dy || !gamma || !dx || rows <= 0 || C <= 0 || C % 8 || (ldx | lddy | lddx) % 8) return SEER_EINVAL;
     if (dres && ldres % 8) return SEER_EINVAL;
     if ((dgamma != nullptr) != (dbeta != nullptr)) return SEER_EINVAL;
@@ -876,8 +923,41 @@ extern "C" int seer_layernorm_bwd(const void* x, const void* dy, int64_t rows, i
     else SEER_LNB(3);
 #undef SEER_LNB
     SEER_LAUNCH_CHECK();
-    if (dgamma) {
+    if (dgamma && !partials_only) {
         hipLaunchKernelGGL(colfinal_kernel, dim3((C + 63) / 64, 2, 1), dim3(1024), 0, st, workspace, (int)blocks, 2, C, dbeta, dgamma);
+        SEER_LAUNCH_CHECK();
+    }
+    return SEER_OK;
+}
+
+extern "C" int seer_layernorm_bwd(const void* x, const void* dy, int64_t rows, int32_t C, int32_t ldx, int32_t lddy,
+                                  const float* gamma, float eps, const void* dres, int32_t ldres, void* dx, int32_t lddx,
+                                  float* dgamma, float* dbeta, float* workspace, void* stream) {
+    return layernorm_bwd_impl(x, dy, rows, C, ldx, lddy, gamma, eps, dres, ldres, dx, lddx, dgamma, dbeta, workspace, false, stream);
+}
+
+extern "C" int seer_layernorm_bwd_partials(const void* x, const void* dy, int64_t rows, int32_t C, int32_t ldx, int32_t lddy,
+                                           const float* gamma, float eps, const void* dres, int32_t ldres, void* dx, int32_t lddx,
+                                           float* workspace, void* stream) {
+    if (!workspace) return SEER_EINVAL;
+    return layernorm_bwd_impl(x, dy, rows, C, ldx, lddy, gamma, eps, dres, ldres, dx, lddx, workspace, workspace, workspace, true, stream);
+}
+
+extern "C" int seer_colfinal_grouped(const seer_colfinal_item* items, int32_t n_items, void* stream) {
+    if (!items || n_items <= 0) return SEER_EINVAL;
+    for (int i = 0; i < n_items; ++i)
+        if (!items[i].ws || items[i].nblocks <= 0 || items[i].C <= 0 || items[i].NV < 1 || items[i].NV > 2) return SEER_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    for (int base = 0; base < n_items; base += CF_GROUP) {
+        CfGroup g{};
+        g.n = n_items - base < CF_GROUP ? n_items - base : CF_GROUP;
+        int blk = 0;
+        for (int j = 0; j < g.n; ++j) {
+            const seer_colfinal_item& it = items[base + j];
+            g.it[j] = CfItem{it.ws, it.out0, it.out1, it.nblocks, it.NV, it.C, blk};
+            blk += ((it.C + 63) / 64) * it.NV;
+        }
+        hipLaunchKernelGGL(colfinal_grouped_kernel, dim3(blk), dim3(1024), 0, st, g);
         SEER_LAUNCH_CHECK();
     }
     return SEER_OK;

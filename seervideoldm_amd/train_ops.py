@@ -162,17 +162,42 @@ def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
 
 def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, *, eps: float = 1e-5,
                   dres: Optional[torch.Tensor] = None, dx: Optional[torch.Tensor] = None,
-                  dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None,
+                  defer: Optional[list] = None) -> torch.Tensor:
+    """defer = a list: d gamma / d beta are left as partial slabs and (slabs, n, d beta, d gamma) is appended to it -- colfinal_grouped
+    adds the slabs of every norm on the list in one launch (same bits)."""
     _req(x, bf16, "x"); _req(dy, bf16, "dy"); _req(gamma, torch.float32, "gamma")
     assert x.dim() == 2 and x.stride(1) == 1 and dy.shape == x.shape and dy.stride(1) == 1
     rows, Cc = x.shape
     if dx is None:
         dx = torch.empty((rows, Cc), device=x.device, dtype=bf16)
     ws = _col_ws(rows, Cc, x.device) if dgamma is not None else None
+    if dgamma is not None and defer is not None:
+        _req(dgamma, torch.float32, "dgamma"); _req(dbeta, torch.float32, "dbeta")
+        assert dgamma.is_contiguous() and dbeta.is_contiguous() and dgamma.numel() == Cc and dbeta.numel() == Cc
+        lib = _lib.load()
+        check(lib.seer_layernorm_bwd_partials(_p(x), _p(dy), rows, Cc, x.stride(0), dy.stride(0), _p(gamma), float(eps),
+                                              _p(dres), 0 if dres is None else dres.stride(0), _p(dx), dx.stride(0), _p(ws), _stream()),
+              "seer_layernorm_bwd_partials")
+        defer.append((ws, int(lib.seer_layernorm_bwd_slabs(rows)), 2, Cc, dbeta, dgamma))
+        return dx
     check(_lib.load().seer_layernorm_bwd(_p(x), _p(dy), rows, Cc, x.stride(0), dy.stride(0), _p(gamma), float(eps),
                                          _p(dres), 0 if dres is None else dres.stride(0), _p(dx), dx.stride(0),
                                          _p(dgamma), _p(dbeta), _p(ws), _stream()), "seer_layernorm_bwd")
     return dx
+
+
+def colfinal_grouped(items) -> None:
+    """items: [(slabs [n][NV][C] fp32, n, NV, C, out0 [C] or None, out1 [C] or None), ...]: out_v = the sum of the slabs, every item in
+    one launch (seer_colfinal_grouped)"""
+    if not items:
+        return
+    arr = (_lib.ColfinalItem * len(items))()
+    for it, (ws, n, NV, Cc, o0, o1) in zip(arr, items):
+        _req(ws, torch.float32, "slabs")
+        assert ws.numel() >= n * NV * Cc
+        it.ws, it.out0, it.out1, it.nblocks, it.NV, it.C = _p(ws), _p(o0), _p(o1), n, NV, Cc
+    check(_lib.load().seer_colfinal_grouped(arr, len(items), _stream()), "seer_colfinal_grouped")
 
 
 def groupnorm_bwd(x1: torch.Tensor, x2: Optional[torch.Tensor], batch: int, groups: int, stats: torch.Tensor, count: float,

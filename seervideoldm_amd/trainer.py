@@ -174,6 +174,7 @@ class SeerTrainer:
         # where the walk reaches it)
         self._dw_deferred = os.environ.get("SEER_DW_GROUPED", "1") != "0" and hasattr(tops, "gemm_tn_grouped")
         self._dw: List[Tuple] = []
+        self._cf: Optional[List[Tuple]] = [] if self._dw_deferred and hasattr(tops, "colfinal_grouped") else None   # d gamma / d beta slabs of the LayerNorms, as the weight gradients
 
     # ================================================================================================ helpers
     def _frozenT(self, key: str) -> torch.Tensor:
@@ -222,6 +223,9 @@ class SeerTrainer:
         if self._dw:
             self.tops.gemm_tn_grouped(self._dw)
             self._dw = []
+        if self._cf:
+            self.tops.colfinal_grouped(self._cf)
+            self._cf = []
 
     def _cb(self, B):
         """`colsum_batch` of a launch whose output feeds a GroupNorm: accumulate into the step's arena when there is one"""
@@ -312,7 +316,7 @@ class SeerTrainer:
         dn3 = self._lin_bwd(P, W, w1, b1, n3, dpre)
         return tops.layernorm_bwd(hf, dn3, W[g3], dres=dout, dx=dx,
                                   dgamma=P.view(P.g, g3) if P is not None else None,
-                                  dbeta=P.view(P.g, b3) if P is not None else None)
+                                  dbeta=P.view(P.g, b3) if P is not None else None, defer=self._cf)
 
     @staticmethod
     def _unet_ff_names(tb):
@@ -470,7 +474,7 @@ class SeerTrainer:
         ops.rotary_inplace(dqkv, 0, C, self.eng.heads, d, rot_dim, tpb, self._conj(cs))      # R^T on dq, dk
         dn1 = self._lin_bwd(P, w, tb + ".attn1.qkv", None, n1, dqkv)
         dh0 = tops.layernorm_bwd(h0, dn1, w[tb + ".norm1.weight"], dres=dh1, dgamma=P.view(P.g, tb + ".norm1.weight"),
-                                 dbeta=P.view(P.g, tb + ".norm1.bias"))
+                                 dbeta=P.view(P.g, tb + ".norm1.bias"), defer=self._cf)
         dhn = self._lin_bwd(P, w, p + ".proj_in.weight", p + ".proj_in.bias", hn, dh0)
         dx, _ = self._gn_bwd(sg, dhn, dres1=dout)
         return dx
@@ -673,7 +677,7 @@ class SeerTrainer:
         tape, x_last, ctx, (b, Fr, l, C, heads, d, rot_dim, src) = saved
         G = lambda k: P.view(P.g, k)
         ffn = lambda p: (p + ".norm3.w", p + ".norm3.b", p + ".ff1.w", p + ".ff1.b", p + ".ff2.w", p + ".ff2.b")
-        dx = tops.layernorm_bwd(x_last, dy, W["norm.w"], dgamma=G("norm.w"), dbeta=G("norm.b"))
+        dx = tops.layernorm_bwd(x_last, dy, W["norm.w"], dgamma=G("norm.w"), dbeta=G("norm.b"), defer=self._cf)
         for entry in reversed(tape):
             if entry[0] == 1:
                 _, p, x3, m1, qkv_t, at, lset, kwt, cs, sff1 = entry
@@ -686,7 +690,7 @@ class SeerTrainer:
                                        dqkv[sl, :C], dqkv[sl, C:2 * C], dqkv[sl, 2 * C:], **kwt)
                 ops.rotary_inplace(dqkv, 0, C, heads, d, rot_dim, Fr * l, self._conj(cs))
                 dm1 = self._lin_bwd(P, W, p + ".attn1.qkv", None, m1, dqkv)
-                dx = tops.layernorm_bwd(x3, dm1, W[p + ".norm1.w"], dres=dx4, dgamma=G(p + ".norm1.w"), dbeta=G(p + ".norm1.b"))
+                dx = tops.layernorm_bwd(x3, dm1, W[p + ".norm1.w"], dres=dx4, dgamma=G(p + ".norm1.w"), dbeta=G(p + ".norm1.b"), defer=self._cf)
             else:
                 _, p, x0, n1, qkv, a1, lse1, kw1, x1, n2, q2, kv, a2, lse2, kw2, sff0 = entry
                 dx2 = self._ff_bwd(P, W, ffn(p), sff0, dx)
@@ -696,13 +700,13 @@ class SeerTrainer:
                 tops.attention_bwd(q2, kv[:, :C], kv[:, C:], a2, lse2, da2, dq2, dkv[:, :C], dkv[:, C:], **kw2)
                 self._lin_bwd(P, W, p + ".attn2.kv", None, ctx, dkv, need_dx=False)       # CLIP is frozen: no d ctx
                 dn2 = self._lin_bwd(P, W, p + ".attn2.q", None, n2, dq2)
-                dx1 = tops.layernorm_bwd(x1, dn2, W[p + ".norm2.w"], dres=dx2, dgamma=G(p + ".norm2.w"), dbeta=G(p + ".norm2.b"))
+                dx1 = tops.layernorm_bwd(x1, dn2, W[p + ".norm2.w"], dres=dx2, dgamma=G(p + ".norm2.w"), dbeta=G(p + ".norm2.b"), defer=self._cf)
                 da1 = self._lin_bwd(P, W, p + ".attn1.out.w", p + ".attn1.out.b", a1, dx1)
                 dqkv = torch.empty_like(qkv)
                 tops.attention_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], a1, lse1, da1, dqkv[:, :C], dqkv[:, C:2 * C],
                                    dqkv[:, 2 * C:], **kw1)
                 dn1 = self._lin_bwd(P, W, p + ".attn1.qkv", None, n1, dqkv)
-                dx = tops.layernorm_bwd(x0, dn1, W[p + ".norm1.w"], dres=dx1, dgamma=G(p + ".norm1.w"), dbeta=G(p + ".norm1.b"))
+                dx = tops.layernorm_bwd(x0, dn1, W[p + ".norm1.w"], dres=dx1, dgamma=G(p + ".norm1.w"), dbeta=G(p + ".norm1.b"), defer=self._cf)
         self._flush_dw()
         # token embeddings: learnable_query sees every row, pos_embed[src[f], :l] the rows of frame f summed over the batch
         tops.colsum(dx, out=G("learnable_query").reshape(-1))

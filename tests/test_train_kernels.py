@@ -210,6 +210,29 @@ def test_layernorm_bwd(device, rows, C, with_w, with_res):
         _rel(db, br.grad, 1e-3, "ln dbeta")
 
 
+def test_layernorm_bwd_deferred_finals_are_the_same_bits(device):
+    """d gamma / d beta left as partial slabs and added for MANY norms in one launch (seer_layernorm_bwd_partials +
+    seer_colfinal_grouped: the end of a backward walk) == one final launch per norm; more norms than one launch's table holds"""
+    from seervideoldm_amd import train_ops
+    shapes = [(924, 1024), (12288, 320), (3072, 640), (768, 1280), (100, 320), (8, 64), (9000, 1536)] + [(64 + 8 * i, 320) for i in range(70)]
+    queue, want, got = [], [], []
+    for i, (rows, C) in enumerate(shapes):
+        x = _rand((rows, C), device, 3 * i + 1, 2.0).to(bf16)
+        dy = _rand((rows, C), device, 3 * i + 2).to(bf16)
+        gamma = 1 + 0.2 * _rand((C,), device, 3 * i + 3)
+        dg, db = torch.zeros(C, device=device), torch.zeros(C, device=device)
+        dx = train_ops.layernorm_bwd(x, dy, gamma, dgamma=dg, dbeta=db)
+        dg2, db2 = torch.full((C,), float("nan"), device=device), torch.full((C,), float("nan"), device=device)
+        dx2 = train_ops.layernorm_bwd(x, dy, gamma, dgamma=dg2, dbeta=db2, defer=queue)
+        assert torch.equal(dx, dx2)
+        want.append((dg, db))
+        got.append((dg2, db2))
+    assert len(queue) == len(shapes) and torch.isnan(got[0][0]).all()
+    train_ops.colfinal_grouped(queue)
+    for (dg, db), (dg2, db2), sh in zip(want, got, shapes):
+        assert torch.equal(dg, dg2) and torch.equal(db, db2), sh
+
+
 @pytest.mark.parametrize("B,rows,C1,C2,silu,with_w", [(1, 256, 320, 0, True, False), (2, 192, 640, 0, False, True),
                                                       (1, 1024, 320, 320, True, False), (2, 48, 1280, 1280, True, True),
                                                       (1, 100, 640, 320, True, True), (1, 64, 128, 0, False, True)])

@@ -110,13 +110,24 @@ def colsum(x, out=None):
     return out
 
 
-def layernorm_bwd(x, dy, gamma, *, eps=1e-5, dres=None, dx=None, dgamma=None, dbeta=None):
+def colfinal_grouped(items):
+    for ws, n, NV, Cc, o0, o1 in items:
+        t = ws[:n * NV * Cc].reshape(n, NV, Cc).sum(0)
+        if o0 is not None:
+            o0.copy_(t[0])
+        if o1 is not None and NV > 1:
+            o1.copy_(t[1])
+
+
+def layernorm_bwd(x, dy, gamma, *, eps=1e-5, dres=None, dx=None, dgamma=None, dbeta=None, defer=None):
     xr = x.float().requires_grad_(True)
     g = gamma.detach().clone().requires_grad_(True)
     b = torch.zeros_like(g).requires_grad_(True)
     F.layer_norm(xr, (x.shape[1],), g, b, eps).backward(dy.float())
     r = xr.grad + (dres.float() if dres is not None else 0)
-    if dgamma is not None:
+    if dgamma is not None and defer is not None:         # one slab [1][2][C]: (d beta, d gamma)
+        defer.append((torch.stack([b.grad, g.grad]).reshape(-1), 1, 2, x.shape[1], dbeta, dgamma))
+    elif dgamma is not None:
         dgamma.copy_(g.grad)
         dbeta.copy_(b.grad)
     if dx is None:
