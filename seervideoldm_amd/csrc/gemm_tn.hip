@@ -135,7 +135,7 @@ __device__ __forceinline__ void tn_tile(bf16* imgA, bf16* imgB, const bf16* __re
         }
 }
 
-__global__ void __launch_bounds__(256) seer_gemm_tn_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb,
+__global__ void __launch_bounds__(256, 3) seer_gemm_tn_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb,
                                                            int M, int N, int K, int m_chunk, float* __restrict__ C, int64_t slice_stride,
                                                            float* __restrict__ colsum /* [N] per slice, or NULL */, int64_t colsum_stride) {
     __shared__ __attribute__((aligned(16))) bf16 imgA[TM * TRS];
@@ -161,7 +161,7 @@ struct TnGroup {
     int n;
 };
 
-__global__ void __launch_bounds__(256) seer_gemm_tn_grouped_kernel(const TnGroup g) {
+__global__ void __launch_bounds__(256, 3) seer_gemm_tn_grouped_kernel(const TnGroup g) {
     __shared__ __attribute__((aligned(16))) bf16 imgA[TM * TRS];
     __shared__ __attribute__((aligned(16))) bf16 imgB[TM * TRS];
     const int wg = blockIdx.x;

@@ -324,46 +324,61 @@ __global__ void __launch_bounds__(1024) colfinal_grouped_kernel(const CfGroup g)
 
 // GroupNorm backward, middle stage: the chunk partials of colpartial_kernel<2> (per (b, c): A = sum gy, Bv = sum gy xhat) -> per
 // (b, g) projections s1 = sum_c gamma_c A_bc, s2 = sum_c gamma_c B_bc (scaled by 1/count), and dgamma_c = sum_b B_bc,
-// dbeta_c = sum_b A_bc.  One block per group: 16 chunk lanes x 64 channel lanes add the partials (then in lane order: a fixed
+// dbeta_c = sum_b A_bc.  One block per group: chunk lanes x channel lanes add the partials (then a tree over the chunk lanes: a fixed
 // order), wave 0 forms the projections; cpg <= 128.  (This was a colfinal_kernel launch + a per-group kernel.)
+// CL = channel lanes (16 / 32 for groups of <= 16 / <= 32 channels, else 64 lanes x 2 channels): the other 1024 / CL lanes split the
+// chunks, so the narrow groups of the 32x32 level (10 channels, 1024 chunks) take 16 trips over the partials instead of 64
+template <int CL>
 __global__ void __launch_bounds__(1024) gn_bwd_group_fused_kernel(const float* __restrict__ ws, int nchunks, int batch, int C,
                                                                   int cpg, int groups, const float* __restrict__ gamma,
                                                                   float inv_count, float* __restrict__ proj,
                                                                   float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ float red[4][16][64];                 // [v + 2 k2][chunk lane][channel lane]
+    constexpr int KL = 1024 / CL, NK2 = CL == 64 ? 2 : 1;
+    __shared__ float red[2 * NK2][KL][CL];           // [v + 2 k2][chunk lane][channel lane]
     const int grp = blockIdx.x;
-    const int cl = threadIdx.x & 63, kl = threadIdx.x >> 6;
-    float dg[2] = {0.f, 0.f}, db[2] = {0.f, 0.f};
+    const int cl = threadIdx.x % CL, kl = threadIdx.x / CL;
+    float dg[NK2], db[NK2];
+#pragma unroll
+    for (int k2 = 0; k2 < NK2; ++k2) dg[k2] = db[k2] = 0.f;
     // grid.y = batch when no d gamma / d beta is asked for (nothing crosses batch items then), 1 otherwise
     for (int b = blockIdx.y; b < batch; b += gridDim.y) {
-        float s[4] = {0.f, 0.f, 0.f, 0.f};           // the four sums of this lane at once: independent loads in flight
+        float s[2 * NK2];                            // the sums of this lane at once: independent loads in flight
+#pragma unroll
+        for (int j = 0; j < 2 * NK2; ++j) s[j] = 0.f;
         const float* w = ws + ((int64_t)b * nchunks) * 2 * C + grp * cpg + cl;
-        const bool has0 = cl < cpg, has1 = cl + 64 < cpg;
-        for (int k = kl; k < nchunks; k += 16) {
+        const bool has0 = cl < cpg, has1 = NK2 == 2 && cl + 64 < cpg;
+        for (int k = kl; k < nchunks; k += KL) {
             const float* wk = w + (int64_t)k * 2 * C;
             if (has0) { s[0] += wk[0]; s[1] += wk[C]; }
-            if (has1) { s[2] += wk[64]; s[3] += wk[C + 64]; }
+            if constexpr (NK2 == 2) {
+                if (has1) { s[2] += wk[64]; s[3] += wk[C + 64]; }
+            }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) red[j][kl][cl] = s[j];
+        for (int j = 0; j < 2 * NK2; ++j) red[j][kl][cl] = s[j];
         __syncthreads();
+#pragma unroll
+        for (int h = KL / 2; h >= 1; h >>= 1) {      // chunk lanes: a tree in a fixed order
+            if (kl < h) {
+#pragma unroll
+                for (int j = 0; j < 2 * NK2; ++j) red[j][kl][cl] += red[j][kl + h][cl];
+            }
+            __syncthreads();
+        }
         if (threadIdx.x < 64) {
             float pa = 0.f, pb = 0.f;
+            if (threadIdx.x < CL) {
 #pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) {
-                const int c_local = cl + 64 * k2;
-                if (c_local < cpg) {
-                    float A = 0.f, Bv = 0.f;
-#pragma unroll
-                    for (int l = 0; l < 16; ++l) {
-                        A += red[2 * k2][l][cl];
-                        Bv += red[2 * k2 + 1][l][cl];
+                for (int k2 = 0; k2 < NK2; ++k2) {
+                    const int c_local = cl + 64 * k2;
+                    if (c_local < cpg) {
+                        const float A = red[2 * k2][0][cl], Bv = red[2 * k2 + 1][0][cl];
+                        const float gm = gamma[grp * cpg + c_local];
+                        pa += gm * A;
+                        pb += gm * Bv;
+                        dg[k2] += Bv;
+                        db[k2] += A;
                     }
-                    const float gm = gamma[grp * cpg + c_local];
-                    pa += gm * A;
-                    pb += gm * Bv;
-                    dg[k2] += Bv;
-                    db[k2] += A;
                 }
             }
             pa = wave_sum(pa);
@@ -375,9 +390,9 @@ __global__ void __launch_bounds__(1024) gn_bwd_group_fused_kernel(const float* _
         }
         __syncthreads();
     }
-    if (dgamma && threadIdx.x < 64) {
+    if (dgamma && threadIdx.x < CL) {
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
+        for (int k2 = 0; k2 < NK2; ++k2) {
             const int c_local = cl + 64 * k2;
             if (c_local < cpg) {
                 dgamma[grp * cpg + c_local] = dg[k2];
@@ -1004,8 +1019,13 @@ extern "C" int seer_groupnorm_bwd(const void* x1, int32_t C1, const void* x2, in
     const size_t lds = (size_t)g.rows_par * g.cpp * 16 * sizeof(float);
     hipLaunchKernelGGL(colpartial_kernel<2>, grid, dim3(256), lds, st, a, g, workspace);
     SEER_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gn_bwd_group_fused_kernel, dim3(groups, dgamma ? 1 : batch), dim3(1024), 0, st, workspace, g.nchunks, batch, C, a.cpg, groups,
-                       gamma, a.inv_count, proj, dgamma, dbeta);
+#define SEER_GNB_GROUP(CL)                                                                                                          \
+    hipLaunchKernelGGL(gn_bwd_group_fused_kernel<CL>, dim3(groups, dgamma ? 1 : batch), dim3(1024), 0, st, workspace, g.nchunks, batch, \
+                       C, a.cpg, groups, gamma, a.inv_count, proj, dgamma, dbeta)
+    if (a.cpg <= 16) SEER_GNB_GROUP(16);
+    else if (a.cpg <= 32) SEER_GNB_GROUP(32);
+    else SEER_GNB_GROUP(64);
+#undef SEER_GNB_GROUP
     SEER_LAUNCH_CHECK();
     hipLaunchKernelGGL(gn_bwd_apply_kernel, grid, dim3(256), 0, st, a, g, proj, reinterpret_cast<const bf16*>(dres1),
                        reinterpret_cast<const bf16*>(dres2), reinterpret_cast<bf16*>(dx1), reinterpret_cast<bf16*>(dx2));
