@@ -24,8 +24,17 @@ EXACT = False
 FX_SCALE = float(1 << 20)
 
 
+def _mm64(a, bt):
+    """[..., K] @ [K, N] in float64, one row at a time (a batched product of 1 x K rows): a float64 BLAS blocks by shape too -- a row
+    of `a @ bt` differs in its last bits with the number of rows beside it (measured: 2 of 6 row subsets of a 512-row product), and
+    once in many runs the difference crosses an fp32 rounding boundary and travels through the network"""
+    lead = a.shape[:-1]
+    a2 = a.double().reshape(-1, 1, a.shape[-1])
+    return torch.bmm(a2, bt.double().unsqueeze(0).expand(a2.shape[0], -1, -1)).reshape(*lead, bt.shape[1])
+
+
 def _mm(a, bt):
-    return (a.double() @ bt.double()).float() if EXACT else a @ bt
+    return _mm64(a, bt).float() if EXACT else a @ bt
 
 
 def _fx_sums(res, colsum_batch):
@@ -209,8 +218,10 @@ def conv3x3(x, w, n_img, Hin, Win, *, stride=1, upsample=False, bias=None, resid
     if upsample:
         xi = F.interpolate(xi, scale_factor=2.0, mode="nearest")
     wt = w.float().reshape(Co, 3, 3, Ci).permute(0, 3, 1, 2)
-    if EXACT:
-        y = F.conv2d(xi.double(), wt.double(), None, stride=stride, padding=1).float().permute(0, 2, 3, 1).reshape(-1, Co)
+    if EXACT:       # one image per call: the same shape whatever the number of images (frames) the rank holds
+        wd = wt.double()
+        y = torch.cat([F.conv2d(xi[i:i + 1].double(), wd, None, stride=stride, padding=1) for i in range(xi.shape[0])], 0)
+        y = y.float().permute(0, 2, 3, 1).reshape(-1, Co)
     else:
         y = F.conv2d(xi, wt, None, stride=stride, padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
     res = _epilogue(y, bias, False, rowvec, rows_per_batch, False, residual, False, out)
@@ -230,7 +241,7 @@ def conv_up2x(x, w4, n_img, Hin, Win, *, bias=None, out=None, tile=0, colsum_bat
             for ty in range(2):
                 for tx in range(2):
                     src = xi[:, a + ty:a + ty + Hin, b + tx:b + tx + Win, :]        # source (y + a - 1 + ty, x + b - 1 + tx)
-                    acc = acc + (src.double() @ wf[a * 2 + b, :, ty, tx, :].t().double() if EXACT else src @ wf[a * 2 + b, :, ty, tx, :].t())
+                    acc = acc + (_mm64(src, wf[a * 2 + b, :, ty, tx, :].t()) if EXACT else src @ wf[a * 2 + b, :, ty, tx, :].t())
             y[:, a::2, b::2, :] = acc.float() if EXACT else acc
     res = _epilogue(y.reshape(-1, Co), bias, False, None, 0, False, None, False, out)
     res.colsums = _fx_sums(res, colsum_batch)
@@ -401,7 +412,10 @@ def conv_in(x, w_khwc, bias):
     B, Cin, Fr, H, W = x.shape
     wt = w_khwc.permute(3, 2, 0, 1)
     xi = x.permute(0, 2, 1, 3, 4).reshape(B * Fr, Cin, H, W)
-    y = F.conv2d(xi.double(), wt.double(), bias.double(), padding=1).float() if EXACT else F.conv2d(xi, wt, bias, padding=1)
+    if EXACT:
+        y = torch.cat([F.conv2d(xi[i:i + 1].double(), wt.double(), bias.double(), padding=1) for i in range(xi.shape[0])], 0).float()
+    else:
+        y = F.conv2d(xi, wt, bias, padding=1)
     return y.permute(0, 2, 3, 1).reshape(-1, y.shape[1]).to(bf16)
 
 
@@ -411,7 +425,10 @@ def conv_out(x, w_ohwc, bias, B, Fr, H, W):
         w_ohwc = w_ohwc.float().reshape(w_ohwc.shape[0], 3, 3, C0)
     xi = x.float().reshape(B * Fr, H, W, C0).permute(0, 3, 1, 2)
     wt = w_ohwc.permute(0, 3, 1, 2)
-    y = F.conv2d(xi.double(), wt.double(), bias.double(), padding=1).float() if EXACT else F.conv2d(xi, wt, bias, padding=1)
+    if EXACT:
+        y = torch.cat([F.conv2d(xi[i:i + 1].double(), wt.double(), bias.double(), padding=1) for i in range(xi.shape[0])], 0).float()
+    else:
+        y = F.conv2d(xi, wt, bias, padding=1)
     return y.reshape(B, Fr, -1, H, W).permute(0, 2, 1, 3, 4).contiguous()
 
 
