@@ -1516,6 +1516,21 @@ int prepare(seer_gemm_desc& d, int* splits) {
             // runs a K tile no faster than two co-resident ones do): two K slices bring the second workgroup back.  3x3 convs only
             // (K >= 2880): 47.1 -> 44.9, 84.4 -> 76.8, 128.0 -> 103.5 us; the K = 1280 GEMM loses (profiles/r02_half_rows.log)
             const long t96160 = (long)((d.M + 95) / 96) * ((d.N + 159) / 160);
+            // Round 6, COLD weights (profiles/r06_lab_cold_weights.log: each launch of a shape reads another weight tensor, >= 400 MB in
+            // rotation, as inside the step, where a launch's weights were last touched 1.7 GB of other weights ago and come from HBM,
+            // not from the 256 MB memory-side cache a back-to-back sweep over ONE tensor reads them from): cold, every launch costs
+            // 3-15 us more, and the ranking moves towards FEWER workgroups re-reading a weight tile -- fewer K slices, wider tiles.
+            //  * the 4x4-level convs (384 rows): 96x160 tiles x 8 slices = 256 workgroups, ONE round (29.5 / 44.6 us cold against 36.1 /
+            //    48.2 for 128x128 x 16 slices; hot the two are level)
+            //  * a plain GEMM that took 4 slices of 128x128 (the 8x8-level ff.net.2 | proj_out, 1536 x 1280 x 6400): 2 slices (41.3
+            //    against 43.3 cold; 40.6 against 37.8 hot)
+            if (d.tile == SEER_TILE_AUTO && d.mode == SEER_GEMM_CONV3X3 && d.M <= 384 && d.N % 160 == 0 && nk >= 160 && t96160 <= 32) {
+                s = 8;
+                d.tile = SEER_TILE_G96x160_2;
+            } else if (s128 == 4 && d.mode == SEER_GEMM_PLAIN && t128 * 2 >= 200 && d.tile == SEER_TILE_AUTO) {
+                s = 2;
+                d.tile = SEER_TILE_G128x128_2;
+            } else
             if (s128 > 1 && t128 * s128 >= 200 && d.tile == SEER_TILE_AUTO) {
                 s = s128;
                 d.tile = SEER_TILE_G128x128_2;
@@ -1565,6 +1580,10 @@ int resolve_tile(const seer_gemm_desc& d) {
         }
         else if ((d.epilogue & SEER_EPI_ROTARY) && d.N == 1920 && nk >= 5 && (long)((d.M + 95) / 96) * 12 * d.batch >= 256)
             tile = SEER_TILE_G96x160_2;      // 6 144 x 1 920 x 640 rotary: 24.0 us against 26.8 on 128x128 (same log)
+        // (cold weights, r06_lab_cold_weights.log: with a short K loop the fuller last round of 96-row tiles does not pay for their extra
+        //  weight reads -- the 16x16-level q|k|v projection, 6144 x 1920 x 640: 21.5 us on 128x128 against 24.4 cold, 20.8 / 19.2 hot)
+        else if (t128 >= 256 && n_fits_128 && d.N >= 640 && nk <= 10 && d.mode == SEER_GEMM_PLAIN && !(d.epilogue & SEER_EPI_GEGLU))
+            tile = SEER_TILE_G128x128_2;
         else if (t128 >= 256 && n_fits_128 && d.N >= 640) {
             // 128x128, unless 96-row tiles leave the last round of resident workgroups (two per CU) clearly fuller: the q|k|v
             // projections of the 8x8 / 16x16 level are 360 / 720 tiles of 128 rows (0.70 of one / two rounds) but 480 / 960 of 96
@@ -1576,9 +1595,20 @@ int resolve_tile(const seer_gemm_desc& d) {
         // a conv whose 128x128 grid just misses one round of the chip but whose 96x128 grid fills it (the 16x16-level 320 -> 640
         // conv: 240 / 320 tiles): 34.5 against 45.0 us on 128x64 (profiles/r04_conv_tile_sweep.log); plain GEMMs of those sizes stay
         // on 128x64 (ff.net.2 at that level: 34.0 against 31.5, r04_ff2_tile_sweep.log)
+        // ... unless 96x160 tiles make exactly one round of the chip (that conv: 256 tiles; 35.0 against 41.7 us with cold weights,
+        // r06_lab_cold_weights.log)
+        else if (d.mode == SEER_GEMM_CONV3X3 && d.N % 160 == 0 && d.N >= 640 && nk >= 40 &&
+                 (long)((d.M + 95) / 96) * (d.N / 160) * d.batch >= 224 && (long)((d.M + 95) / 96) * (d.N / 160) * d.batch <= 256)
+            tile = SEER_TILE_G96x160_2;
         else if (d.mode == SEER_GEMM_CONV3X3 && n_fits_128 && d.N >= 640 && t128 >= 192 && nk >= 40 &&
                  (long)((d.M + 95) / 96) * ((d.N + 127) / 128) * d.batch >= 256)
             tile = SEER_TILE_G96x128_2;
+        // cold weights (r06_lab_cold_weights.log): a 128x128 grid that almost fills one round (200-255 tiles: the 16x16-level projections,
+        // shortcuts and ff.net.2 | proj_out, 6144 rows x 640) beats twice as many 128x64 tiles -- 10.2 / 16.5 / 22.0 / 34.1 us against 11.6 /
+        // 19.2 / 26.5 / 38.7 (hot: level); and where the 128x64 grid itself is 200-255 tiles (the 8x8-level projections and shortcuts,
+        // 1536 rows x 1280) it beats the 64x64 ring: 12.5 / 20.6 against 13.7 / 24.9
+        else if (d.mode == SEER_GEMM_PLAIN && n_fits_128 && d.N >= 640 && t128 >= 200 && nk >= 10) tile = SEER_TILE_G128x128_2;
+        else if (d.mode == SEER_GEMM_PLAIN && t12864 >= 200 && t12864 < 256 && nk >= 12) tile = SEER_TILE_G128x64_3;
         else if (t12864 >= 256 && nk >= 5) tile = SEER_TILE_G128x64_3;   // (K = 320 too: 8.9 vs 9.7 us on 12 288 x 320, r02_half_rows.log)
         else if (nk >= 64) tile = SEER_TILE_G64x64_5;        // long K on few tiles: deeper ring (see prepare(), unsplit_ring)
         else if (nk >= 12) tile = SEER_TILE_G64x64_3;
