@@ -1524,8 +1524,10 @@ int prepare(seer_gemm_desc& d, int* splits) {
             //    48.2 for 128x128 x 16 slices; hot the two are level)
             //  * a plain GEMM that took 4 slices of 128x128 (the 8x8-level ff.net.2 | proj_out, 1536 x 1280 x 6400): 2 slices (41.3
             //    against 43.3 cold; 40.6 against 37.8 hot)
+            //    (fewer rows -- a rank's share of the frames -- keep the one round: 256 / tiles slices, each >= 11 K tiles)
             if (d.tile == SEER_TILE_AUTO && d.mode == SEER_GEMM_CONV3X3 && d.M <= 384 && d.N % 160 == 0 && nk >= 160 && t96160 <= 32) {
-                s = 8;
+                s = (int)(256 / t96160);
+                while (s > 1 && nk / s < 11) s >>= 1;
                 d.tile = SEER_TILE_G96x160_2;
             } else if (s128 == 4 && d.mode == SEER_GEMM_PLAIN && t128 * 2 >= 200 && d.tile == SEER_TILE_AUTO) {
                 s = 2;
