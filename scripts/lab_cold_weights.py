@@ -75,34 +75,39 @@ def run(kind, name, dims, variants, **kw):
     (conv_case if kind == "conv" else gemm_case)(name, *dims, variants, **kw)
 
 
-print("us per launch, hot / cold weights, per (tile, splits); tiles: 0 auto, 5 128x128/2 stages, 16 96x160/2, 18 96x128/2, 12 128x160/2, "
-      "8 / 10 64x64 with 3 / 5 stages, 7 128x64/3, 14 256x128/2")
-C4 = [(0, 0), (5, 8), (5, 16), (16, 4), (16, 8), (16, 12), (16, 16), (18, 8), (12, 8), (14, 8)]
-run("conv", "conv 4x4 1280->1280", (24, 4, 1280, 1280), C4)
-run("conv", "conv 4x4 2560->1280", (24, 4, 2560, 1280), C4)
-C8 = [(0, 0), (5, 2), (5, 4), (16, 2), (16, 4), (18, 2), (18, 4), (12, 2), (12, 4), (14, 4)]
-run("conv", "conv 8x8 1280->1280", (24, 8, 1280, 1280), C8)
-run("conv", "conv 8x8 2560->1280", (24, 8, 2560, 1280), C8)
-run("conv", "conv 8x8 1920->1280", (24, 8, 1920, 1280), C8)
-run("conv", "conv 8x8 640->1280", (24, 8, 640, 1280), C8)
-C16 = [(0, 0), (5, 1), (5, 2), (16, 1), (16, 2), (18, 1), (18, 2), (12, 1), (12, 2), (14, 2)]
-run("conv", "conv 16x16 640->640", (24, 16, 640, 640), C16)
-run("conv", "conv 16x16 1280->640", (24, 16, 1280, 640), C16)
-run("conv", "conv 16x16 1920->640", (24, 16, 1920, 640), C16)
-run("conv", "conv 16x16 960->640", (24, 16, 960, 640), C16)
-run("conv", "conv 16x16 320->640", (24, 16, 320, 640), C16)
-GV = [(0, 0), (8, 1), (10, 1), (7, 1), (5, 1), (18, 1), (12, 1), (5, 2), (5, 4), (8, 4)]
-print()
-for nm, dims in (("L2 proj 1536x1280x1280", (1536, 1280, 1280)), ("L2 qkv 1536x3840x1280", (1536, 3840, 1280)),
-                 ("L2 ff2 1536x1280x6400", (1536, 1280, 6400)), ("L2 shortcut 1536x1280x2560", (1536, 1280, 2560)),
-                 ("L1 proj 6144x640x640", (6144, 640, 640)), ("L1 qkv 6144x1920x640", (6144, 1920, 640)),
-                 ("L1 ff2 6144x640x3200", (6144, 640, 3200)), ("L1 shortcut 6144x640x1280", (6144, 640, 1280)),
-                 ("L1 shortcut 6144x640x1920", (6144, 640, 1920)),
-                 ("mid proj 384x1280x1280", (384, 1280, 1280)), ("mid qkv 384x3840x1280", (384, 3840, 1280)),
-                 ("mid ff2 384x1280x6400", (384, 1280, 6400)), ("L3 shortcut 384x1280x2560", (384, 1280, 2560))):
-    run("gemm", nm, dims, GV)
-GG = [(0, 0), (5, 1), (18, 1), (12, 1), (7, 1), (19, 1), (20, 1)]
-print("\nGEGLU projections (tile 19 = weight-stationary, 20 = AUTO restricted to the tile kernels)")
-for nm, dims in (("L1 ff1 geglu 6144x5120x640", (6144, 5120, 640)), ("L2 ff1 geglu 1536x10240x1280", (1536, 10240, 1280)),
-                 ("mid ff1 geglu 384x10240x1280", (384, 10240, 1280))):
-    run("gemm", nm, dims, GG, geglu=True)
+def main():
+    print("us per launch, hot / cold weights, per (tile, splits); tiles: 0 auto, 5 128x128/2 stages, 16 96x160/2, 18 96x128/2, 12 128x160/2, "
+          "8 / 10 64x64 with 3 / 5 stages, 7 128x64/3, 14 256x128/2")
+    C4 = [(0, 0), (5, 8), (5, 16), (16, 4), (16, 8), (16, 12), (16, 16), (18, 8), (12, 8), (14, 8)]
+    run("conv", "conv 4x4 1280->1280", (24, 4, 1280, 1280), C4)
+    run("conv", "conv 4x4 2560->1280", (24, 4, 2560, 1280), C4)
+    C8 = [(0, 0), (5, 2), (5, 4), (16, 2), (16, 4), (18, 2), (18, 4), (12, 2), (12, 4), (14, 4)]
+    run("conv", "conv 8x8 1280->1280", (24, 8, 1280, 1280), C8)
+    run("conv", "conv 8x8 2560->1280", (24, 8, 2560, 1280), C8)
+    run("conv", "conv 8x8 1920->1280", (24, 8, 1920, 1280), C8)
+    run("conv", "conv 8x8 640->1280", (24, 8, 640, 1280), C8)
+    C16 = [(0, 0), (5, 1), (5, 2), (16, 1), (16, 2), (18, 1), (18, 2), (12, 1), (12, 2), (14, 2)]
+    run("conv", "conv 16x16 640->640", (24, 16, 640, 640), C16)
+    run("conv", "conv 16x16 1280->640", (24, 16, 1280, 640), C16)
+    run("conv", "conv 16x16 1920->640", (24, 16, 1920, 640), C16)
+    run("conv", "conv 16x16 960->640", (24, 16, 960, 640), C16)
+    run("conv", "conv 16x16 320->640", (24, 16, 320, 640), C16)
+    GV = [(0, 0), (8, 1), (10, 1), (7, 1), (5, 1), (18, 1), (12, 1), (5, 2), (5, 4), (8, 4)]
+    print()
+    for nm, dims in (("L2 proj 1536x1280x1280", (1536, 1280, 1280)), ("L2 qkv 1536x3840x1280", (1536, 3840, 1280)),
+                     ("L2 ff2 1536x1280x6400", (1536, 1280, 6400)), ("L2 shortcut 1536x1280x2560", (1536, 1280, 2560)),
+                     ("L1 proj 6144x640x640", (6144, 640, 640)), ("L1 qkv 6144x1920x640", (6144, 1920, 640)),
+                     ("L1 ff2 6144x640x3200", (6144, 640, 3200)), ("L1 shortcut 6144x640x1280", (6144, 640, 1280)),
+                     ("L1 shortcut 6144x640x1920", (6144, 640, 1920)),
+                     ("mid proj 384x1280x1280", (384, 1280, 1280)), ("mid qkv 384x3840x1280", (384, 3840, 1280)),
+                     ("mid ff2 384x1280x6400", (384, 1280, 6400)), ("L3 shortcut 384x1280x2560", (384, 1280, 2560))):
+        run("gemm", nm, dims, GV)
+    GG = [(0, 0), (5, 1), (18, 1), (12, 1), (7, 1), (19, 1), (20, 1)]
+    print("\nGEGLU projections (tile 19 = weight-stationary, 20 = AUTO restricted to the tile kernels)")
+    for nm, dims in (("L1 ff1 geglu 6144x5120x640", (6144, 5120, 640)), ("L2 ff1 geglu 1536x10240x1280", (1536, 10240, 1280)),
+                     ("mid ff1 geglu 384x10240x1280", (384, 10240, 1280))):
+        run("gemm", nm, dims, GG, geglu=True)
+
+
+if "--import-only" not in sys.argv:
+    main()

@@ -1510,8 +1510,12 @@ int prepare(seer_gemm_desc& d, int* splits) {
             // against 40.0: profiles/r04_ff2_tile_sweep.log)
             const bool unsplit_ring = false;
             int s128 = 1;
+            // (cold weights, r06_lab_cold_weights.log / r06_lab_cold_train.log: a PLAIN product is sliced to ONE round of the chip, not two
+            //  -- 1536 x 1280 x 6400: 2 slices 41.3 against 43.3 us for 4; 768 x 1280 x 10240: 4 slices 37.0 against 45.3 for 8; 924 x 768 x
+            //  6144: 4 slices 23.8 against 30.7 -- while the convs, whose slices are ten times longer, keep two)
+            const long split_target = d.mode == SEER_GEMM_PLAIN ? 180 : 400, split_accept = d.mode == SEER_GEMM_PLAIN ? 180 : 200;
             if (d.N % 128 == 0 && d.N >= 640 && d.M >= 256 && t128 < 256 && nk >= 64 && !unsplit_ring)
-                while (t128 * s128 < 400 && s128 < 16 && nk / (2 * s128) >= 11) s128 *= 2;
+                while (t128 * s128 < split_target && s128 < 16 && nk / (2 * s128) >= 11) s128 *= 2;
             // N = 320 on half the rows (one CFG half per rank: 12 288 rows = 256 tiles of 96x160, one lone workgroup per CU, which
             // runs a K tile no faster than two co-resident ones do): two K slices bring the second workgroup back.  3x3 convs only
             // (K >= 2880): 47.1 -> 44.9, 84.4 -> 76.8, 128.0 -> 103.5 us; the K = 1280 GEMM loses (profiles/r02_half_rows.log)
@@ -1522,18 +1526,13 @@ int prepare(seer_gemm_desc& d, int* splits) {
             // 3-15 us more, and the ranking moves towards FEWER workgroups re-reading a weight tile -- fewer K slices, wider tiles.
             //  * the 4x4-level convs (384 rows): 96x160 tiles x 8 slices = 256 workgroups, ONE round (29.5 / 44.6 us cold against 36.1 /
             //    48.2 for 128x128 x 16 slices; hot the two are level)
-            //  * a plain GEMM that took 4 slices of 128x128 (the 8x8-level ff.net.2 | proj_out, 1536 x 1280 x 6400): 2 slices (41.3
-            //    against 43.3 cold; 40.6 against 37.8 hot)
             //    (fewer rows -- a rank's share of the frames -- keep the one round: 256 / tiles slices, each >= 11 K tiles)
             if (d.tile == SEER_TILE_AUTO && d.mode == SEER_GEMM_CONV3X3 && d.M <= 384 && d.N % 160 == 0 && nk >= 160 && t96160 <= 32) {
                 s = (int)(256 / t96160);
                 while (s > 1 && nk / s < 11) s >>= 1;
                 d.tile = SEER_TILE_G96x160_2;
-            } else if (s128 == 4 && d.mode == SEER_GEMM_PLAIN && t128 * 2 >= 200 && d.tile == SEER_TILE_AUTO) {
-                s = 2;
-                d.tile = SEER_TILE_G128x128_2;
             } else
-            if (s128 > 1 && t128 * s128 >= 200 && d.tile == SEER_TILE_AUTO) {
+            if (s128 > 1 && t128 * s128 >= split_accept && d.tile == SEER_TILE_AUTO) {
                 s = s128;
                 d.tile = SEER_TILE_G128x128_2;
             } else if (d.N == 320 && d.mode == SEER_GEMM_CONV3X3 && t96160 >= 128 && t96160 <= 256 && nk >= 40 &&
@@ -1566,7 +1565,11 @@ int resolve_tile(const seer_gemm_desc& d) {
         const int n128 = (d.N + 127) / 128 * 128;
         const bool n_fits_128 = (n128 - d.N) * 8 <= d.N;           // <= 12.5 % padded columns
         const long t128160 = (long)((d.M + 127) / 128) * ((d.N + 159) / 160) * d.batch;
-        if ((d.N == 320 || d.N == 960) && nk >= 5 && t128160 >= 256 && !(d.epilogue & SEER_EPI_GEGLU)) {
+        const long t96160_ = (long)((d.M + 95) / 96) * ((d.N + 159) / 160) * d.batch;
+        // (12 288 rows x 320 -- one CFG half, or the b = 1 fine-tuning step -- are 256 tiles of 96x160: one round; 16.2 / 28.6 / 12.9 us
+        //  against 19.6 / 33.9 / 15.1 on 128x64 with cold weights, r06_lab_cold_train.log)
+        if ((d.N == 320 || d.N == 960) && nk >= 5 && (t128160 >= 256 || (d.N == 320 && t96160_ >= 224 && t96160_ <= 256)) &&
+            !(d.epilogue & SEER_EPI_GEGLU)) {
             // (with the fast epilogue the 160-wide tiles also win at K = 320 .. 960, where the register-staged 64x64 tile used to:
             //  projections of the 320-wide level 17.5 -> 15.6 / 14.4 -> 12.0 us, its 1x1 shortcuts 20.0 -> 16.2 / 26.5 -> 20.6, and
             //  its q|k|v projection, N = 960 = 6 x 160, 32.7 (weight-stationary) -> 26.4: profiles/r02_tile_sweep_fastepi.log)
@@ -1610,7 +1613,10 @@ int resolve_tile(const seer_gemm_desc& d) {
         // 19.2 / 26.5 / 38.7 (hot: level); and where the 128x64 grid itself is 200-255 tiles (the 8x8-level projections and shortcuts,
         // 1536 rows x 1280) it beats the 64x64 ring: 12.5 / 20.6 against 13.7 / 24.9
         else if (d.mode == SEER_GEMM_PLAIN && n_fits_128 && d.N >= 640 && t128 >= 200 && nk >= 10) tile = SEER_TILE_G128x128_2;
-        else if (d.mode == SEER_GEMM_PLAIN && t12864 >= 200 && t12864 < 256 && nk >= 12) tile = SEER_TILE_G128x64_3;
+        else if (d.mode == SEER_GEMM_PLAIN && n_fits_128 && d.N >= 640 && t128 < 200 && nk >= 10 &&
+                 (long)((d.M + 95) / 96) * ((d.N + 127) / 128) * d.batch >= 200 && (long)((d.M + 95) / 96) * ((d.N + 127) / 128) * d.batch <= 256)
+            tile = SEER_TILE_G96x128_2;         // 768 x 3840 x 1280 (b = 1 step, 8x8 level): 240 tiles, 14.9 against 20.6 us cold on 128x64
+        else if (d.mode == SEER_GEMM_PLAIN && t12864 >= 200 && t12864 < 256 && nk >= 10) tile = SEER_TILE_G128x64_3;   // (3072 x 640 x 640: 7.7 against 10.5)
         else if (t12864 >= 256 && nk >= 5) tile = SEER_TILE_G128x64_3;   // (K = 320 too: 8.9 vs 9.7 us on 12 288 x 320, r02_half_rows.log)
         else if (nk >= 64) tile = SEER_TILE_G64x64_5;        // long K on few tiles: deeper ring (see prepare(), unsplit_ring)
         else if (nk >= 12) tile = SEER_TILE_G64x64_3;
