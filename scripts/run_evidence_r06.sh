@@ -32,6 +32,7 @@ python scripts/bench_vendor_gemm.py > $O/r06_vendor_gemm_calibration.log 2>&1
 python scripts/lab_ff_fused.py > $O/r06_lab_ff_fused.log 2>&1
 python scripts/exp_shard_sizes.py > $O/r06_shard_sizes.log 2>&1
 python scripts/lab_rowchain.py > $O/r06_lab_rowchain.log 2>&1
+python scripts/lab_ff_pre.py > $O/r06_lab_ff_pre.log 2>&1
 python scripts/exp_fixed_vs_variable.py > $O/r06_fixed_vs_variable.md 2>&1
 # 4c. the fp16-storage engine (the mixed_precision every shipped yaml names): the same bench line, an extra measurement
 python bench.py --dtype fp16 --no-cpu-baseline --no-train 2>/dev/null | cut -c1-6000 > $O/r06_bench_fp16.json.log
@@ -45,6 +46,10 @@ S4=$(ls $O/rocprof4/*/*_kernel_stats.csv | head -1)
 python scripts/rocprof_summary.py $S4 63 > $O/r06_rocprof_summary_config4.md 2>&1
 rm -rf $O/rocprof4
 tail -c 600 $O/r06_bench_final.json.log; cat $O/r06_step_timeline.md | head -12; cat $O/r06_shard_sizes.log
+# 6b. the fine-tuning step: grouped against per-layer weight gradients, and one steady-state step by kernel family
+bash scripts/ab_train_dw.sh > $O/r06_train_dw_grouped.log 2>&1
+bash scripts/run_train_profile.sh > /dev/null 2>&1
+cp $R/gpurun_out/r06t/r06_train_step_profile.md $O/r06_train_step_profile.md
 # 7. the whole GPU suite and the smoke test on the same tree
 python -m pytest tests -m gpu -q --durations=25 > $O/r06_gpu_tests.log 2>&1; echo "pytest rc $?" >> $O/r06_gpu_tests.log
 python -c "import __graft_entry__ as g; g.smoke()" >> $O/r06_gpu_tests.log 2>&1; echo "smoke rc $?" >> $O/r06_gpu_tests.log
