@@ -1535,7 +1535,9 @@ int prepare(seer_gemm_desc& d, int* splits) {
             if (s128 > 1 && t128 * s128 >= split_accept && d.tile == SEER_TILE_AUTO) {
                 s = s128;
                 d.tile = SEER_TILE_G128x128_2;
-            } else if (d.N == 320 && d.mode == SEER_GEMM_CONV3X3 && t96160 >= 128 && t96160 <= 256 && nk >= 40 &&
+            // (with COLD weights the 320 -> 320 conv, K = 2880, is faster unsplit -- 34.8 against 40.6 us -- and the longer ones keep their
+            //  two slices: 60.9 against 63.7, 81.3 against 91.7; profiles/r06_lab_cold_train_convs.log)
+            } else if (d.N == 320 && d.mode == SEER_GEMM_CONV3X3 && t96160 >= 128 && t96160 <= 256 && nk >= 80 &&
                        d.tile == SEER_TILE_AUTO) {
                 s = 2;
                 d.tile = SEER_TILE_G96x160_2;
