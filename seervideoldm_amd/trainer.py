@@ -774,6 +774,9 @@ class SeerTrainer:
     def _phase_a(self, model_input, target, timesteps, text_cond_emb, cond_frames):
         b, _, Fr, _, _ = model_input.shape
         assert self.fstext.num_frames == Fr, "fstext.set_numframe(F) first (train.py:187)"
+        self._dw = []                              # (a walk that raised half way must not leave its queue to the next step)
+        if self._cf is not None:
+            self._cf = []
         self._wt_plan.run()
         y, fs_saved = self._fstext_fwd(text_cond_emb)                     # [b*F*l, Dc] bf16, rows (b, f, l)
         t = timesteps if torch.is_tensor(timesteps) else torch.tensor([timesteps] * b)
