@@ -137,7 +137,9 @@ __global__ void __launch_bounds__(64 * WM * WN) seer_gemm_kernel(const seer_gemm
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
     }
 #ifndef SEER_GEMM_GM
-#define SEER_GEMM_GM 8          // M tiles per block group (sweep: profiles/r01_gemm_group_sweep.log)
+#define SEER_GEMM_GM 4          // M tiles per block group (round 1 chose 8 from a back-to-back sweep, profiles/r01_gemm_group_sweep.log; inside the
+                               // step -- cold operands -- 4 is the best of 1, 2, 3, 4, 6, 8, 16, 32: 9.59 against 9.64 ms and 9.77 against 9.81 on two
+                               // boxes, profiles/r06_gemm_group_in_step.log)
 #endif
     constexpr int GM = SEER_GEMM_GM;
     const int group = wg / (GM * tiles_n);
