@@ -148,3 +148,32 @@ def test_text_loss_option(setup):
     num = sum(((got[k].reshape(gf[k].shape) - gf[k]) ** 2).sum() for k in gf) ** 0.5
     den = sum((gf[k] ** 2).sum() for k in gf) ** 0.5
     assert num / den < 3e-2, float(num / den)
+
+
+def test_deferred_weight_gradients_are_final_at_the_hook_and_equal_the_immediate_ones(setup, monkeypatch):
+    """the weight gradients (and the LayerNorms' d gamma / d beta finals) of a backward walk wait for its end and go out as one group
+    (_lin_bwd / _flush_dw): (1) the same gradients as with one launch per layer (SEER_DW_GROUPED=0); (2) the UNet's gradient segment is
+    complete when `on_unet_grads` runs -- a data-parallel step starts its all-reduce there (start_unet_allreduce) -- and the
+    FSTextTransformer walk does not touch it afterwards; (3) no queue entry outlives the step"""
+    usd, fsd, unet, fst = setup
+    B, Fr, cond, H = 1, 3, 1, 8
+    fst.set_numframe(Fr)
+    x, noise, text = _randn((B, 4, Fr, H, H), 1), _randn((B, 4, Fr - cond, H, H), 2), _randn((B, 77, 192), 3)
+    t = torch.tensor([417])
+    tr = SeerTrainer(unet, fst, ops=tob, tops=ttob, **HP)
+    assert tr._dw_deferred and tr._cf is not None
+    seen = {}
+    calls = []
+    real = ttob.gemm_tn_grouped
+    monkeypatch.setattr(ttob, "gemm_tn_grouped", lambda probs: (calls.append(len(probs)), real(probs))[1])
+    tr.forward_backward(x, noise, t, text, cond, on_unet_grads=lambda: seen.update(gu=tr.pu.g.clone(), gf=tr.pf.g.clone()))
+    assert calls and len(calls) == 2 and min(calls) > 1, calls          # one group per walk (UNet, FSTextTransformer), many layers each
+    assert not tr._dw and not tr._cf
+    assert torch.equal(seen["gu"], tr.pu.g), "the UNet segment changed after the hook"
+    assert not torch.equal(seen["gf"], tr.pf.g)                          # ... while the FSTextTransformer segment was still to come
+    monkeypatch.setenv("SEER_DW_GROUPED", "0")
+    tr0 = SeerTrainer(unet, fst, ops=tob, tops=ttob, **HP)
+    assert not tr0._dw_deferred
+    tr0.forward_backward(x, noise, t, text, cond)
+    assert torch.equal(tr0.pu.g, tr.pu.g) and torch.equal(tr0.pf.g, tr.pf.g)
+    assert len(calls) == 2
