@@ -772,6 +772,57 @@ def test_fused_feed_forward_switch(device, monkeypatch):
     assert rel < 2e-2, rel
 
 
+def test_row_chain_and_feed_forward_prologue_switches(device, monkeypatch):
+    """the row-owning launches of the 320-channel level in the engine: GroupNorm -> proj_in -> norm1 -> q|k|v and attn1.to_out + residual
+    -> norm2 -> attn2.to_q as one launch each (ops.rowchain), the block's last to_out + residual as the prologue of the fused
+    feed-forward (ops.ff_fused(pre=...)); model.rowchain = False / SEER_FF_PRE=0 run the launches they replace.  Every form lands on the
+    oracle, next to the others.  (Row thresholds lowered so that the small test network takes the launches at its finest level; the
+    full-size tests take them by ops.rowchain_pays / ops.ff_fused_pays.)"""
+    from seervideoldm_amd import ops
+    monkeypatch.setattr(ops, "ff_fused_pays", lambda rows, n_cu=256: rows >= 6144)
+    monkeypatch.setattr(ops, "rowchain_pays", lambda rows, n_cu=None, products=4: rows >= 6144)
+    cfg, sd, m = _model("mini", device)
+    x, ctx, t = _randn((2, 4, 3, 32, 32), 25), _randn((2, 3, 77, cfg["cross_attention_dim"]), 26), torch.tensor([400, 400])
+    ref = O.unet_forward(sd, cfg, x, t, ctx, cond_frame=1)
+    real_rc, real_ff, n = ops.rowchain, ops.ff_fused, {"rc": 0, "pre": 0, "ff": 0}
+
+    def rc(*a, **k):
+        r = real_rc(*a, **k)
+        n["rc"] += r is not None
+        return r
+
+    def ff(*a, **k):
+        y = real_ff(*a, **k)
+        n["ff"] += y is not None
+        n["pre"] += y is not None and k.get("pre") is not None
+        return y
+    monkeypatch.setattr(ops, "rowchain", rc)
+    monkeypatch.setattr(ops, "ff_fused", ff)
+    outs, counts = {}, {}
+    for name, chain, pre in (("chains + prologue", True, "1"), ("chains", True, "0"), ("neither", False, "1")):
+        monkeypatch.setenv("SEER_FF_PRE", pre)
+        for k in n:
+            n[k] = 0
+        m._engine = None
+        m.rowchain = chain
+        try:
+            outs[name] = m(x.to(device), t.to(device), ctx.to(device), cond_frame=1).clone()
+        finally:
+            del m.rowchain
+            m._engine = None
+        counts[name] = dict(n)
+        _check(outs[name], ref, f"unet {name}")
+    # the 32x32 level of the mini network: a text and a temporal block in 1 down + 2 up layers.  Text block: two chains + the fused
+    # feed-forward; temporal block: one chain -- its feed-forward skips the conditioning frame's rows (4096 of 6144 left: below the
+    # threshold set above, the unfused launches)
+    assert counts["chains + prologue"] == {"rc": 3 * 3, "pre": 3, "ff": 3}, counts
+    assert counts["chains"] == {"rc": 3 * 3, "pre": 0, "ff": 3}, counts
+    assert counts["neither"] == {"rc": 0, "pre": 0, "ff": 3}, counts
+    for a in ("chains", "neither"):
+        rel = ((outs["chains + prologue"].float() - outs[a].float()).norm() / outs[a].float().norm()).item()
+        assert rel < 2e-2, (a, rel)
+
+
 def test_statistics_forms_fall_back_and_agree(device, monkeypatch):
     """The accumulated GroupNorm statistics and the folded LayerNorm are optimisations with fall-backs: an arena that runs out hands
     later producers the per-tile form (a GroupNorm whose two sources then disagree on the form takes the statistics pass), and every
