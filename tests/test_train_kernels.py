@@ -414,7 +414,7 @@ def test_gemm_tn_grouped(device):
     bits do not depend on its companions"""
     from seervideoldm_amd import train_ops
     shapes = [(924, 768, 768), (12288, 960, 320), (1536, 320, 1280), (160, 1280, 1280), (100, 2560, 320), (3072, 640, 2560),
-              (64, 8, 8), (1000, 136, 72), (2049, 320, 320), (4096, 128, 136)]
+              (64, 8, 8), (1000, 136, 72), (2049, 320, 320), (4096, 128, 136), (20000, 136, 128), (40000, 64, 72)]   # > 16 384 rows: K slices
     shapes = shapes + [(192 + 64 * i, 320, 320) for i in range(45)]              # 55 problems: two launches
     probs, refs = [], []
     for i, (M, N, K) in enumerate(shapes):
@@ -430,7 +430,7 @@ def test_gemm_tn_grouped(device):
         if cs is not None:
             _rel(cs, rc, 1e-5, f"gemm_tn_grouped colsum {sh}")
     # alone, in another order, beside other problems: the same bits
-    for i in (1, 8, 0, 30):
+    for i in (1, 8, 0, 30, 10, 11):
         dy, x, out, cs = probs[i]
         o2 = torch.empty_like(out)
         c2 = torch.empty_like(cs) if cs is not None else None
