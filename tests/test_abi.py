@@ -77,6 +77,21 @@ def test_argument_validation_without_gpu(lib_path):
     r.gn_stats = r.gn_gamma = r.gn_beta = 16
     r.gn_count, r.groups, r.rows_per_batch = 500.0, 32, 50           # a 96-row tile would span three batch elements
     assert lib.seer_rowchain_c320(ctypes.byref(r), None) == -38
+    # grouped training entries: host tables are checked item by item before anything is launched
+    assert lib.seer_gemm_tn_grouped_f32(None, 0, None, 0, None) == -22 and lib.seer_colfinal_grouped(None, 0, None) == -22
+    assert lib.seer_layernorm_bwd_slabs(0) == -22 and lib.seer_layernorm_bwd_slabs(100) == 13 and lib.seer_layernorm_bwd_slabs(10 ** 6) == 1024
+    items = (_lib.TnItem * 2)()
+    for it in items:
+        it.A = it.B = it.C = 16
+        it.lda, it.ldb, it.M, it.N, it.K = 320, 320, 4096, 320, 320
+    assert lib.seer_gemm_tn_grouped_workspace_bytes(items, 2) == 0                  # unsplit up to 16 384 rows: no workspace
+    items[1].M = 40000                                                           # three K slices of [N*K + N] floats
+    assert lib.seer_gemm_tn_grouped_workspace_bytes(items, 2) == 3 * (320 * 320 + 320) * 4
+    items[1].lda = 100                                                           # row pitch below N
+    assert lib.seer_gemm_tn_grouped_workspace_bytes(items, 2) == -22 and lib.seer_gemm_tn_grouped_f32(items, 2, None, 0, None) == -22
+    cf = (_lib.ColfinalItem * 1)()
+    cf[0].ws, cf[0].nblocks, cf[0].NV, cf[0].C = 16, 4, 3, 320                     # NV is 1 or 2
+    assert lib.seer_colfinal_grouped(cf, 1, None) == -22
 
 
 def test_header_is_plain_c_and_the_c_caller_links(lib_path):

@@ -228,7 +228,13 @@ def test_layernorm_bwd_deferred_finals_are_the_same_bits(device):
         want.append((dg, db))
         got.append((dg2, db2))
     assert len(queue) == len(shapes) and torch.isnan(got[0][0]).all()
+    # one-value slabs (NV = 1: column sums) ride in the same launch
+    slabs = _rand((37, 1, 200), device, 999)
+    col = torch.full((200,), float("nan"), device=device)
+    queue.append((slabs.reshape(-1), 37, 1, 200, col, None))
     train_ops.colfinal_grouped(queue)
+    _rel(col, slabs.sum((0, 1)), 1e-6, "colfinal NV=1")
+    queue.pop()
     for (dg, db), (dg2, db2), sh in zip(want, got, shapes):
         assert torch.equal(dg, dg2) and torch.equal(db, db2), sh
 
